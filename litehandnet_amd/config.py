@@ -1,0 +1,47 @@
+"""Attribute-dict config, reading the same keys as the reference's experiment files.
+
+The reference loads python-dict configs into `addict.Dict` (config/__init__.py:27-39);
+`addict` is not a dependency here, so this is the minimal stand-in: attribute access,
+`.get`, nested dicts wrapped on access.
+"""
+
+
+class AttrDict(dict):
+    def __getattr__(self, k):
+        try:
+            v = self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+        return AttrDict(v) if isinstance(v, dict) and not isinstance(v, AttrDict) else v
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+    def get(self, k, default=None):
+        v = super().get(k, default)
+        return AttrDict(v) if isinstance(v, dict) and not isinstance(v, AttrDict) else v
+
+
+def litehandnet_cfg(variant="A", channels=128, num_joints=21, image_size=256, **model_kw):
+    """Config with the keys of config/litehandnet/*_256x256_*.py (variant B keys) and
+    config/litehandnet/freihand/_1_*_ca_r4_leaky.py (variant A keys)."""
+    if variant == "A":
+        model = dict(name="litehandnet", num_stage=4, num_block=[2, 2, 2], input_channel=channels,
+                     ca_type="ca", reduction=4, activation="leakyrelu", output_channel=num_joints)
+    elif variant == "B":
+        model = dict(name="litehourglass", num_stage=4, msrb_ca="ca", rbu_ca="none",
+                     input_channel=channels, output_channel=num_joints)
+    else:
+        raise ValueError(variant)
+    model.update(model_kw)
+    return AttrDict(
+        MODEL=model,
+        DATASET=dict(num_joints=num_joints, image_size=[image_size, image_size],
+                     heatmap_size=[image_size // 4, image_size // 4]),
+        PIPELINE=dict(sigma=2, kernel=(11, 11), encoding="MSRA", unbiased_encoding=True,
+                      use_udp=False, simdr_split_ratio=0, target_type="GaussianHeatmap"),
+        LOSS=dict(type="TopdownHeatmapLoss", loss_weight=[1.0, 0.1], auto_weight=False),
+        TRAIN=dict(syncBN=False, find_unused_parameters=False, batch_per_gpu=64),
+        OPTIMIZER=dict(type="Adam", lr=5e-4),
+        EVAL=dict(pck_threshold=0.2),
+    )

@@ -1,0 +1,234 @@
+"""ORACLE (test infrastructure only -- never imported by the product path).
+
+numpy restatement of the reference's Gaussian heatmap encode / decode / metric
+arithmetic.  Pinned against the real reference functions (loaded by file path in
+the build container) by `tests/golden/make_golden.py`; fixtures in tests/golden/.
+
+Reference behaviour followed (paths relative to the reference tree):
+  * encode   datasets/data_pipeline/generateTarget.py:74-159  (_msra_generate_target)
+  * argmax   utils/post_processing/evaluation/top_down_eval.py:199-231 (_get_max_preds)
+  * shift    utils/post_processing/evaluation/top_down_eval.py:440-452 ('default' branch)
+  * shift'   utils/heatmap_post_processing.py:6-33 (legacy twin: clamped neighbours, +0.5)
+  * DARK     utils/post_processing/evaluation/top_down_eval.py:233-272, 338-372, 433-439
+  * back-map datasets/data_pipeline/post_transforms.py:6-48 (transform_preds)
+  * NMS      utils/HeatmapParser.py:41-50 (11x11 max-pool peak keep)
+  * PCK/AUC/EPE  utils/post_processing/evaluation/top_down_eval.py:12-62,104-196
+DARK's blur uses cv2.GaussianBlur in the reference; cv2 is absent, so the blur
+here follows OpenCV's documented kernel rule and is "parity unpinned" at bit level
+(see DESIGN.md).
+"""
+import numpy as np
+
+
+# ----------------------------------------------------------------- encode
+def msra_generate_target(joints_3d, joints_3d_visible, image_size, heatmap_size, sigma=2,
+                         unbiased=True):
+    """joints_3d [K,3] image coords, visible [K,3] -> target [K,H,W] f32, weight [K,1] f32."""
+    K = joints_3d.shape[0]
+    W, H = heatmap_size
+    image_size = np.asarray(image_size)
+    weight = np.zeros((K, 1), np.float32)
+    target = np.zeros((K, H, W), np.float32)
+    r = sigma * 3
+    stride = image_size / [W, H]                       # float64, as in the reference
+    xs = np.arange(0, W, 1, np.float32)
+    ys = np.arange(0, H, 1, np.float32)[:, None]
+    for k in range(K):
+        weight[k] = joints_3d_visible[k, 0]
+        if unbiased:
+            mx = joints_3d[k][0] / stride[0]
+            my = joints_3d[k][1] / stride[1]
+            if mx - r >= W or my - r >= H or mx + r + 1 < 0 or my + r + 1 < 0:
+                weight[k] = 0
+            if weight[k] > 0.5:
+                target[k] = np.exp(-((xs - mx) ** 2 + (ys - my) ** 2) / (2 * sigma ** 2))
+        else:
+            mx = int(joints_3d[k][0] / stride[0] + 0.5)
+            my = int(joints_3d[k][1] / stride[1] + 0.5)
+            ul = [int(mx - r), int(my - r)]
+            br = [int(mx + r + 1), int(my + r + 1)]
+            if ul[0] >= W or ul[1] >= H or br[0] < 0 or br[1] < 0:
+                weight[k] = 0
+            if weight[k] > 0.5:
+                size = 2 * r + 1
+                g1 = np.arange(0, size, 1, np.float32)
+                g = np.exp(-((g1 - size // 2) ** 2 + (g1[:, None] - size // 2) ** 2) / (2 * sigma ** 2))
+                gx = max(0, -ul[0]), min(br[0], W) - ul[0]
+                gy = max(0, -ul[1]), min(br[1], H) - ul[1]
+                ix = max(0, ul[0]), min(br[0], W)
+                iy = max(0, ul[1]), min(br[1], H)
+                target[k][iy[0]:iy[1], ix[0]:ix[1]] = g[gy[0]:gy[1], gx[0]:gx[1]]
+    return target, weight
+
+
+# ----------------------------------------------------------------- decode
+def get_max_preds(heatmaps):
+    """[N,K,H,W] -> preds [N,K,2] f32 (x = idx % W, y = idx // W; -1 where max <= 0), maxvals [N,K,1]."""
+    N, K, _, W = heatmaps.shape
+    flat = heatmaps.reshape(N, K, -1)
+    idx = flat.argmax(2)
+    maxvals = flat.max(2)[..., None]
+    preds = np.stack([idx % W, idx // W], -1).astype(np.float32)
+    preds = np.where(maxvals > 0.0, preds, np.float32(-1))
+    return preds.astype(np.float32), maxvals
+
+
+def refine_default(heatmaps, preds):
+    """+-0.25 sign shift, only strictly inside the border (1 < p < size-1)."""
+    N, K, H, W = heatmaps.shape
+    out = preds.copy()
+    for n in range(N):
+        for k in range(K):
+            px, py = int(out[n, k, 0]), int(out[n, k, 1])
+            if 1 < px < W - 1 and 1 < py < H - 1:
+                h = heatmaps[n, k]
+                d = np.array([h[py, px + 1] - h[py, px - 1], h[py + 1, px] - h[py - 1, px]])
+                out[n, k] += np.sign(d) * 0.25
+    return out
+
+
+def refine_offset_legacy(heatmaps, kpts_xy):
+    """utils/heatmap_post_processing.py:6-33: clamped neighbours, strict '>' else minus, then +0.5."""
+    N, K, H, W = heatmaps.shape
+    out = kpts_xy.astype(np.float32).copy()
+    for n in range(N):
+        for k in range(K):
+            x, y = out[n, k]
+            xx, yy = int(x), int(y)
+            h = heatmaps[n, k]
+            x += 0.25 if h[yy, min(xx + 1, W - 1)] > h[yy, max(xx - 1, 0)] else -0.25
+            y += 0.25 if h[min(yy + 1, H - 1), xx] > h[max(yy - 1, 0), xx] else -0.25
+            out[n, k] = (x + 0.5, y + 0.5)
+    return out
+
+
+def transform_preds(coords, center, scale, output_size, use_udp=False):
+    scale = scale * 200.0
+    if use_udp:
+        sx, sy = scale[0] / (output_size[0] - 1.0), scale[1] / (output_size[1] - 1.0)
+    else:
+        sx, sy = scale[0] / output_size[0], scale[1] / output_size[1]
+    out = np.ones_like(coords)
+    out[:, 0] = coords[:, 0] * sx + center[0] - scale[0] * 0.5
+    out[:, 1] = coords[:, 1] * sy + center[1] - scale[1] * 0.5
+    return out
+
+
+def opencv_gaussian_kernel1d(ksize):
+    """cv2.getGaussianKernel(ksize, sigma<=0): sigma = 0.3*((ksize-1)*0.5-1)+0.8, normalised.
+    (OpenCV uses fixed tables for ksize<=7 with sigma<=0; 11 and 19 use the formula.)"""
+    sigma = 0.3 * ((ksize - 1) * 0.5 - 1) + 0.8
+    x = np.arange(ksize, dtype=np.float64) - (ksize - 1) * 0.5
+    k = np.exp(-(x * x) / (2 * sigma * sigma))
+    return (k / k.sum())
+
+
+def gaussian_blur(heatmaps, kernel=11):
+    """Separable blur of the zero-padded map then max re-normalisation (top_down_eval.py:233-272)."""
+    k1 = opencv_gaussian_kernel1d(kernel).astype(np.float32)
+    b = (kernel - 1) // 2
+    out = np.empty_like(heatmaps)
+    N, K, H, W = heatmaps.shape
+    for n in range(N):
+        for j in range(K):
+            src = heatmaps[n, j]
+            omax = src.max()
+            pad = np.zeros((H + 2 * b, W + 2 * b), np.float32)
+            pad[b:-b, b:-b] = src
+            tmp = np.zeros_like(pad)
+            for t in range(kernel):           # rows (x direction) first, zero border
+                sh = t - b
+                lo, hi = max(0, -sh), min(pad.shape[1], pad.shape[1] - sh)
+                tmp[:, lo:hi] += k1[t] * pad[:, lo + sh:hi + sh]
+            res = np.zeros_like(pad)
+            for t in range(kernel):
+                sh = t - b
+                lo, hi = max(0, -sh), min(pad.shape[0], pad.shape[0] - sh)
+                res[lo:hi, :] += k1[t] * tmp[lo + sh:hi + sh, :]
+            res = res[b:-b, b:-b]
+            out[n, j] = res * (omax / res.max())
+    return out
+
+
+def taylor(hm, coord):
+    H, W = hm.shape
+    px, py = int(coord[0]), int(coord[1])
+    if 1 < px < W - 2 and 1 < py < H - 2:
+        dx = 0.5 * (hm[py][px + 1] - hm[py][px - 1])
+        dy = 0.5 * (hm[py + 1][px] - hm[py - 1][px])
+        dxx = 0.25 * (hm[py][px + 2] - 2 * hm[py][px] + hm[py][px - 2])
+        dxy = 0.25 * (hm[py + 1][px + 1] - hm[py - 1][px + 1] - hm[py + 1][px - 1] + hm[py - 1][px - 1])
+        dyy = 0.25 * (hm[py + 2][px] - 2 * hm[py][px] + hm[py - 2][px])
+        det = dxx * dyy - dxy ** 2
+        if det != 0:
+            inv = np.linalg.inv(np.array([[dxx, dxy], [dxy, dyy]]))
+            coord = coord + (-inv @ np.array([dx, dy]))
+    return coord
+
+
+def keypoints_from_heatmaps(heatmaps, center, scale, post_process="default", kernel=11):
+    """-> (hm_preds [N,K,2], preds [N,K,2] image coords, maxvals [N,K,1]); use_udp=False path."""
+    heatmaps = heatmaps.copy()
+    N, K, H, W = heatmaps.shape
+    hm_preds, maxvals = get_max_preds(heatmaps)
+    if post_process == "unbiased":
+        lg = np.log(np.maximum(gaussian_blur(heatmaps, kernel), 1e-10))
+        for n in range(N):
+            for k in range(K):
+                hm_preds[n, k] = taylor(lg[n, k], hm_preds[n, k])
+    elif post_process is not None:
+        hm_preds = refine_default(heatmaps, hm_preds)
+    preds = hm_preds.copy()
+    for i in range(N):
+        preds[i] = transform_preds(preds[i], center[i], scale[i], [W, H])
+    return hm_preds, preds, maxvals
+
+
+def heatmap_nms(heatmaps, kernel=11):
+    """h * (maxpool_{k x k, stride 1, pad k//2}(h) == h)   (HeatmapParser.py:41-50; -inf padding)."""
+    N, K, H, W = heatmaps.shape
+    p = kernel // 2
+    pad = np.full((N, K, H + 2 * p, W + 2 * p), -np.inf, heatmaps.dtype)
+    pad[:, :, p:p + H, p:p + W] = heatmaps
+    mx = np.full_like(heatmaps, -np.inf)
+    for dy in range(kernel):
+        for dx in range(kernel):
+            mx = np.maximum(mx, pad[:, :, dy:dy + H, dx:dx + W])
+    return heatmaps * (mx == heatmaps).astype(heatmaps.dtype)
+
+
+# ----------------------------------------------------------------- metrics
+def _calc_distances(preds, targets, mask, normalize):
+    N, K, _ = preds.shape
+    m = mask.copy()
+    m[np.where((normalize == 0).sum(1))[0], :] = False
+    d = np.full((N, K), -1, np.float32)
+    normalize = normalize.copy()
+    normalize[np.where(normalize <= 0)] = 1e6
+    d[m] = np.linalg.norm(((preds - targets) / normalize[:, None, :])[m], axis=-1)
+    return d.T
+
+
+def _distance_acc(d, thr):
+    v = d != -1
+    n = v.sum()
+    return (d[v] < thr).sum() / n if n > 0 else -1
+
+
+def keypoint_pck_accuracy(pred, gt, mask, thr, normalize):
+    d = _calc_distances(pred, gt, mask, normalize)
+    acc = np.array([_distance_acc(x, thr) for x in d])
+    valid = acc[acc >= 0]
+    return acc, (valid.mean() if len(valid) else 0), len(valid)
+
+
+def keypoint_auc(pred, gt, mask, normalize, num_step=20):
+    nor = np.tile(np.array([[normalize, normalize]]), (pred.shape[0], 1))
+    ys = [keypoint_pck_accuracy(pred, gt, mask, i / num_step, nor)[1] for i in range(num_step)]
+    return float(sum(ys) / num_step)
+
+
+def keypoint_epe(pred, gt, mask):
+    d = _calc_distances(pred, gt, mask, np.ones((pred.shape[0], pred.shape[2]), np.float32))
+    v = d[d != -1]
+    return v.sum() / max(1, len(v))

@@ -1,0 +1,410 @@
+"""ORACLE (test infrastructure only -- never imported by the product path).
+
+CPU restatement, in plain PyTorch fp32 / NCHW, of the reference's convolutional
+heatmap path.  Only `tests/`, `__graft_entry__.smoke()` and the `cpu_baseline`
+leg of `bench.py` may import this file.  It is pinned against the real
+reference by `tests/golden/make_golden.py` (run in the build container, where
+`/root/reference` is importable) and the committed fixtures in `tests/golden/`.
+
+Every class keeps the reference's attribute names because the `state_dict()`
+keys are the compatibility contract (checkpoint row); the
+bodies are written from the behaviour, not copied.
+
+Reference behaviour followed (paths relative to the reference tree):
+  * conv+BN(+act) unit            models/pose_estimation/liteHandNet/repblocks.py:8-44
+  * 3-branch re-param block        models/pose_estimation/liteHandNet/repblocks.py:76-144
+  * channel attention              models/pose_estimation/liteHandNet/common.py:40-66
+  * variant A (registered name)    models/pose_estimation/liteHandNet/liteHandNet.py:8-238
+  * variant B (MSRB hourglass)     models/pose_estimation/liteHandNet/litehourglass.py:13-237
+  * init                           models/weight_init.py:21-32
+  * loss                           loss/loss.py:69-114, loss/heatmapLoss.py:228-265
+"""
+import torch
+from torch import nn
+import torch.nn.functional as F
+
+_ACTS = {"leakyrelu": nn.LeakyReLU, "relu": nn.ReLU, "silu": nn.SiLU}
+
+
+def _act(kind):
+    """kind: None | class | str -> module instance."""
+    if kind is None:
+        return nn.Identity()
+    if isinstance(kind, str):
+        kind = _ACTS[kind.lower()]
+    return kind()
+
+
+def _repconv_act(kind, inplace):
+    """repblocks.py:29-30 builds `activation(inplace)` POSITIONALLY.  For nn.LeakyReLU the first
+    positional parameter is negative_slope, so the unit's non-linearity is LeakyReLU(slope=float(inplace)):
+    ReLU-like (slope 0) when inplace=False, the identity (slope 1) when inplace=True.  nn.ReLU / nn.SiLU
+    take `inplace` first and behave normally.  This is the reference's behaviour, so it is the oracle's."""
+    if kind is None:
+        return nn.Identity()
+    if isinstance(kind, str):
+        kind = _ACTS[kind.lower()]
+    if kind is nn.LeakyReLU:
+        return nn.LeakyReLU(negative_slope=float(inplace))
+    return kind()
+
+
+def _conv_bn(cin, cout, k, stride, pad, dil=1, groups=1):
+    seq = nn.Sequential()
+    seq.add_module("conv", nn.Conv2d(cin, cout, k, stride, pad, dil, groups, bias=False))
+    seq.add_module("bn", nn.BatchNorm2d(cout))
+    return seq
+
+
+class RepConv(nn.Module):
+    """act(BN(conv(x))); keys `conv.conv.weight`, `conv.bn.*`."""
+
+    def __init__(self, cin, cout, kernel=1, stride=1, padding=0, dilation=1, groups=1,
+                 activation=nn.LeakyReLU, inplace=False):
+        super().__init__()
+        self.conv = _conv_bn(cin, cout, kernel, stride, padding, dilation, groups)
+        self.nonlinearity = _repconv_act(activation, inplace)
+
+    def forward(self, x):
+        return self.nonlinearity(self.conv(x))
+
+
+class RepBlock(nn.Module):
+    """act(BN(conv_kxk(x)) + BN(conv_1x1(x)) [+ BN(x)])."""
+
+    def __init__(self, cin, cout, k=3, stride=1, padding=1, groups=1, activation=nn.LeakyReLU):
+        super().__init__()
+        self.rbr_identity = nn.BatchNorm2d(cin) if (cin == cout and stride == 1) else None
+        self.rbr_dense = _conv_bn(cin, cout, k, stride, padding, 1, groups)
+        self.rbr_1x1 = _conv_bn(cin, cout, 1, stride, 0, 1, groups)
+        self.nonlinearity = _act(activation)
+
+    def forward(self, x):
+        y = self.rbr_dense(x) + self.rbr_1x1(x)
+        if self.rbr_identity is not None:
+            y = y + self.rbr_identity(x)
+        return self.nonlinearity(y)
+
+
+class ChannelAttension(nn.Module):
+    """x * sigmoid(W2 lrelu(W1 drop(BN(dw3x3_valid(avgpool_3x3(x))))))."""
+
+    def __init__(self, c, p_drop=0.3):
+        super().__init__()
+        self.conv3x3 = nn.Sequential()
+        self.conv3x3.add_module("conv", nn.Conv2d(c, c, 3, 1, 0, groups=c, bias=False))
+        self.conv3x3.add_module("bn", nn.BatchNorm2d(c))
+        self.conv1x1 = nn.Sequential(
+            nn.Dropout2d(p=p_drop),
+            nn.Conv2d(c, c // 2, 1),
+            nn.LeakyReLU(),
+            nn.Conv2d(c // 2, c, 1),
+            nn.Sigmoid())
+
+    def forward(self, x):
+        pooled = F.adaptive_avg_pool2d(x, (3, 3))
+        return x * self.conv1x1(self.conv3x3(pooled))
+
+
+def _make_ca(kind, c, p_drop):
+    if kind == "ca":
+        return ChannelAttension(c, p_drop)
+    if kind == "none":
+        return nn.Identity()
+    raise ValueError(f"ca_type {kind!r}: the hot path covers 'ca' and 'none' only")
+
+
+# --------------------------------------------------------------------------
+# Variant B: MSRB hourglass  (litehourglass.py)
+# --------------------------------------------------------------------------
+class MSRB(nn.Module):
+    def __init__(self, cin, cout, ca_type="none", p_drop=0.3):
+        super().__init__()
+        h = cin // 2
+        self.branch1 = nn.ModuleList([RepConv(h, h, 3, 1, 1, groups=h, activation=None) for _ in range(2)])
+        self.branch2 = nn.ModuleList([RepConv(h, h, 3, 1, 2, 2, groups=h, activation=None) for _ in range(2)])
+        self.ca = nn.ModuleList([_make_ca(ca_type if ca_type == "ca" else "none", cout, p_drop) for _ in range(2)])
+        self.conv = RepConv(cin, cout, 1, 1, 0)
+
+    def forward(self, x):
+        acc = x
+        for b1, b2, ca in zip(self.branch1, self.branch2, self.ca):
+            lo, hi = torch.chunk(acc, 2, dim=1)
+            acc = acc + ca(torch.cat([b1(lo), b2(hi)], dim=1))
+        return self.conv(acc + x)
+
+
+class RepBasicUnit(nn.Module):
+    def __init__(self, cin, cout, ca_type="ca", p_drop=0.3):
+        super().__init__()
+        self.left_part = cin // 2
+        r_in, r_out = cin - self.left_part, cout - self.left_part
+        self.conv = nn.Sequential(RepConv(r_in, r_out, 1),
+                                  RepConv(r_out, r_out, 3, padding=1, groups=r_out))
+        self.ca = _make_ca(ca_type, cout, p_drop)
+
+    def forward(self, x):
+        keep, work = x[:, :self.left_part], x[:, self.left_part:]
+        return self.ca(torch.cat([keep, self.conv(work)], dim=1))
+
+
+class _HourglassB(nn.Module):
+    def __init__(self, num_stage, c, msrb_ca, rbu_ca, p_drop):
+        super().__init__()
+        self.num_stage = num_stage
+        self.encoder, self.decoder = nn.ModuleList(), nn.ModuleList()
+        self.maxpool = nn.MaxPool2d(2, 2)
+        for i in range(num_stage):
+            for lst in (self.encoder, self.decoder):
+                first = MSRB(c, c, msrb_ca, p_drop) if i == 0 else RepBasicUnit(c, c, rbu_ca, p_drop)
+                lst.append(nn.Sequential(first, RepBasicUnit(c, c, rbu_ca, p_drop)))
+
+    def forward(self, x):
+        skips = []
+        for i, enc in enumerate(self.encoder):
+            x = enc(x)
+            skips.append(x)
+            if i + 1 < self.num_stage:
+                x = self.maxpool(x)
+        outs = []
+        for i in reversed(range(self.num_stage)):
+            if i == self.num_stage - 1:
+                x = self.decoder[i](skips[i])
+                x = x + F.adaptive_avg_pool2d(skips[0], skips[-1].shape[2:])
+            else:
+                x = F.interpolate(x, size=skips[i].shape[2:]) + skips[i]
+                x = self.decoder[i](x)
+            outs.append(x)
+        return tuple(outs)
+
+
+class _StemB(nn.Module):
+    def __init__(self, c, p_drop):
+        super().__init__()
+        m = max(c // 4, 32)
+        self.conv1 = nn.Sequential(RepConv(3, m, 3, 2, 1), RepConv(m, m, 3, 1, 1, groups=m))
+        self.branch1 = nn.Sequential(RepConv(m, m, 1), RepConv(m, m, 3, 2, 1, groups=m, activation=None),
+                                     RepConv(m, m, 1))
+        self.branch2 = nn.MaxPool2d(2, 2, ceil_mode=True)
+        self.conv2 = nn.Sequential(RepConv(2 * m, c), RepBasicUnit(c, c, "ca", p_drop),
+                                   RepBasicUnit(c, c, "ca", p_drop))
+
+    def forward(self, x):
+        t = self.conv1(x)
+        return self.conv2(torch.cat([self.branch1(t), self.branch2(t)], dim=1))
+
+
+class LiteHourglassNet(nn.Module):
+    """Variant B.  cfg keys: MODEL.{num_stage,msrb_ca,rbu_ca,input_channel,output_channel}."""
+
+    def __init__(self, cfg, p_drop=0.3):
+        super().__init__()
+        M = cfg.MODEL
+        c = M.get("input_channel", 256)
+        self.stem = _StemB(c, p_drop)
+        self.backone = _HourglassB(M.get("num_stage", 4), c, M.get("msrb_ca", "ca"), M.get("rbu_ca", "ca"), p_drop)
+        self.neck = nn.Sequential(RepBasicUnit(c, c, "ca", p_drop), RepBasicUnit(c, c, "ca", p_drop))
+        self.head = nn.Conv2d(c, M.get("output_channel", cfg.DATASET.num_joints), 1)
+        self.init_weights()
+
+    def forward(self, x):
+        return self.head(self.neck(self.backone(self.stem(x))[-1]))
+
+    def init_weights(self):  # litehourglass.py:224-230: conv ~ N(0,1), bias 0; BN gamma 1, beta 0
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.normal_(m.weight, 0, 1)
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.ones_(m.weight)
+                nn.init.zeros_(m.bias)
+
+
+# --------------------------------------------------------------------------
+# Variant A: registered `litehandnet`  (liteHandNet.py)
+# --------------------------------------------------------------------------
+class DWConv(nn.Module):
+    def __init__(self, cin, cout, padding=1, dilation=1, activation=nn.LeakyReLU):
+        super().__init__()
+        self.depthwise_conv = RepConv(cin, cin, 3, 1, padding, dilation, groups=cin, activation=activation)
+        self.pointwise_conv = RepConv(cin, cout, 1, activation=activation)
+
+    def forward(self, x):
+        return self.pointwise_conv(self.depthwise_conv(x))
+
+
+class BottleNeck(nn.Module):
+    def __init__(self, c, reduction=4, activation=nn.LeakyReLU):
+        super().__init__()
+        m = c // reduction
+        self.conv = nn.Sequential(RepConv(c, m, 1, activation=activation, inplace=True),
+                                  RepConv(m, m, 3, 1, 1, activation=activation, inplace=True),
+                                  RepConv(m, c, 1, activation=None))
+        self.activation = _act(activation)
+
+    def forward(self, x):
+        return self.activation(x + self.conv(x))
+
+
+class BasicBlock(nn.Module):
+    def __init__(self, cin, cout, stride=1, activation=nn.LeakyReLU):
+        super().__init__()
+        self.conv = nn.Sequential(RepConv(cin, cout, 3, stride, 1, activation=activation, inplace=True),
+                                  RepConv(cin, cout, 3, 1, 1, activation=None))
+        self.skip_layer = (RepConv(cin, cout, 1, stride, 0, activation=None)
+                           if (stride == 2 or cin != cout) else nn.Identity())
+        self.activation = _act(activation)
+
+    def forward(self, x):
+        return self.activation(self.skip_layer(x) + self.conv(x))
+
+
+class Residual(nn.Module):
+    def __init__(self, cin, cout, stride, num_block, reduction, activation):
+        super().__init__()
+        self.conv1 = BasicBlock(cin, cout, stride, activation)
+        self.blocks = nn.Sequential(*[BottleNeck(cout, reduction, activation) for _ in range(num_block)])
+
+    def forward(self, x):
+        return self.blocks(self.conv1(x))
+
+
+class MSAB(nn.Module):
+    def __init__(self, cin, cout, ca_type="ca", activation=nn.LeakyReLU, p_drop=0.3):
+        super().__init__()
+        m = cin // 2
+        a = activation
+        self.conv1 = RepConv(cin, m, 1, activation=a, inplace=True)
+        self.mid1_conv = nn.ModuleList([
+            nn.Sequential(DWConv(m, m // 2, activation=a), DWConv(m // 2, m // 2, activation=a)),
+            nn.Sequential(DWConv(m, m, activation=a), DWConv(m, m, activation=a))])
+        self.mid2_conv = nn.ModuleList([
+            nn.Sequential(DWConv(m, m // 2, 2, 2, activation=a), DWConv(m // 2, m // 2, activation=a)),
+            nn.Sequential(DWConv(m, m, 2, 2, activation=a), DWConv(m, m, activation=a))])
+        self.conv2 = RepConv(cin, cout, 1, activation=a, inplace=True)
+        self.ca = _make_ca(ca_type, cout, p_drop)
+
+    def forward(self, x):
+        t = self.conv1(x)
+        for r in range(2):
+            t = torch.cat([self.mid1_conv[r](t), self.mid2_conv[r](t)], dim=1)
+        return self.ca(self.conv2(t + x))
+
+
+class _HourglassA(nn.Module):
+    def __init__(self, levels, c, blocks, ca_type, reduction, act, p_drop):
+        super().__init__()
+        assert len(blocks) == levels - 1
+        self.num_levels = levels
+        self.encoder = nn.ModuleList([MSAB(c, c, ca_type, p_drop=p_drop)])
+        self.decoder = nn.ModuleList()
+        for nb in blocks:
+            self.encoder.append(Residual(c, c, 2, nb, reduction, act))
+            self.decoder.append(Residual(c, c, 1, nb, reduction, act))
+        self.decoder.append(MSAB(c, c, ca_type, p_drop=p_drop))
+
+    def forward(self, x):
+        enc = []
+        for layer in self.encoder:
+            x = layer(x)
+            enc.append(x)
+        short = F.adaptive_avg_pool2d(enc[0], enc[-1].shape[2:])
+        outs = []
+        for i, layer in enumerate(self.decoder):
+            peer = enc[self.num_levels - 1 - i]
+            if i == 0:
+                x = layer(peer) + short
+            else:
+                x = F.interpolate(layer(x), size=peer.shape[2:]) + peer
+            outs.append(x)
+        return tuple(outs)
+
+
+class _StemA(nn.Module):
+    def __init__(self, cout, act, min_mid=32):
+        super().__init__()
+        m = max(cout // 4, min_mid)
+        self.conv1 = nn.Sequential(RepBlock(3, m, 3, 2, 1, activation=act),
+                                   RepBlock(m, m, 7, 1, 3, groups=m, activation=act))
+        self.branch1 = nn.Sequential(RepConv(m, m, 1, activation=act, inplace=True),
+                                     RepConv(m, m, 3, 2, 1, activation=act, inplace=True))
+        self.branch2 = nn.MaxPool2d(2, 2, ceil_mode=True)
+        self.conv1x1 = nn.Conv2d(2 * m, cout, 1)
+
+    def forward(self, x):
+        t = self.conv1(x)
+        return self.conv1x1(torch.cat([self.branch1(t), self.branch2(t)], dim=1))
+
+
+class LiteHandNet(nn.Module):
+    """Variant A.  cfg keys: MODEL.{num_stage,input_channel,output_channel,num_block,ca_type,reduction,activation}."""
+
+    def __init__(self, cfg, p_drop=0.3):
+        super().__init__()
+        M = cfg.MODEL
+        c = M.get("input_channel", 128)
+        red = M.get("reduction", 2)
+        ca = M.get("ca_type", "ca")
+        act = _ACTS[M.get("activation", "LeakyReLU").lower()]
+        assert red in (2, 4)
+        self.pre = _StemA(c, act)
+        self.hgs = _HourglassA(M.get("num_stage", 4), c, M.get("num_block", [2, 2, 2]), ca, red, act, p_drop)
+        self.features = nn.Sequential(BottleNeck(c, 2, act), RepConv(c, c, 1, activation=act, inplace=True))
+        self.out_layer = nn.Conv2d(c, M.get("output_channel", cfg.DATASET.num_joints), 1)
+        self.init_weights()
+
+    def forward(self, x):
+        return self.out_layer(self.features(self.hgs(self.pre(x))[-1]))
+
+    def init_weights(self):  # liteHandNet.py:236-238 + weight_init.py:28-32: EVERY .weight ~ N(0,1) incl. BN gamma
+        for m in self.modules():
+            w = getattr(m, "weight", None)
+            if isinstance(w, torch.Tensor):
+                nn.init.normal_(w, 0, 1)
+            b = getattr(m, "bias", None)
+            if isinstance(b, torch.Tensor):
+                nn.init.zeros_(b)
+
+
+def get_model(cfg, p_drop=0.3):
+    """Mirror of models/__init__.py:20-26 restricted to the hot path.
+
+    `litehandnet` -> variant A (the registered class); `litehourglass` -> variant B
+    (unregistered in the reference; file litehourglass.py)."""
+    name = cfg.MODEL.name
+    if name == "litehandnet":
+        return LiteHandNet(cfg, p_drop)
+    if name == "litehourglass":
+        return LiteHourglassNet(cfg, p_drop)
+    raise AssertionError(f"model <{name}> is outside the hot path")
+
+
+# --------------------------------------------------------------------------
+# loss
+# --------------------------------------------------------------------------
+def distance_loss(output, target, target_weight, balance=True, thr=0.5):
+    """Class-balanced weighted MSE, loss/heatmapLoss.py:242-265 (L2, reduction='mean')."""
+    l = (output - target) ** 2 * target_weight.unsqueeze(-1)
+    if balance:
+        pos = target > thr
+        n = l.numel()
+        pf = n / (pos.sum() + 1) * 0.1
+        nf = n / ((~pos).sum() + 1)
+        l = torch.where(pos, l * pf, l * nf)
+    return l.mean()
+
+
+class TopdownHeatmapLoss(nn.Module):
+    """loss/loss.py:69-114 with simdr_split_ratio == 0 and auto_weight False."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.balance = cfg.MODEL.name != "atthandnet"
+        self.loss_weight = cfg.LOSS.loss_weight
+
+    def forward(self, output, meta):
+        t = meta["target"].to(output.device)
+        w = meta["target_weight"].to(output.device)
+        loss = self.loss_weight[0] * distance_loss(output, t, w, self.balance)
+        return loss, {"heatmap": loss.item()}

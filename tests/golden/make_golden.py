@@ -1,0 +1,235 @@
+"""Golden-vector generator.  RUNS ONLY IN THE BUILD CONTAINER (needs /root/reference).
+
+It imports the real reference (models + loss via the package; encode/decode/metric files
+by path with an empty `cv2` stub -- those functions never call cv2), runs it on seeded
+inputs with weights synthesised by `oracle.synth`, asserts that the oracle restatement
+(`oracle/torch_ref.py`, `oracle/heatmap_np.py`) agrees, and writes small `.npz` fixtures
+(inputs + expected outputs only; no reference source text) next to this file.
+
+    python tests/golden/make_golden.py
+"""
+import importlib.util
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+
+from litehandnet_amd.config import litehandnet_cfg  # noqa: E402
+from oracle import heatmap_np as onp  # noqa: E402
+from oracle import synth, torch_ref  # noqa: E402
+
+
+def _load_reference():
+    for name in ("turtle", "grpc", "cv2"):
+        m = types.ModuleType(name)
+        m.forward = None
+        m.Channel = None
+        sys.modules.setdefault(name, m)
+    sys.path.insert(0, REF)
+    import models as ref_models  # noqa
+    from models.pose_estimation.liteHandNet import litehourglass as ref_b
+    from loss.loss import TopdownHeatmapLoss as RefLoss
+
+    def by_path(dotted, rel):
+        spec = importlib.util.spec_from_file_location(dotted, os.path.join(REF, rel))
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[dotted] = mod
+        spec.loader.exec_module(mod)
+        return mod
+
+    for pkg in ("datasets", "datasets.data_pipeline"):
+        sys.modules.setdefault(pkg, types.ModuleType(pkg))
+    pt = by_path("datasets.data_pipeline.post_transforms", "datasets/data_pipeline/post_transforms.py")
+    gt = by_path("ref_generateTarget", "datasets/data_pipeline/generateTarget.py")
+    ev = by_path("ref_top_down_eval", "utils/post_processing/evaluation/top_down_eval.py")
+    return ref_models, ref_b, RefLoss, pt, gt, ev
+
+
+def _no_dropout(model):
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout2d):
+            m.p = 0.0
+
+
+def _model_case(ref_model, ora_model, n, size, seed, tag, out):
+    sd = synth.synth_state_dict(ref_model, seed)
+    ref_model.load_state_dict(sd)
+    ora_model.load_state_dict(sd)  # identical keys or this raises
+    x = synth.synth_images(n, size, seed)
+    hs = size // 4
+    joints = synth.synth_joints(n, 21, size, seed + 1)
+    tgt = np.stack([onp.msra_generate_target(j, np.ones_like(j), [size, size], [hs, hs])[0] for j in joints])
+    w = np.ones((n, 21, 1), np.float32)
+    w[0, 3] = 0
+    meta = {"target": torch.from_numpy(tgt), "target_weight": torch.from_numpy(w)}
+    res = {}
+    for name, model, lossmod in (("ref", ref_model, out["ref_loss"]), ("ora", ora_model, out["ora_loss"])):
+        model.train()
+        _no_dropout(model)
+        model.zero_grad()
+        y = model(x)
+        loss, _ = lossmod(y, meta)
+        loss.backward()
+        res[name] = dict(y=y.detach().numpy(), loss=float(loss),
+                         gnorm={k: float(p.grad.norm()) for k, p in model.named_parameters()},
+                         rm={k: v.numpy().copy() for k, v in model.state_dict().items() if k.endswith("running_mean")},
+                         rv={k: v.numpy().copy() for k, v in model.state_dict().items() if k.endswith("running_var")})
+    a, b = res["ref"], res["ora"]
+    scale = np.abs(a["y"]).max()
+    err = np.abs(a["y"] - b["y"]).max() / scale
+    print(f"[{tag}] oracle vs reference: out rel err {err:.2e}, loss {a['loss']:.6f} vs {b['loss']:.6f}")
+    assert err < 1e-5 and abs(a["loss"] - b["loss"]) <= 1e-5 * abs(a["loss"])
+    for k in a["gnorm"]:
+        assert abs(a["gnorm"][k] - b["gnorm"][k]) <= 2e-4 * (abs(a["gnorm"][k]) + 1e-6), (k, a["gnorm"][k], b["gnorm"][k])
+    for k in a["rm"]:
+        assert np.allclose(a["rm"][k], b["rm"][k], rtol=1e-5, atol=1e-6)
+    keys = sorted(a["gnorm"])
+    first_bn = sorted(a["rm"])[0]
+    np.savez_compressed(
+        os.path.join(HERE, f"model_{tag}.npz"),
+        n=n, size=size, seed=seed, heatmap=a["y"].astype(np.float32), loss=np.float64(a["loss"]),
+        grad_keys=np.array(keys), grad_norms=np.array([a["gnorm"][k] for k in keys], np.float64),
+        bn_key=np.array(first_bn), bn_running_mean=a["rm"][first_bn],
+        bn_running_var=a["rv"][first_bn.replace("running_mean", "running_var")],
+        target_weight=w)
+    return a
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    ref_models, ref_b, RefLoss, pt, gt, ev = _load_reference()
+    cfgA, cfgB = litehandnet_cfg("A"), litehandnet_cfg("B")
+    out = {"ref_loss": RefLoss(cfgA), "ora_loss": torch_ref.TopdownHeatmapLoss(cfgA)}
+
+    # ---- known answers stored in the reference's notebooks (test_models_performance.ipynb:247)
+    cfgA_ref = litehandnet_cfg("A")
+    refA = ref_models.get_model(cfgA_ref)
+    nA = sum(p.numel() for p in refA.parameters())
+    refB = ref_b.LiteHandNet(cfgB)
+    nB = sum(p.numel() for p in refB.parameters())
+    assert nA == 2272981, nA
+    oraA, oraB = torch_ref.get_model(cfgA), torch_ref.get_model(cfgB)
+    assert sum(p.numel() for p in oraA.parameters()) == nA
+    assert sum(p.numel() for p in oraB.parameters()) == nB
+    assert list(oraA.state_dict()) == list(refA.state_dict())
+    assert list(oraB.state_dict()) == list(refB.state_dict())
+    json.dump({"litehandnet_A_params": nA, "litehourglass_B_params": nB,
+               "A_keys": len(refA.state_dict()), "B_keys": len(refB.state_dict())},
+              open(os.path.join(HERE, "known_answers.json"), "w"), indent=1)
+
+    # ---- full models, fwd + loss + bwd, train-mode BN, dropout off
+    _model_case(refB, oraB, 2, 64, 3, "B_64", out)
+    _model_case(refB, oraB, 2, 256, 5, "B_256", out)
+    _model_case(refA, oraA, 2, 64, 4, "A_64", out)
+    _model_case(refA, oraA, 2, 256, 6, "A_256", out)
+
+    # ---- variant B with CA everywhere + rbu_ca='ca' (exercise gates in the hourglass), eval-mode BN too
+    cfgB2 = litehandnet_cfg("B", rbu_ca="ca")
+    rB2, oB2 = ref_b.LiteHandNet(cfgB2), torch_ref.get_model(cfgB2)
+    _model_case(rB2, oB2, 2, 64, 7, "Bca_64", out)
+    for tag, rm, om in (("B", refB, oraB), ("A", refA, oraA)):
+        rm.eval(); om.eval()
+        x = synth.synth_images(2, 64, 11)
+        with torch.no_grad():
+            yr, yo = rm(x).numpy(), om(x).numpy()
+        assert np.abs(yr - yo).max() <= 1e-5 * np.abs(yr).max()
+        np.savez_compressed(os.path.join(HERE, f"model_{tag}_64_eval.npz"), seed=11, heatmap=yr,
+                            weights_seed={"B": 5, "A": 6}[tag])
+
+    # ---- loss alone (reference loss/heatmapLoss.py:242-265 through loss/loss.py:93-114)
+    r = np.random.Generator(np.random.PCG64(21))
+    o = torch.from_numpy(r.standard_normal((2, 21, 64, 64)).astype(np.float32)).requires_grad_()
+    j = synth.synth_joints(2, 21, 256, 9, margin=0.1)
+    vis = np.ones_like(j); vis[1, 5] = 0
+    tw = [onp.msra_generate_target(a, v, [256, 256], [64, 64]) for a, v in zip(j, vis)]
+    t = torch.from_numpy(np.stack([a for a, _ in tw])); w = torch.from_numpy(np.stack([b for _, b in tw]))
+    lr, _ = out["ref_loss"](o, {"target": t, "target_weight": w})
+    lr.backward()
+    g = o.grad.numpy().copy()
+    lo = torch_ref.distance_loss(o.detach(), t, w)
+    assert abs(float(lr) - float(lo)) < 1e-6 * abs(float(lr))
+    np.savez_compressed(os.path.join(HERE, "loss.npz"), joints=j, visible=vis, seed=21, loss=np.float64(float(lr)),
+                        npos=int((t > 0.5).sum()), grad_abs_sum=np.float64(np.abs(g).sum()),
+                        grad_sample=g[:, ::5, ::16, ::16].copy())
+
+    # ---- encode (generateTarget.py:74-159), both branches, incl. the reference's own annotated samples
+    ann = json.load(open(os.path.join(REF, "test/test_example/two_samples.json")))
+    kp = np.array([a["keypoints"] for a in ann["annotations"]], np.float32).reshape(-1, 21, 3)
+    rj = synth.synth_joints(48, 21, 256, 13, margin=0.15)
+    joints = np.concatenate([np.concatenate([kp[..., :2], np.zeros_like(kp[..., :1])], -1), rj])
+    vis = np.ones_like(joints)
+    vis[3, 2] = 0; vis[7, :] = 0
+    enc = {}
+    for unb in (True, False):
+        G = gt.TopDownGenerateTarget(sigma=2, unbiased_encoding=unb)
+        T, Wt = [], []
+        for a, v in zip(joints, vis):
+            ai = dict(num_joints=21, image_size=np.array([256, 256]), heatmap_size=[64, 64],
+                      joint_weights=None, use_different_joint_weights=False)
+            tr, wr = G._msra_generate_target(ai, a, v, 2)
+            to, wo = onp.msra_generate_target(a, v, [256, 256], [64, 64], 2, unb)
+            assert np.array_equal(tr, to) and np.array_equal(wr, wo)
+            T.append(tr); Wt.append(wr)
+        T, Wt = np.stack(T), np.stack(Wt)
+        tag = "unbiased" if unb else "biased"
+        flat = T.reshape(T.shape[0], 21, -1)
+        enc[f"{tag}_weight"] = Wt
+        enc[f"{tag}_argmax"] = flat.argmax(2).astype(np.int32)
+        enc[f"{tag}_max"] = flat.max(2)
+        enc[f"{tag}_sum"] = flat.astype(np.float64).sum(2)
+        enc[f"{tag}_full_first2"] = T[:2]
+    np.savez_compressed(os.path.join(HERE, "encode.npz"), joints=joints, visible=vis, **enc)
+
+    # ---- decode: argmax (+ties, non-positive maps), 'default' shift, transform_preds, PCK/AUC/EPE
+    r = np.random.Generator(np.random.PCG64(31))
+    hm = r.standard_normal((6, 21, 64, 64)).astype(np.float32) * 0.05
+    jj = synth.synth_joints(6, 21, 256, 17)
+    for n in range(6):
+        hm[n] += onp.msra_generate_target(jj[n], np.ones_like(jj[n]), [256, 256], [64, 64])[0]
+    hm[0, 0] = -1.0                      # max <= 0 -> (-1,-1)
+    hm[0, 1] = 0.0; hm[0, 1, 10, 7] = 2.0; hm[0, 1, 30, 9] = 2.0   # tie: first flat index wins
+    hm[0, 2] = 0.0; hm[0, 2, 0, 0] = 1.0                            # border: no shift
+    hm[0, 3] = 0.0; hm[0, 3, 63, 63] = 1.0
+    hm[0, 4] = 0.0; hm[0, 4, 1, 5] = 1.0                            # py == 1: no shift (strict)
+    center = r.uniform(60, 200, (6, 2)).astype(np.float32)
+    scale = r.uniform(0.5, 1.5, (6, 2)).astype(np.float32)
+    p0, mv = ev._get_max_preds(hm)
+    hp, pr, mv2 = ev.keypoints_from_heatmaps(hm, center, scale, post_process="default")
+    o0, omv = onp.get_max_preds(hm)
+    ohp, opr, _ = onp.keypoints_from_heatmaps(hm, center, scale, "default")
+    assert np.array_equal(p0, o0) and np.array_equal(mv, omv)
+    assert np.array_equal(hp, ohp) and np.array_equal(pr, opr)
+    gtk = jj[..., :2] + r.normal(0, 6, (6, 21, 2)).astype(np.float32)
+    mask = np.ones((6, 21), bool); mask[2, 4] = False
+    bbox = r.uniform(80, 200, (6, 1)).astype(np.float32)
+    norm = np.concatenate([bbox, bbox], 1)
+    acc, pck, cnt = ev.keypoint_pck_accuracy(pr.copy(), gtk.copy(), mask.copy(), 0.2, norm.copy())
+    oacc, opck, ocnt = onp.keypoint_pck_accuracy(pr.copy(), gtk.copy(), mask.copy(), 0.2, norm.copy())
+    assert np.array_equal(acc, oacc) and pck == opck and cnt == ocnt
+    auc = ev.keypoint_auc(pr.copy(), gtk.copy(), mask.copy(), 30)
+    epe = ev.keypoint_epe(pr.copy(), gtk.copy(), mask.copy())
+    assert abs(auc - onp.keypoint_auc(pr.copy(), gtk.copy(), mask.copy(), 30)) < 1e-12
+    assert abs(epe - onp.keypoint_epe(pr.copy(), gtk.copy(), mask.copy())) < 1e-6
+    # Taylor step of DARK (pure numpy in the reference) on a log-Gaussian map
+    lg = np.log(np.maximum(hm[1], 1e-10))
+    tay = np.stack([ev._taylor(lg[k], p0[1, k].copy()) for k in range(21)])
+    otay = np.stack([onp.taylor(lg[k], o0[1, k].copy()) for k in range(21)])
+    assert np.allclose(tay, otay, rtol=1e-6, atol=1e-6)
+    np.savez_compressed(os.path.join(HERE, "decode.npz"), heatmaps=hm, center=center, scale=scale,
+                        argmax_xy=p0, maxvals=mv, hm_preds=hp, preds=pr, gt=gtk, mask=mask, normalize=norm,
+                        pck_acc=acc, pck=np.float64(pck), pck_cnt=cnt, auc=np.float64(auc), epe=np.float64(epe),
+                        taylor_in=lg, taylor_out=tay)
+    print("golden fixtures written to", HERE)
+
+
+if __name__ == "__main__":
+    main()
