@@ -1,0 +1,173 @@
+/* liblhn -- MI355X (gfx950) kernels for litehandnet's convolutional heatmap path.
+ *
+ * C ABI only: raw device pointers, explicit sizes, a hipStream_t (passed as void*), int status.
+ * 0 = ok; nonzero = invalid argument / unsupported shape / HIP error, text via lhn_last_error().
+ * Nothing here allocates or frees caller memory; every tensor is borrowed for the duration of
+ * the call on the given stream.  The reference has no native interface -- each entry point cites
+ * the Python function (file:line under the reference tree) whose arithmetic it replaces.
+ *
+ * Activation layout inside the library: NHWC fp32.  A buffer may carry a *pending* per-channel
+ * transform (BatchNorm scale/shift + leaky slope, written by lhn_bn_finalize) and a per-(n,c)
+ * gate (channel attention); consumers apply   v = gate[n,c] * lrelu_slope[c](scale[c]*raw+shift[c])
+ * on load, so train-mode BatchNorm costs no extra pass over HBM.
+ */
+#ifndef LHN_H
+#define LHN_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LHN_VERSION 1
+
+typedef struct lhn_view {
+  float*       data;    /* base of the [N,H,W,cstride] buffer                                        */
+  const float* table;   /* [3][cstride] scale | shift | slope, absolute channel index; NULL=identity */
+  const float* gate;    /* [N][cstride] or NULL                                                      */
+  int32_t N, H, W;
+  int32_t cstride;      /* channels of the underlying buffer                                          */
+  int32_t coff;         /* first channel of the view                                                  */
+  int32_t C;            /* channels of the view                                                       */
+} lhn_view;
+
+/* gradient-side companion of a BatchNorm'd conv output (see DESIGN.md "backward") */
+typedef struct lhn_gradview {
+  const float* dz;       /* gradient w.r.t. the consumed value z, same geometry as the forward view  */
+  const float* dpool;    /* [N][9][cstride] d(loss)/d(pooled)/|bin| from channel attention, or NULL  */
+  const float* coef;     /* [3][cstride]  A | B | C :  dy = A*du + B*y + C   (NULL: dy = du)          */
+} lhn_gradview;
+
+int         lhn_version(void);
+const char* lhn_last_error(void);
+int         lhn_device_ok(void);              /* 0 if a gfx950 device is usable                       */
+
+/* ---------------------------------------------------------------- heatmap encode / decode / loss
+ * lhn_heatmap_encode    datasets/data_pipeline/generateTarget.py:74-159 (_msra_generate_target)
+ * lhn_heatmap_argmax    utils/post_processing/evaluation/top_down_eval.py:199-231 (_get_max_preds)
+ * lhn_heatmap_refine    .../top_down_eval.py:440-452 ('default' +-0.25 shift); mode 1 =
+ *                       utils/heatmap_post_processing.py:6-33 / utils/HeatmapParser.py:197-223 twin
+ * lhn_transform_preds   datasets/data_pipeline/post_transforms.py:6-48
+ * lhn_heatmap_decode    .../top_down_eval.py:375-463 (keypoints_from_heatmaps, 'default'), fused
+ * lhn_heatmap_nms       utils/HeatmapParser.py:41-50 (k x k max-pool peak keep)
+ * lhn_pck_accuracy      .../top_down_eval.py:12-62,129-165
+ * lhn_loss_balanced_mse loss/loss.py:93-114 + loss/heatmapLoss.py:242-265
+ */
+int lhn_heatmap_encode(const float* joints /*[N,K,3]*/, const float* visible /*[N,K,3]*/,
+                       float* target /*[N,K,H,W]*/, float* weight /*[N,K]*/, int N, int K, int H, int W,
+                       float img_w, float img_h, float sigma, int unbiased, void* stream);
+int lhn_heatmap_argmax(const float* hm /*[N,K,H,W]*/, float* preds /*[N,K,2]*/, float* maxvals /*[N,K]*/,
+                       int32_t* index /*[N,K] or NULL*/, int N, int K, int H, int W, void* stream);
+int lhn_heatmap_refine(const float* hm, float* preds /*[N,K,2] in/out*/, int N, int K, int H, int W,
+                       int mode, void* stream);
+int lhn_transform_preds(const float* coords /*[N,K,2]*/, const float* center /*[N,2]*/,
+                        const float* scale /*[N,2]*/, float* out /*[N,K,2]*/, int N, int K, int W, int H,
+                        int use_udp, void* stream);
+int lhn_heatmap_decode(const float* hm, const float* center, const float* scale, float* hm_preds,
+                       float* preds, float* maxvals, int N, int K, int H, int W, int post_process,
+                       void* stream);
+int lhn_heatmap_nms(float* hm /*in place*/, float* scratch /*same size*/, int N, int K, int H, int W,
+                    int kernel, void* stream);
+int lhn_pck_accuracy(const float* pred, const float* gt, const uint8_t* mask /*[N,K]*/,
+                     const float* normalize /*[N,2]*/, float thr, float* acc /*[K]*/,
+                     float* avg_cnt /*[2]: avg, cnt*/, int N, int K, void* stream);
+/* acc: double[4] = {S_pos, S_neg, n_pos (exact integer < 2^53), unused}; zeroed by the call */
+int lhn_loss_balanced_mse_fwd(const float* out, const float* target, const float* weight /*[N,K]*/,
+                              double* acc, float* loss /*[1]*/, int64_t NK, int64_t HW, float loss_weight,
+                              int balance, void* stream);
+int lhn_loss_balanced_mse_bwd(const float* out, const float* target, const float* weight,
+                              const double* acc, const float* dloss /*[1] or NULL=1*/, float* dout,
+                              int64_t NK, int64_t HW, float loss_weight, int balance, void* stream);
+
+/* ---------------------------------------------------------------- conv building blocks (NHWC)
+ * lhn_conv_pw_*    1x1 convolution of RepConv / nn.Conv2d            repblocks.py:8-44
+ * lhn_conv_dw_*    depthwise k x k (dilation, stride) of RepConv     repblocks.py:8-44, liteHandNet.py:8-21
+ * lhn_conv_stem_*  dense k x k on the 3-channel NCHW image           litehourglass.py:170, liteHandNet.py:175
+ * lhn_conv_kxk_*   dense 3x3 (BasicBlock / BottleNeck)               liteHandNet.py:23-54
+ * lhn_bn_finalize  train/eval BatchNorm2d statistics -> table        torch.nn.BatchNorm2d semantics
+ * stats: double[2][Cout] (sum, sum of squares), accumulated with atomics; caller zeroes.
+ */
+int lhn_conv_pw_fwd(const lhn_view* x, const float* w /*[Cout,Cin]*/, const float* bias /*or NULL*/,
+                    const lhn_view* y, double* stats /*or NULL*/, int stride, float* y_nchw /*or NULL*/,
+                    void* stream);
+int lhn_conv_dw_fwd(const lhn_view* x, const float* w /*[C,1,k,k]*/, const lhn_view* y, double* stats,
+                    int k, int stride, int pad, int dil, void* stream);
+int lhn_conv_stem_fwd(const float* img /*[N,3,Hi,Wi]*/, const float* w /*[Cout,3,k,k]*/, const lhn_view* y,
+                      double* stats, int Hi, int Wi, int k, int stride, int pad, void* stream);
+int lhn_conv_kxk_fwd(const lhn_view* x, const float* w /*[Cout,Cin,3,3]*/, const lhn_view* y, double* stats,
+                     int stride, void* stream);
+int lhn_bn_finalize(const double* stats, const float* gamma, const float* beta, float* running_mean,
+                    float* running_var, int64_t* num_batches_tracked, float* table, int cstride, int coff,
+                    int C, float* save_mean_invstd /*[2][C]*/, double count, float eps, float momentum,
+                    float slope, int training, void* stream);
+int lhn_table_fill(float* table, int cstride, int coff, int C, float scale, float shift, float slope,
+                   void* stream);
+
+/* elementwise / pooling (liteHandNet.py:88-113, litehourglass.py:136-163, common.py:40-66) */
+int lhn_ew_fwd(const lhn_view* srcs, int nsrc, const lhn_view* dst, float out_slope, void* stream);
+int lhn_maxpool2_fwd(const lhn_view* x, const lhn_view* y, void* stream);
+int lhn_avgpool_fwd(const lhn_view* x, float* out /*[N,OH,OW,x.C]*/, int OH, int OW, void* stream);
+int lhn_ca_mlp_fwd(const float* pooled /*[N,9,C]*/, const float* w3 /*[C,1,3,3]*/, const float* gamma,
+                   const float* beta, float* rmean, float* rvar, int64_t* nbt, const float* w1 /*[C/2,C]*/,
+                   const float* b1, const float* w2 /*[C,C/2]*/, const float* b2, const float* dropmask,
+                   float* gate, int gate_stride, int gate_coff, float* save /*see DESIGN*/, int N, int C,
+                   float eps, float momentum, int training, void* stream);
+
+/* backward building blocks */
+int lhn_bn_bwd_reduce(const lhn_view* y, const lhn_gradview* g, const float* save_mean_invstd,
+                      double* sums /*[2][C]: sum du, sum du*xhat*/, void* stream);
+int lhn_bn_bwd_finalize(const double* sums, const float* gamma, const float* save_mean_invstd,
+                        float* coef, int cstride, int coff, int C, double count, float* dgamma, float* dbeta,
+                        void* stream);
+int lhn_conv_pw_bwd(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy,
+                    float* dx /*grad buffer of x, same geometry, or NULL*/, int dx_accumulate, float* dw,
+                    float* dbias, int stride, const float* dy_nchw, void* stream);
+int lhn_conv_dw_bwd(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx,
+                    int dx_accumulate, float* dw, int k, int stride, int pad, int dil, void* stream);
+int lhn_conv_stem_bwd(const float* img, const lhn_view* y, const lhn_gradview* gy, float* dw, int Hi, int Wi,
+                      int k, int stride, int pad, void* stream);
+int lhn_conv_kxk_bwd(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx,
+                     int dx_accumulate, float* dw, int stride, void* stream);
+int lhn_ew_bwd(const lhn_view* srcs, int nsrc, const lhn_view* dst, const float* ddst, float out_slope,
+               float* const* dsrcs, const int* accumulate, void* stream);
+/* single-source form used by the plan: dst may carry a gate and a pooled gradient (channel attention) */
+int lhn_ew_bwd2(const lhn_view* src, const lhn_view* dst, const float* ddst, const float* dst_dpool, float out_slope,
+                float* dsrc, int accumulate, void* stream);
+int lhn_maxpool2_bwd(const lhn_view* x, const lhn_view* y, const float* dy, float* dx, int dx_accumulate,
+                     void* stream);
+int lhn_avgpool_bwd(const lhn_view* x, const float* dout /*[N,OH,OW,C]*/, int OH, int OW, float* dx,
+                    int dx_accumulate, void* stream);
+int lhn_gate_bwd_reduce(const lhn_view* y, const float* dz, float* dgate /*[N][C] dense*/, void* stream);
+int lhn_ca_mlp_bwd(const float* pooled, const float* w3, const float* gamma, const float* w1, const float* w2,
+                   const float* dropmask, const float* save, const float* dgate, float* dpool /*[N,9,cs]*/,
+                   int cstride, int coff, int H, int W, float* dw3, float* dgamma, float* dbeta, float* dw1,
+                   float* db1, float* dw2, float* db2, int N, int C, void* stream);
+
+/* ---------------------------------------------------------------- plan executor
+ * A plan is a static list of the calls above over one workspace arena, built by the Python
+ * mirror of the reference's nn.Module tree (models/__init__.py:20-26 get_model).  One
+ * lhn_plan_run() enqueues a whole forward (phase 0) or backward (phase 1) on the stream. */
+typedef struct lhn_op {
+  int32_t kind;
+  int32_t in_buf[3], in_coff[3], in_C[3];
+  int32_t out_buf, out_coff, out_C;
+  int32_t p[12];       /* parameter / state indices into the params array, -1 = none              */
+  int64_t ws[6];       /* byte offsets into the workspace, -1 = none                               */
+  int32_t i[8];
+  float   f[4];
+} lhn_op;
+
+typedef struct lhn_buf {
+  int64_t data_off, table_off, gate_off, grad_off, dpool_off, coef_off;  /* bytes, -1 = none */
+  int32_t N, H, W, C;
+} lhn_buf;
+
+void* lhn_plan_create(const lhn_buf* bufs, int nbufs, const lhn_op* fwd, int nfwd, const lhn_op* bwd, int nbwd);
+void  lhn_plan_destroy(void* plan);
+/* io: phase 0 {image NCHW, heatmap NCHW out}; phase 1 {image NCHW, d(heatmap) NCHW} */
+int   lhn_plan_run(void* plan, int phase, void* workspace, void* const* params, void* const* grads,
+                   void* const* io, int training, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,25 @@
+"""HIP-backed mirror of models/pose_estimation/liteHandNet/common.py:40-66 (ChannelAttension)."""
+from torch import nn
+
+from .engine import PlanModule
+
+
+class ChannelAttension(PlanModule):
+    """x * sigmoid(W2 lrelu(W1 dropout2d(BN(dw3x3_valid(adaptive_avg_pool(x,3))))))  (the reference's spelling)."""
+
+    def __init__(self, channel, deploy=False, p_drop=0.3):
+        super().__init__()
+        assert not deploy
+        self.conv3x3 = nn.Sequential()
+        self.conv3x3.add_module("conv", nn.Conv2d(channel, channel, 3, 1, 0, groups=channel, bias=False))
+        self.conv3x3.add_module("bn", nn.BatchNorm2d(channel))
+        self.conv1x1 = nn.Sequential(nn.Dropout2d(p=p_drop), nn.Conv2d(channel, channel // 2, 1, 1, 0),
+                                     nn.LeakyReLU(inplace=True), nn.Conv2d(channel // 2, channel, 1, 1, 0),
+                                     nn.Sigmoid())
+
+    def emit(self, pb, x, out=None):
+        # the gate attaches to the buffer behind x; a view that does not own its buffer is materialised first
+        b = pb.bufs[x.buf]
+        if x.coff != 0 or x.C != b.C or b.gate:
+            x = pb.ew([x])
+        return pb.channel_attention(x, self)

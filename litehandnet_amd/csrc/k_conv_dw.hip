@@ -1,0 +1,362 @@
+// Depthwise k x k convolution (stride, dilation) and the 3-channel stem convolution, NHWC fp32.
+// HBM-bound: each thread owns 4 channels of one output pixel and gathers its taps through L1/L2
+// (neighbouring outputs share them), applying the producer's pending BatchNorm/activation on load;
+// the epilogue accumulates this layer's BatchNorm statistics (one double atomic per block+channel).
+#include "lhn_common.h"
+
+// ------------------------------------------------------------------ depthwise forward
+__global__ void __launch_bounds__(256) k_dw_fwd(lhn_view x, const float* __restrict__ w, lhn_view y,
+                                                double* __restrict__ stats, int K, int stride, int pad, int dil) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int C = x.C, C4 = C >> 2, KK = K * K;
+  float* Ws = smem;                                   // [KK][C]
+  f4* red = reinterpret_cast<f4*>(smem + KK * C);     // [256][2]
+  const int tid = threadIdx.x;
+  for (int i = tid; i < KK * C; i += 256) {
+    const int c = i / KK, t = i - c * KK;
+    Ws[t * C + c] = w[i];
+  }
+  __syncthreads();
+  const int c4 = tid % C4, pl = tid / C4, PL = 256 / C4;
+  const int cin = x.coff + 4 * c4, cout = y.coff + 4 * c4;
+  const Xf4 xf = lhn_load_xf(x, cin);
+  const int64_t total = (int64_t)y.N * y.H * y.W;
+  f4 s = (f4){0.f, 0.f, 0.f, 0.f}, q = s;
+  for (int64_t pix = (int64_t)blockIdx.x * PL + pl; pix < total; pix += (int64_t)gridDim.x * PL) {
+    const int wo = (int)(pix % y.W);
+    const int64_t t = pix / y.W;
+    const int ho = (int)(t % y.H), n = (int)(t / y.H);
+    f4 acc = (f4){0.f, 0.f, 0.f, 0.f};
+    for (int kh = 0; kh < K; ++kh) {
+      const int ih = ho * stride - pad + kh * dil;
+      if (ih < 0 || ih >= x.H) continue;
+      for (int kw = 0; kw < K; ++kw) {
+        const int iw = wo * stride - pad + kw * dil;
+        if (iw < 0 || iw >= x.W) continue;
+        const f4 v = lhn_load_val(x, xf, ((int64_t)n * x.H + ih) * x.W + iw, n, cin);
+        acc += v * *reinterpret_cast<const f4*>(Ws + (kh * K + kw) * C + 4 * c4);
+      }
+    }
+    *reinterpret_cast<f4*>(y.data + pix * y.cstride + cout) = acc;
+    s += acc;
+    q += acc * acc;
+  }
+  if (stats) {
+    red[tid * 2] = s;
+    red[tid * 2 + 1] = q;
+    __syncthreads();
+    if (tid < C4) {
+      double sd[4] = {0, 0, 0, 0}, qd[4] = {0, 0, 0, 0};
+      for (int j = 0; j < PL; ++j) {
+        const f4 a = red[(j * C4 + tid) * 2], b = red[(j * C4 + tid) * 2 + 1];
+        sd[0] += a.x; sd[1] += a.y; sd[2] += a.z; sd[3] += a.w;
+        qd[0] += b.x; qd[1] += b.y; qd[2] += b.z; qd[3] += b.w;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        atomicAdd(stats + 4 * tid + j, sd[j]);
+        atomicAdd(stats + C + 4 * tid + j, qd[j]);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ stem forward (NCHW 3-channel image -> NHWC)
+// thread = (output pixel, group of 8 output channels)
+__global__ void __launch_bounds__(256) k_stem_fwd(const float* __restrict__ img, const float* __restrict__ w, lhn_view y,
+                                                  double* __restrict__ stats, int Hi, int Wi, int K, int stride, int pad) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int CO = y.C, CG = CO >> 3, KK = K * K, T = 3 * KK;
+  float* Ws = smem;                                  // [T][CO]
+  float* red = smem + T * CO;                        // [256][16]
+  const int tid = threadIdx.x;
+  for (int i = tid; i < T * CO; i += 256) {
+    const int co = i / T, t = i - co * T;
+    Ws[t * CO + co] = w[i];
+  }
+  __syncthreads();
+  const int cg = tid % CG, pl = tid / CG, PL = 256 / CG;
+  const int64_t total = (int64_t)y.N * y.H * y.W;
+  float s[8], q[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.f;
+  for (int64_t pix = (int64_t)blockIdx.x * PL + pl; pix < total; pix += (int64_t)gridDim.x * PL) {
+    const int wo = (int)(pix % y.W);
+    const int64_t t = pix / y.W;
+    const int ho = (int)(t % y.H), n = (int)(t / y.H);
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int c = 0; c < 3; ++c) {
+      const float* plane = img + ((int64_t)n * 3 + c) * Hi * Wi;
+      for (int kh = 0; kh < K; ++kh) {
+        const int ih = ho * stride - pad + kh;
+        if (ih < 0 || ih >= Hi) continue;
+        for (int kw = 0; kw < K; ++kw) {
+          const int iw = wo * stride - pad + kw;
+          if (iw < 0 || iw >= Wi) continue;
+          const float v = plane[(int64_t)ih * Wi + iw];
+          const float* wr = Ws + (c * KK + kh * K + kw) * CO + cg * 8;
+          const f4 w0 = *reinterpret_cast<const f4*>(wr), w1 = *reinterpret_cast<const f4*>(wr + 4);
+          acc[0] += v * w0.x; acc[1] += v * w0.y; acc[2] += v * w0.z; acc[3] += v * w0.w;
+          acc[4] += v * w1.x; acc[5] += v * w1.y; acc[6] += v * w1.z; acc[7] += v * w1.w;
+        }
+      }
+    }
+    float* o = y.data + pix * y.cstride + y.coff + cg * 8;
+    *reinterpret_cast<f4*>(o) = (f4){acc[0], acc[1], acc[2], acc[3]};
+    *reinterpret_cast<f4*>(o + 4) = (f4){acc[4], acc[5], acc[6], acc[7]};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      s[j] += acc[j];
+      q[j] += acc[j] * acc[j];
+    }
+  }
+  if (stats) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      red[tid * 16 + j] = s[j];
+      red[tid * 16 + 8 + j] = q[j];
+    }
+    __syncthreads();
+    if (tid < CO) {
+      const int g = tid >> 3, j = tid & 7;
+      double sd = 0, qd = 0;
+      for (int p = 0; p < PL; ++p) {
+        sd += red[(p * CG + g) * 16 + j];
+        qd += red[(p * CG + g) * 16 + 8 + j];
+      }
+      atomicAdd(stats + tid, sd);
+      atomicAdd(stats + CO + tid, qd);
+    }
+  }
+}
+
+static inline int grid_for(int64_t items_per_block_total, int per_block, int cap_per_cu) {
+  int64_t g = (items_per_block_total + per_block - 1) / per_block;
+  const int64_t cap = (int64_t)lhn_num_cus() * cap_per_cu;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+static inline bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+extern "C" int lhn_conv_dw_fwd(const lhn_view* x, const float* w, const lhn_view* y, double* stats, int k, int stride,
+                               int pad, int dil, void* stream) {
+  LHN_CHECK_ARG(lhn_view_ok(x) && lhn_view_ok(y) && w, "lhn_conv_dw_fwd: bad view / null pointer");
+  LHN_CHECK_ARG(x->C == y->C && pow2(x->C) && x->C <= 256, "lhn_conv_dw_fwd: channels %d -> %d (power of two <= 256)", x->C, y->C);
+  LHN_CHECK_ARG(k >= 1 && k <= 7 && (k & 1) && stride >= 1 && dil >= 1 && pad >= 0, "lhn_conv_dw_fwd: k=%d stride=%d dil=%d", k, stride, dil);
+  const int Ho = (x->H + 2 * pad - dil * (k - 1) - 1) / stride + 1, Wo = (x->W + 2 * pad - dil * (k - 1) - 1) / stride + 1;
+  LHN_CHECK_ARG(y->N == x->N && y->H == Ho && y->W == Wo, "lhn_conv_dw_fwd: output %dx%d, expected %dx%d", y->H, y->W, Ho, Wo);
+  const int PL = 256 / (x->C / 4);
+  const size_t lds = (size_t)(k * k * x->C) * 4 + 256 * 2 * 16;
+  hipLaunchKernelGGL(k_dw_fwd, dim3(grid_for((int64_t)y->N * Ho * Wo, PL, 8)), dim3(256), lds, (hipStream_t)stream, *x, w,
+                     *y, stats, k, stride, pad, dil);
+  LHN_CHECK_LAUNCH("lhn_conv_dw_fwd");
+  return 0;
+}
+
+extern "C" int lhn_conv_stem_fwd(const float* img, const float* w, const lhn_view* y, double* stats, int Hi, int Wi, int k,
+                                 int stride, int pad, void* stream) {
+  LHN_CHECK_ARG(img && w && lhn_view_ok(y), "lhn_conv_stem_fwd: bad view / null pointer");
+  LHN_CHECK_ARG(y->C % 8 == 0 && pow2(y->C / 8) && y->C <= 256, "lhn_conv_stem_fwd: Cout=%d", y->C);
+  LHN_CHECK_ARG((k == 1 || k == 3) && stride >= 1, "lhn_conv_stem_fwd: k=%d", k);
+  const int Ho = (Hi + 2 * pad - k) / stride + 1, Wo = (Wi + 2 * pad - k) / stride + 1;
+  LHN_CHECK_ARG(y->H == Ho && y->W == Wo, "lhn_conv_stem_fwd: output %dx%d, expected %dx%d", y->H, y->W, Ho, Wo);
+  const int PL = 256 / (y->C / 8);
+  const size_t lds = (size_t)(3 * k * k * y->C) * 4 + 256 * 16 * 4;
+  hipLaunchKernelGGL(k_stem_fwd, dim3(grid_for((int64_t)y->N * Ho * Wo, PL, 8)), dim3(256), lds, (hipStream_t)stream, img,
+                     w, *y, stats, Hi, Wi, k, stride, pad);
+  LHN_CHECK_LAUNCH("lhn_conv_stem_fwd");
+  return 0;
+}
+
+// =====================================================================================================
+// Backward.  dy is formed on the fly:  du = lrelu'(u) * (gate*dz + pooled-gradient),  dy = A*du + B*y + C.
+__device__ __forceinline__ f4 dw_load_dy(const lhn_view& y, const lhn_gradview& g, const Xf4& xf, const Gr4& gr,
+                                         int64_t pix, int n, int h, int w, int ca) {
+  const f4 raw = *reinterpret_cast<const f4*>(y.data + pix * y.cstride + ca);
+  const f4 dz = *reinterpret_cast<const f4*>(g.dz + pix * y.cstride + ca);
+  const f4 du = lhn_grad_du(y, g, xf, raw, dz, n, h, w, ca);
+  return gr.A * du + gr.B * raw + gr.Cc;
+}
+
+// dgrad: one thread = 4 channels of one INPUT pixel
+__global__ void __launch_bounds__(256) k_dw_bwd_data(lhn_view x, const float* __restrict__ w, lhn_view y, lhn_gradview gy,
+                                                     float* __restrict__ dx, int accumulate, int K, int stride, int pad,
+                                                     int dil) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int C = x.C, C4 = C >> 2, KK = K * K;
+  float* Ws = smem;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < KK * C; i += 256) {
+    const int c = i / KK, t = i - c * KK;
+    Ws[t * C + c] = w[i];
+  }
+  __syncthreads();
+  const int c4 = tid % C4, pl = tid / C4, PL = 256 / C4;
+  const int cx = x.coff + 4 * c4, cy = y.coff + 4 * c4;
+  const Xf4 yxf = lhn_load_xf(y, cy);
+  const Gr4 ygr = lhn_load_coef(gy, y.cstride, cy);
+  const int64_t total = (int64_t)x.N * x.H * x.W;
+  for (int64_t pix = (int64_t)blockIdx.x * PL + pl; pix < total; pix += (int64_t)gridDim.x * PL) {
+    const int wi = (int)(pix % x.W);
+    const int64_t t = pix / x.W;
+    const int hi = (int)(t % x.H), n = (int)(t / x.H);
+    f4 acc = (f4){0.f, 0.f, 0.f, 0.f};
+    for (int kh = 0; kh < K; ++kh) {
+      const int hn = hi + pad - kh * dil;
+      if (hn < 0 || hn % stride) continue;
+      const int ho = hn / stride;
+      if (ho >= y.H) continue;
+      for (int kw = 0; kw < K; ++kw) {
+        const int wn = wi + pad - kw * dil;
+        if (wn < 0 || wn % stride) continue;
+        const int wo = wn / stride;
+        if (wo >= y.W) continue;
+        const f4 dy = dw_load_dy(y, gy, yxf, ygr, ((int64_t)n * y.H + ho) * y.W + wo, n, ho, wo, cy);
+        acc += dy * *reinterpret_cast<const f4*>(Ws + (kh * K + kw) * C + 4 * c4);
+      }
+    }
+    float* o = dx + pix * x.cstride + cx;
+    if (accumulate) acc += *reinterpret_cast<const f4*>(o);
+    *reinterpret_cast<f4*>(o) = acc;
+  }
+}
+
+// wgrad: one thread = 4 channels, grid-stride over OUTPUT pixels; KR kernel rows [kh0, kh0+KR) per launch
+template <int K, int KR>
+__global__ void __launch_bounds__(256) k_dw_bwd_weight(lhn_view x, lhn_view y, lhn_gradview gy, float* __restrict__ dw,
+                                                       int stride, int pad, int dil, int kh0) {
+  __shared__ f4 red[256];
+  const int C4 = x.C >> 2;
+  const int tid = threadIdx.x, c4 = tid % C4, pl = tid / C4, PL = 256 / C4;
+  const int cx = x.coff + 4 * c4, cy = y.coff + 4 * c4;
+  const Xf4 xxf = lhn_load_xf(x, cx), yxf = lhn_load_xf(y, cy);
+  const Gr4 ygr = lhn_load_coef(gy, y.cstride, cy);
+  f4 acc[KR * K];
+#pragma unroll
+  for (int i = 0; i < KR * K; ++i) acc[i] = (f4){0.f, 0.f, 0.f, 0.f};
+  const int64_t total = (int64_t)y.N * y.H * y.W;
+  for (int64_t pix = (int64_t)blockIdx.x * PL + pl; pix < total; pix += (int64_t)gridDim.x * PL) {
+    const int wo = (int)(pix % y.W);
+    const int64_t t = pix / y.W;
+    const int ho = (int)(t % y.H), n = (int)(t / y.H);
+    const f4 dy = dw_load_dy(y, gy, yxf, ygr, pix, n, ho, wo, cy);
+#pragma unroll
+    for (int r = 0; r < KR; ++r) {
+      const int ih = ho * stride - pad + (kh0 + r) * dil;
+      if (ih < 0 || ih >= x.H) continue;
+#pragma unroll
+      for (int kw = 0; kw < K; ++kw) {
+        const int iw = wo * stride - pad + kw * dil;
+        if (iw < 0 || iw >= x.W) continue;
+        acc[r * K + kw] += dy * lhn_load_val(x, xxf, ((int64_t)n * x.H + ih) * x.W + iw, n, cx);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < KR * K; ++i) {
+    __syncthreads();
+    red[tid] = acc[i];
+    __syncthreads();
+    if (tid < C4) {
+      f4 s = (f4){0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < PL; ++j) s += red[j * C4 + tid];
+      const int tap = (kh0 + i / K) * K + (i % K);
+      atomicAdd(dw + (4 * tid + 0) * K * K + tap, s.x);
+      atomicAdd(dw + (4 * tid + 1) * K * K + tap, s.y);
+      atomicAdd(dw + (4 * tid + 2) * K * K + tap, s.z);
+      atomicAdd(dw + (4 * tid + 3) * K * K + tap, s.w);
+    }
+  }
+}
+
+// stem wgrad: thread = (pixel lane, 4 output channels); T = 3*K*K accumulators of float4
+template <int K>
+__global__ void __launch_bounds__(256) k_stem_bwd(const float* __restrict__ img, lhn_view y, lhn_gradview gy,
+                                                  float* __restrict__ dw, int Hi, int Wi, int stride, int pad) {
+  constexpr int T = 3 * K * K;
+  __shared__ f4 red[256];
+  const int C4 = y.C >> 2;
+  const int tid = threadIdx.x, c4 = tid % C4, pl = tid / C4, PL = 256 / C4;
+  const int cy = y.coff + 4 * c4;
+  const Xf4 yxf = lhn_load_xf(y, cy);
+  const Gr4 ygr = lhn_load_coef(gy, y.cstride, cy);
+  f4 acc[T];
+#pragma unroll
+  for (int i = 0; i < T; ++i) acc[i] = (f4){0.f, 0.f, 0.f, 0.f};
+  const int64_t total = (int64_t)y.N * y.H * y.W;
+  for (int64_t pix = (int64_t)blockIdx.x * PL + pl; pix < total; pix += (int64_t)gridDim.x * PL) {
+    const int wo = (int)(pix % y.W);
+    const int64_t t = pix / y.W;
+    const int ho = (int)(t % y.H), n = (int)(t / y.H);
+    const f4 dy = dw_load_dy(y, gy, yxf, ygr, pix, n, ho, wo, cy);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float* plane = img + ((int64_t)n * 3 + c) * Hi * Wi;
+#pragma unroll
+      for (int kh = 0; kh < K; ++kh) {
+        const int ih = ho * stride - pad + kh;
+#pragma unroll
+        for (int kw = 0; kw < K; ++kw) {
+          const int iw = wo * stride - pad + kw;
+          float v = 0.f;
+          if (ih >= 0 && ih < Hi && iw >= 0 && iw < Wi) v = plane[(int64_t)ih * Wi + iw];
+          acc[c * K * K + kh * K + kw] += dy * v;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < T; ++i) {
+    __syncthreads();
+    red[tid] = acc[i];
+    __syncthreads();
+    if (tid < C4) {
+      f4 s = (f4){0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < PL; ++j) s += red[j * C4 + tid];
+      atomicAdd(dw + (4 * tid + 0) * T + i, s.x);
+      atomicAdd(dw + (4 * tid + 1) * T + i, s.y);
+      atomicAdd(dw + (4 * tid + 2) * T + i, s.z);
+      atomicAdd(dw + (4 * tid + 3) * T + i, s.w);
+    }
+  }
+}
+
+extern "C" int lhn_conv_dw_bwd(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx,
+                               int dx_accumulate, float* dw, int k, int stride, int pad, int dil, void* stream) {
+  LHN_CHECK_ARG(lhn_view_ok(x) && lhn_view_ok(y) && w && gy && gy->dz && dw, "lhn_conv_dw_bwd: bad view / null pointer");
+  LHN_CHECK_ARG(x->C == y->C && pow2(x->C) && x->C <= 256, "lhn_conv_dw_bwd: channels");
+  LHN_CHECK_ARG(k == 3 || k == 7, "lhn_conv_dw_bwd: k=%d (3 or 7)", k);
+  hipStream_t s = (hipStream_t)stream;
+  const int PL = 256 / (x->C / 4);
+  if (dx) {
+    const size_t lds = (size_t)(k * k * x->C) * 4;
+    hipLaunchKernelGGL(k_dw_bwd_data, dim3(grid_for((int64_t)x->N * x->H * x->W, PL, 8)), dim3(256), lds, s, *x, w, *y, *gy, dx,
+                       dx_accumulate, k, stride, pad, dil);
+  }
+  const int gw = grid_for((int64_t)y->N * y->H * y->W, PL, 4);
+  if (k == 3) {
+    hipLaunchKernelGGL((k_dw_bwd_weight<3, 3>), dim3(gw), dim3(256), 0, s, *x, *y, *gy, dw, stride, pad, dil, 0);
+  } else {
+    for (int kh = 0; kh < 7; ++kh)
+      hipLaunchKernelGGL((k_dw_bwd_weight<7, 1>), dim3(gw), dim3(256), 0, s, *x, *y, *gy, dw, stride, pad, dil, kh);
+  }
+  LHN_CHECK_LAUNCH("lhn_conv_dw_bwd");
+  return 0;
+}
+
+extern "C" int lhn_conv_stem_bwd(const float* img, const lhn_view* y, const lhn_gradview* gy, float* dw, int Hi, int Wi, int k,
+                                 int stride, int pad, void* stream) {
+  LHN_CHECK_ARG(img && lhn_view_ok(y) && gy && gy->dz && dw, "lhn_conv_stem_bwd: bad view / null pointer");
+  LHN_CHECK_ARG(pow2(y->C / 4) && y->C <= 256 && (k == 1 || k == 3), "lhn_conv_stem_bwd: Cout=%d k=%d", y->C, k);
+  const int PL = 256 / (y->C / 4);
+  const int g = grid_for((int64_t)y->N * y->H * y->W, PL, 4);
+  if (k == 3)
+    hipLaunchKernelGGL((k_stem_bwd<3>), dim3(g), dim3(256), 0, (hipStream_t)stream, img, *y, *gy, dw, Hi, Wi, stride, pad);
+  else
+    hipLaunchKernelGGL((k_stem_bwd<1>), dim3(g), dim3(256), 0, (hipStream_t)stream, img, *y, *gy, dw, Hi, Wi, stride, pad);
+  LHN_CHECK_LAUNCH("lhn_conv_stem_bwd");
+  return 0;
+}

@@ -1,0 +1,470 @@
+// 1x1 (pointwise) convolution on fp32 MFMA, NHWC, with the producer's pending BatchNorm/activation
+// applied on load and this layer's BatchNorm statistics accumulated in the epilogue.
+//   Y[m][co] = sum_ci X[m][ci] * W[co][ci]        m = output pixel, X = consumed value of the input view
+// Tile: 128 pixels x (32*NT) output channels per 256-thread block; wave w owns pixel rows [32w,32w+32).
+// MFMA: v_mfma_f32_32x32x2_f32 (exact fp32 fma chain).  Operands come from LDS images with a +4 float
+// row pad so that every ds_read_b128 is conflict-free (row stride = odd number of 16-B slots).
+// K order inside an 8-wide chunk is permuted (lane half h supplies k = 8*kc + 4*h + j at step j); both
+// operands use the same permutation, so only the fp32 summation order differs from a sequential loop.
+#include "lhn_common.h"
+
+template <int CIN, int NT>
+__global__ void __launch_bounds__(256) k_pw_fwd(lhn_view x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                lhn_view y, double* __restrict__ stats, int stride,
+                                                float* __restrict__ y_nchw, int cout, int M, int ntiles) {
+  constexpr int LDA = CIN + 4;
+  constexpr int PF = CIN / 8;   // float4 loads per thread per 128-pixel tile
+  constexpr int C4 = CIN / 4;   // float4 per pixel row
+  constexpr int RP = 256 / C4;  // rows covered per pass
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ws = smem;                    // [32*NT][LDA]
+  float* As = smem + 32 * NT * LDA;    // [128][LDA]
+  float* red = As + 128 * LDA;         // [4][32*NT][2]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  for (int i = tid; i < 32 * NT * C4; i += 256) {
+    const int co = i / C4, k4 = i % C4;
+    f4 v = (f4){0.f, 0.f, 0.f, 0.f};
+    if (co < cout) v = *reinterpret_cast<const f4*>(w + (int64_t)co * CIN + k4 * 4);
+    *reinterpret_cast<f4*>(Ws + co * LDA + k4 * 4) = v;
+  }
+
+  const int c4 = tid % C4, row0 = tid / C4;
+  const int cabs = x.coff + 4 * c4;
+  const Xf4 xf = lhn_load_xf(x, cabs);
+  const int HoWo = y.H * y.W;
+
+  f4 pre[PF];
+  auto in_pix = [&](int m) -> int64_t {
+    if (stride == 1) return m;
+    const int n = m / HoWo, r = m - n * HoWo;
+    const int ho = r / y.W, wo = r - ho * y.W;
+    return ((int64_t)n * x.H + ho * stride) * x.W + wo * stride;
+  };
+  auto issue = [&](int tile) {
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {
+      const int m = tile * 128 + row0 + p * RP;
+      pre[p] = (f4){0.f, 0.f, 0.f, 0.f};
+      if (m < M) pre[p] = *reinterpret_cast<const f4*>(x.data + in_pix(m) * x.cstride + cabs);
+    }
+  };
+  auto commit = [&](int tile) {
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {
+      const int row = row0 + p * RP, m = tile * 128 + row;
+      f4 v = (f4){0.f, 0.f, 0.f, 0.f};
+      if (m < M) {
+        v = lhn_apply_xf(pre[p], xf);
+        if (x.gate) v *= *reinterpret_cast<const f4*>(x.gate + (int64_t)(m / HoWo) * x.cstride + cabs);
+      }
+      *reinterpret_cast<f4*>(As + row * LDA + 4 * c4) = v;
+    }
+  };
+
+  float ssum[NT], ssq[NT], bv[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    ssum[nt] = ssq[nt] = 0.f;
+    const int ch = nt * 32 + l31;
+    bv[nt] = (bias && ch < cout) ? bias[ch] : 0.f;
+  }
+
+  int tile = blockIdx.x;
+  if (tile < ntiles) issue(tile);
+  for (; tile < ntiles; tile += gridDim.x) {
+    commit(tile);
+    __syncthreads();
+    const int next = tile + gridDim.x;
+    if (next < ntiles) issue(next);
+
+    f16v acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+
+    const float* arow = As + (wave * 32 + l31) * LDA + 4 * lh;
+    const float* brow = Ws + l31 * LDA + 4 * lh;
+#pragma unroll 4
+    for (int kc = 0; kc < CIN / 8; ++kc) {
+      const f4 a = *reinterpret_cast<const f4*>(arow + kc * 8);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const f4 b = *reinterpret_cast<const f4*>(brow + nt * 32 * LDA + kc * 8);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[nt], 0, 0, 0);
+      }
+    }
+
+    // epilogue: C/D layout col = lane&31 (channel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel)
+    const int mbase = tile * 128 + wave * 32 + 4 * lh;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int ch = nt * 32 + l31;
+      if (ch >= cout) continue;
+      if (y_nchw) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int m0 = mbase + 8 * g;
+          if (m0 < M) {  // HoWo % 4 == 0 is checked on the host: 4 consecutive pixels share an image
+            const int n = m0 / HoWo, p = m0 - n * HoWo;
+            f4 o = (f4){acc[nt][4 * g] + bv[nt], acc[nt][4 * g + 1] + bv[nt], acc[nt][4 * g + 2] + bv[nt],
+                        acc[nt][4 * g + 3] + bv[nt]};
+            *reinterpret_cast<f4*>(y_nchw + ((int64_t)n * cout + ch) * HoWo + p) = o;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mbase + (r & 3) + 8 * (r >> 2);
+          if (m < M) {
+            const float v = acc[nt][r] + bv[nt];
+            y.data[(int64_t)m * y.cstride + y.coff + ch] = v;
+            ssum[nt] += v;
+            ssq[nt] += v * v;
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  if (stats) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const float s = ssum[nt] + __shfl_xor(ssum[nt], 32, 64);
+      const float q = ssq[nt] + __shfl_xor(ssq[nt], 32, 64);
+      if (lh == 0) {
+        red[(wave * 32 * NT + nt * 32 + l31) * 2 + 0] = s;
+        red[(wave * 32 * NT + nt * 32 + l31) * 2 + 1] = q;
+      }
+    }
+    __syncthreads();
+    if (tid < 32 * NT && tid < cout) {
+      double s = 0, q = 0;
+#pragma unroll
+      for (int wv = 0; wv < 4; ++wv) {
+        s += (double)red[(wv * 32 * NT + tid) * 2 + 0];
+        q += (double)red[(wv * 32 * NT + tid) * 2 + 1];
+      }
+      atomicAdd(stats + tid, s);
+      atomicAdd(stats + cout + tid, q);
+    }
+  }
+}
+
+template <int CIN, int NT>
+static int launch_pw_fwd(const lhn_view* x, const float* w, const float* bias, const lhn_view* y, double* stats,
+                         int stride, float* y_nchw, int cout, hipStream_t s) {
+  const int M = y->N * y->H * y->W;
+  const int ntiles = (M + 127) / 128;
+  const size_t lds = (size_t)((32 * NT + 128) * (CIN + 4) + 4 * 32 * NT * 2) * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pw_fwd<CIN, NT>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      lhn_set_error("lhn_conv_pw_fwd: cannot reserve %zu B of LDS", lds);
+      return 2;
+    }
+    attr_done = true;
+  }
+  int per_cu = (int)((160 * 1024) / lds);
+  if (per_cu > 4) per_cu = 4;
+  if (per_cu < 1) per_cu = 1;
+  int grid = lhn_num_cus() * per_cu;
+  if (grid > ntiles) grid = ntiles;
+  hipLaunchKernelGGL((k_pw_fwd<CIN, NT>), dim3(grid), dim3(256), lds, s, *x, w, bias, *y, stats, stride, y_nchw, cout, M,
+                     ntiles);
+  return 0;
+}
+
+extern "C" int lhn_conv_pw_fwd(const lhn_view* x, const float* w, const float* bias, const lhn_view* y, double* stats,
+                               int stride, float* y_nchw, void* stream) {
+  LHN_CHECK_ARG(lhn_view_ok(x) && w && y, "lhn_conv_pw_fwd: bad input view / null pointer");
+  LHN_CHECK_ARG(stride == 1 || stride == 2, "lhn_conv_pw_fwd: stride %d", stride);
+  LHN_CHECK_ARG(y->N == x->N && y->H == (x->H + stride - 1) / stride && y->W == (x->W + stride - 1) / stride,
+                "lhn_conv_pw_fwd: output geometry %dx%dx%d does not match input %dx%dx%d / stride %d", y->N, y->H, y->W,
+                x->N, x->H, x->W, stride);
+  const int cout = y->C;
+  if (y_nchw) {
+    LHN_CHECK_ARG((y->H * y->W) % 4 == 0 && cout > 0, "lhn_conv_pw_fwd: NCHW output needs H*W %% 4 == 0");
+    LHN_CHECK_ARG(!stats, "lhn_conv_pw_fwd: no statistics on the NCHW head");
+  } else {
+    LHN_CHECK_ARG(lhn_view_ok(y), "lhn_conv_pw_fwd: bad output view");
+  }
+  LHN_CHECK_ARG((int64_t)y->N * y->H * y->W < (1ll << 31) - 256, "lhn_conv_pw_fwd: too many pixels");
+  const int nt = (cout + 31) / 32;
+  hipStream_t s = (hipStream_t)stream;
+  int rc = -1;
+#define PW_CASE(CI, NTV) \
+  if (x->C == CI && nt == NTV) rc = launch_pw_fwd<CI, NTV>(x, w, bias, y, stats, stride, y_nchw, cout, s);
+  PW_CASE(32, 1) PW_CASE(32, 2) PW_CASE(32, 4) PW_CASE(64, 1) PW_CASE(64, 2) PW_CASE(64, 4) PW_CASE(128, 1)
+  PW_CASE(128, 2) PW_CASE(128, 4) PW_CASE(16, 1) PW_CASE(16, 2) PW_CASE(16, 4)
+#undef PW_CASE
+  if (nt == 3) {  // 96 output channels: run as 128 with zero rows
+#define PW_CASE3(CI) \
+  if (x->C == CI) rc = launch_pw_fwd<CI, 4>(x, w, bias, y, stats, stride, y_nchw, cout, s);
+    PW_CASE3(16) PW_CASE3(32) PW_CASE3(64) PW_CASE3(128)
+#undef PW_CASE3
+  }
+  LHN_CHECK_ARG(rc != -1, "lhn_conv_pw_fwd: unsupported channels Cin=%d Cout=%d (Cin in {16,32,64,128}, Cout<=128)", x->C,
+                cout);
+  if (rc) return rc;
+  LHN_CHECK_LAUNCH("lhn_conv_pw_fwd");
+  return 0;
+}
+
+// =====================================================================================================
+// Backward: fused dgrad + wgrad.  Per 64-pixel tile the block stages
+//     dYs[m][co] = dy  (formed on the fly from dz, the saved raw output y and the BN-backward coefficients)
+//     Xs [m][ci] = consumed input value (raw input + the producer's pending transform / gate)
+// and issues   dX[m][ci] = sum_co dYs[m][co] * W[co][ci]   (K = Cout)   -> global, store or accumulate
+//              dW[co][ci] += sum_m dYs[m][co] * Xs[m][ci]  (K = 64)     -> registers across tiles, one
+//                                                                           fp32 atomic add per block at the end
+template <int CIN, int NTO>
+__global__ void __launch_bounds__(256) k_pw_bwd(lhn_view x, const float* __restrict__ w, lhn_view y, lhn_gradview gy,
+                                                float* __restrict__ dx, int dx_acc, float* __restrict__ dw,
+                                                float* __restrict__ dbias, int stride, const float* __restrict__ dy_nchw,
+                                                int cout, int M, int ntiles) {
+  constexpr int NTI = CIN / 32;
+  constexpr int COP = 32 * NTO;
+  constexpr int LDW = CIN + 4, LDY = COP + 4, LDX = CIN + 4;
+  constexpr int NDW = (NTO * NTI + 3) / 4;   // dW tiles per wave
+  constexpr int NDX = (NTI + 1) / 2;         // dX ci-tiles per wave
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ws = smem;                 // [COP][LDW]
+  float* dYs = Ws + COP * LDW;      // [64][LDY]
+  float* Xs = dYs + 64 * LDY;       // [64][LDX]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int HoWo = y.H * y.W;
+
+  for (int i = tid; i < COP * (CIN / 4); i += 256) {
+    const int co = i / (CIN / 4), k4 = i % (CIN / 4);
+    f4 v = (f4){0.f, 0.f, 0.f, 0.f};
+    if (co < cout) v = *reinterpret_cast<const f4*>(w + (int64_t)co * CIN + k4 * 4);
+    *reinterpret_cast<f4*>(Ws + co * LDW + k4 * 4) = v;
+  }
+
+  // loader geometry: X tile 64 x CIN/4 float4, dY tile 64 x COP/4 float4
+  constexpr int XC4 = CIN / 4, XRP = 256 / XC4, XPF = 64 / XRP;
+  constexpr int YC4 = COP / 4, YRP = 256 / YC4, YPF = 64 / YRP;
+  const int xc4 = tid % XC4, xr0 = tid / XC4, xabs = x.coff + 4 * xc4;
+  const int yc4 = tid % YC4, yr0 = tid / YC4, yabs = y.coff + 4 * yc4;
+  const Xf4 xxf = lhn_load_xf(x, xabs);
+  const bool ych_ok = 4 * yc4 < cout;  // cout is a multiple of 4 on the NHWC path
+  Xf4 yxf;
+  Gr4 ygr;
+  if (!dy_nchw && ych_ok) {
+    yxf = lhn_load_xf(y, yabs);
+    ygr = lhn_load_coef(gy, y.cstride, yabs);
+  }
+  f4 bsum = (f4){0.f, 0.f, 0.f, 0.f};
+
+  f16v accw[NDW];
+#pragma unroll
+  for (int t = 0; t < NDW; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accw[t][r] = 0.f;
+
+  auto in_pix = [&](int m) -> int64_t {
+    if (stride == 1) return m;
+    const int n = m / HoWo, r = m - n * HoWo;
+    const int ho = r / y.W, wo = r - ho * y.W;
+    return ((int64_t)n * x.H + ho * stride) * x.W + wo * stride;
+  };
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // ---- stage X
+#pragma unroll
+    for (int p = 0; p < XPF; ++p) {
+      const int row = xr0 + p * XRP, m = tile * 64 + row;
+      f4 v = (f4){0.f, 0.f, 0.f, 0.f};
+      if (m < M) {
+        const f4 raw = *reinterpret_cast<const f4*>(x.data + in_pix(m) * x.cstride + xabs);
+        v = lhn_apply_xf(raw, xxf);
+        if (x.gate) v *= *reinterpret_cast<const f4*>(x.gate + (int64_t)(m / HoWo) * x.cstride + xabs);
+      }
+      *reinterpret_cast<f4*>(Xs + row * LDX + 4 * xc4) = v;
+    }
+    // ---- stage dY
+    if (dy_nchw) {
+      for (int i = tid; i < 64 * COP; i += 256) {
+        const int row = i & 63, co = i >> 6, m = tile * 64 + row;
+        float v = 0.f;
+        if (m < M && co < cout) {
+          const int n = m / HoWo, p = m - n * HoWo;
+          v = dy_nchw[((int64_t)n * cout + co) * HoWo + p];
+        }
+        dYs[row * LDY + co] = v;
+      }
+    } else {
+#pragma unroll
+      for (int p = 0; p < YPF; ++p) {
+        const int row = yr0 + p * YRP, m = tile * 64 + row;
+        f4 v = (f4){0.f, 0.f, 0.f, 0.f};
+        if (m < M && ych_ok) {
+          const int n = m / HoWo, r = m - n * HoWo;
+          const int h = r / y.W, ww = r - h * y.W;
+          const f4 raw = *reinterpret_cast<const f4*>(y.data + (int64_t)m * y.cstride + yabs);
+          const f4 dz = *reinterpret_cast<const f4*>(gy.dz + (int64_t)m * y.cstride + yabs);
+          const f4 du = lhn_grad_du(y, gy, yxf, raw, dz, n, h, ww, yabs);
+          v = ygr.A * du + ygr.B * raw + ygr.Cc;
+          bsum += v;
+        }
+        *reinterpret_cast<f4*>(dYs + row * LDY + 4 * yc4) = v;
+      }
+    }
+    __syncthreads();
+
+    // ---- dW += dY^T X   (K = 64 pixels)
+#pragma unroll 4
+    for (int ks = 0; ks < 32; ++ks) {
+      const float* dyr = dYs + (2 * ks + lh) * LDY + l31;
+      const float* xr = Xs + (2 * ks + lh) * LDX + l31;
+#pragma unroll
+      for (int t = 0; t < NDW; ++t) {
+        const int tl = wave + 4 * t;
+        if (tl < NTO * NTI) {
+          const int it = tl / NTI, jt = tl % NTI;
+          accw[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(dyr[32 * it], xr[32 * jt], accw[t], 0, 0, 0);
+        }
+      }
+    }
+    // ---- dX = dY W   (K = Cout)
+    if (dx) {
+      const int mt = wave & 1;
+      f16v accx[NDX];
+#pragma unroll
+      for (int t = 0; t < NDX; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accx[t][r] = 0.f;
+      const float* arow = dYs + (mt * 32 + l31) * LDY + 4 * lh;
+#pragma unroll 2
+      for (int kc = 0; kc < COP / 8; ++kc) {
+        const f4 a = *reinterpret_cast<const f4*>(arow + kc * 8);
+        const float* wr = Ws + (kc * 8 + 4 * lh) * LDW + l31;
+#pragma unroll
+        for (int t = 0; t < NDX; ++t) {
+          const int jt = (wave >> 1) + 2 * t;
+          if (jt < NTI) {
+            accx[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, wr[0 * LDW + 32 * jt], accx[t], 0, 0, 0);
+            accx[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, wr[1 * LDW + 32 * jt], accx[t], 0, 0, 0);
+            accx[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, wr[2 * LDW + 32 * jt], accx[t], 0, 0, 0);
+            accx[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, wr[3 * LDW + 32 * jt], accx[t], 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < NDX; ++t) {
+        const int jt = (wave >> 1) + 2 * t;
+        if (jt < NTI) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = tile * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (m < M) {
+              float* o = dx + in_pix(m) * x.cstride + x.coff + 32 * jt + l31;
+              *o = dx_acc ? *o + accx[t][r] : accx[t][r];
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- flush dW (C/D layout: row = co within tile, col = lane&31 = ci within tile)
+#pragma unroll
+  for (int t = 0; t < NDW; ++t) {
+    const int tl = wave + 4 * t;
+    if (tl < NTO * NTI) {
+      const int it = tl / NTI, jt = tl % NTI;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = 32 * it + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (co < cout) atomicAdd(dw + (int64_t)co * CIN + 32 * jt + l31, accw[t][r]);
+      }
+    }
+  }
+  if (dbias) {
+    if (dy_nchw) {
+      // head: few channels; recompute per-channel sums is cheap -- done by a separate tiny pass on the host side
+    } else if (ych_ok) {
+      atomicAdd(dbias + 4 * yc4 + 0, bsum.x);
+      atomicAdd(dbias + 4 * yc4 + 1, bsum.y);
+      atomicAdd(dbias + 4 * yc4 + 2, bsum.z);
+      atomicAdd(dbias + 4 * yc4 + 3, bsum.w);
+    }
+  }
+}
+
+// bias gradient of the NCHW head: db[co] = sum_{n,p} dy[n,co,p]
+__global__ void __launch_bounds__(256) k_bias_grad_nchw(const float* __restrict__ dy, float* __restrict__ db, int N, int C,
+                                                        int HW) {
+  const int co = blockIdx.x;
+  double s = 0;
+  for (int n = blockIdx.y; n < N; n += gridDim.y) {
+    const float* p = dy + ((int64_t)n * C + co) * HW;
+    float a = 0.f;
+    for (int i = threadIdx.x; i < HW; i += blockDim.x) a += p[i];
+    s += a;
+  }
+  s = lhn_wave_sum_d(s);
+  __shared__ double red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(db + co, (float)(red[0] + red[1] + red[2] + red[3]));
+}
+
+template <int CIN, int NTO>
+static int launch_pw_bwd(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx, int dx_acc,
+                         float* dw, float* dbias, int stride, const float* dy_nchw, int cout, hipStream_t s) {
+  const int M = y->N * y->H * y->W;
+  const int ntiles = (M + 63) / 64;
+  constexpr int COP = 32 * NTO;
+  const size_t lds = (size_t)(COP * (CIN + 4) + 64 * (COP + 4) + 64 * (CIN + 4)) * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pw_bwd<CIN, NTO>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess) {
+      lhn_set_error("lhn_conv_pw_bwd: cannot reserve %zu B of LDS", lds);
+      return 2;
+    }
+    attr_done = true;
+  }
+  int per_cu = (int)((160 * 1024) / lds);
+  if (per_cu > 2) per_cu = 2;
+  if (per_cu < 1) per_cu = 1;
+  int grid = lhn_num_cus() * per_cu;
+  if (grid > ntiles) grid = ntiles;
+  lhn_gradview g = *gy;
+  hipLaunchKernelGGL((k_pw_bwd<CIN, NTO>), dim3(grid), dim3(256), lds, s, *x, w, *y, g, dx, dx_acc, dw, dbias, stride, dy_nchw,
+                     cout, M, ntiles);
+  if (dbias && dy_nchw)
+    hipLaunchKernelGGL(k_bias_grad_nchw, dim3(cout, y->N < 16 ? y->N : 16), dim3(256), 0, s, dy_nchw, dbias, y->N, cout,
+                       y->H * y->W);
+  return 0;
+}
+
+extern "C" int lhn_conv_pw_bwd(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx,
+                               int dx_accumulate, float* dw, float* dbias, int stride, const float* dy_nchw, void* stream) {
+  LHN_CHECK_ARG(lhn_view_ok(x) && w && y && gy && dw, "lhn_conv_pw_bwd: bad view / null pointer");
+  LHN_CHECK_ARG(stride == 1 || stride == 2, "lhn_conv_pw_bwd: stride %d", stride);
+  LHN_CHECK_ARG(stride == 1 || !dx || dx_accumulate, "lhn_conv_pw_bwd: stride-2 dgrad only accumulates into a zeroed gradient");
+  if (!dy_nchw) LHN_CHECK_ARG(lhn_view_ok(y) && gy->dz, "lhn_conv_pw_bwd: bad output view / missing dz");
+  const int cout = y->C, nto = (cout + 31) / 32;
+  hipStream_t s = (hipStream_t)stream;
+  int rc = -1;
+#define PWB_CASE(CI, NTV) \
+  if (x->C == CI && nto == NTV) rc = launch_pw_bwd<CI, NTV>(x, w, y, gy, dx, dx_accumulate, dw, dbias, stride, dy_nchw, cout, s);
+  PWB_CASE(32, 1) PWB_CASE(32, 2) PWB_CASE(32, 4) PWB_CASE(64, 1) PWB_CASE(64, 2) PWB_CASE(64, 4) PWB_CASE(128, 1)
+  PWB_CASE(128, 2) PWB_CASE(128, 4)
+#undef PWB_CASE
+  LHN_CHECK_ARG(rc != -1, "lhn_conv_pw_bwd: unsupported channels Cin=%d Cout=%d", x->C, cout);
+  if (rc) return rc;
+  LHN_CHECK_LAUNCH("lhn_conv_pw_bwd");
+  return 0;
+}

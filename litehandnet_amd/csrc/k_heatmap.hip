@@ -1,0 +1,418 @@
+// Gaussian heatmap encode / decode / balanced-MSE loss kernels (HBM-bound, NCHW [N,K,H,W] fp32).
+// Reference arithmetic replaced: see include/lhn.h.
+#include "lhn_common.h"
+
+// ------------------------------------------------------------------ encode
+// generateTarget.py:100-123 (unbiased) computes exp() in float64 (numpy>=2 promotion of a float32
+// array with a float64 numpy scalar) and rounds to float32 on assignment; :125-154 (biased) works
+// in float32 on an integer-centred (6*sigma+1)^2 patch.
+__global__ void __launch_bounds__(256) k_encode(const float* __restrict__ joints, const float* __restrict__ visible,
+                                                float* __restrict__ target, float* __restrict__ weight, int NK, int H, int W,
+                                                double stride_x, double stride_y, float sigma, int unbiased) {
+  const int nk = blockIdx.x;
+  if (nk >= NK) return;
+  const float jx = joints[nk * 3 + 0], jy = joints[nk * 3 + 1];
+  float wgt = visible[nk * 3 + 0];
+  const double r = (double)sigma * 3.0;
+  float* out = target + (int64_t)nk * H * W;
+  const int HW = H * W;
+  if (unbiased) {
+    const double mx = (double)jx / stride_x, my = (double)jy / stride_y;
+    if (mx - r >= W || my - r >= H || mx + r + 1 < 0 || my + r + 1 < 0) wgt = 0.f;
+    const bool on = wgt > 0.5f;
+    const double den = 2.0 * (double)sigma * (double)sigma;
+    for (int i = threadIdx.x * 4; i < HW; i += blockDim.x * 4) {
+      f4 v = (f4){0.f, 0.f, 0.f, 0.f};
+      if (on) {
+        float t[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int p = i + j;
+          const double dx = (double)(float)(p % W) - mx, dy = (double)(float)(p / W) - my;
+          t[j] = (float)exp(-(dx * dx + dy * dy) / den);
+        }
+        v = (f4){t[0], t[1], t[2], t[3]};
+      }
+      *reinterpret_cast<f4*>(out + i) = v;
+    }
+  } else {
+    const int mx = (int)((double)jx / stride_x + 0.5), my = (int)((double)jy / stride_y + 0.5);
+    const int ri = (int)r;
+    const int ulx = (int)((double)mx - r), uly = (int)((double)my - r);
+    const int brx = (int)((double)mx + r + 1), bry = (int)((double)my + r + 1);
+    if (ulx >= W || uly >= H || brx < 0 || bry < 0) wgt = 0.f;
+    const bool on = wgt > 0.5f;
+    const float den = 2.f * sigma * sigma;
+    const int size = 2 * ri + 1, c0 = size / 2;
+    for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+      const int x = i % W, y = i / W;
+      float v = 0.f;
+      if (on && x >= ulx && x < brx && y >= uly && y < bry) {
+        const float gx = (float)(x - ulx) - (float)c0, gy = (float)(y - uly) - (float)c0;
+        const float a = __fadd_rn(__fmul_rn(gx, gx), __fmul_rn(gy, gy));
+        v = expf(-a / den);
+      }
+      out[i] = v;
+    }
+  }
+  if (threadIdx.x == 0) weight[nk] = wgt;
+}
+
+// ------------------------------------------------------------------ argmax (first max wins, NaN is max)
+struct MaxI {
+  float v;
+  int i;
+};
+__device__ __forceinline__ bool better(float av, int ai, float bv, int bi) {
+  const bool an = av != av, bn = bv != bv;
+  if (an || bn) return an && (!bn || ai < bi);
+  return av > bv || (av == bv && ai < bi);
+}
+__device__ __forceinline__ MaxI block_argmax(const float* __restrict__ m, int HW) {
+  float bv = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int i = threadIdx.x * 4; i < HW; i += blockDim.x * 4) {
+    const f4 q = *reinterpret_cast<const f4*>(m + i);
+    const float e[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (better(e[j], i + j, bv, bi)) {
+        bv = e[j];
+        bi = i + j;
+      }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(bv, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (better(ov, oi, bv, bi)) {
+      bv = ov;
+      bi = oi;
+    }
+  }
+  __shared__ float sv[4];
+  __shared__ int si[4];
+  const int wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    sv[wv] = bv;
+    si[wv] = bi;
+  }
+  __syncthreads();
+  MaxI r{sv[0], si[0]};
+  for (int k = 1; k < (int)(blockDim.x >> 6); ++k)
+    if (better(sv[k], si[k], r.v, r.i)) {
+      r.v = sv[k];
+      r.i = si[k];
+    }
+  return r;
+}
+
+__device__ __forceinline__ float sgn(float d) { return d > 0.f ? 1.f : (d < 0.f ? -1.f : (d == d ? 0.f : d)); }
+
+// mode 0: top_down_eval.py:440-452 ; mode 1: heatmap_post_processing.py:6-33 (clamped, then +0.5)
+__device__ __forceinline__ void refine_xy(const float* __restrict__ m, int H, int W, int mode, float& x, float& y) {
+  const int px = (int)x, py = (int)y;
+  if (mode == 0) {
+    if (1 < px && px < W - 1 && 1 < py && py < H - 1) {
+      const float dx = m[py * W + px + 1] - m[py * W + px - 1];
+      const float dy = m[(py + 1) * W + px] - m[(py - 1) * W + px];
+      x = __fadd_rn(x, sgn(dx) * 0.25f);
+      y = __fadd_rn(y, sgn(dy) * 0.25f);
+    }
+  } else {
+    const int xr = min(px + 1, W - 1), xl = max(px - 1, 0), yd = min(py + 1, H - 1), yu = max(py - 1, 0);
+    x = __fadd_rn(x, m[py * W + xr] > m[py * W + xl] ? 0.25f : -0.25f);
+    y = __fadd_rn(y, m[yd * W + px] > m[yu * W + px] ? 0.25f : -0.25f);
+    x = __fadd_rn(x, 0.5f);
+    y = __fadd_rn(y, 0.5f);
+  }
+}
+// post_transforms.py:35-46, float32 left-to-right, no contraction
+__device__ __forceinline__ void xform_xy(float x, float y, const float* c, const float* s, int W, int H, int udp,
+                                         float& ox, float& oy) {
+  const float sw = __fmul_rn(s[0], 200.f), sh = __fmul_rn(s[1], 200.f);
+  const float sx = udp ? sw / ((float)W - 1.f) : sw / (float)W;
+  const float sy = udp ? sh / ((float)H - 1.f) : sh / (float)H;
+  ox = __fsub_rn(__fadd_rn(__fmul_rn(x, sx), c[0]), __fmul_rn(sw, 0.5f));
+  oy = __fsub_rn(__fadd_rn(__fmul_rn(y, sy), c[1]), __fmul_rn(sh, 0.5f));
+}
+
+__global__ void __launch_bounds__(256) k_decode(const float* __restrict__ hm, const float* __restrict__ center,
+                                                const float* __restrict__ scale, float* __restrict__ hm_preds,
+                                                float* __restrict__ preds, float* __restrict__ maxvals,
+                                                int32_t* __restrict__ index, int K, int H, int W, int post) {
+  const int nk = blockIdx.x;
+  const float* m = hm + (int64_t)nk * H * W;
+  const MaxI r = block_argmax(m, H * W);
+  if (threadIdx.x == 0) {
+    float x = (float)(r.i % W), y = (float)(r.i / W);
+    if (!(r.v > 0.f)) x = y = -1.f;
+    if (post == 1) refine_xy(m, H, W, 0, x, y);
+    if (maxvals) maxvals[nk] = r.v;
+    if (index) index[nk] = r.i;
+    if (hm_preds) {
+      hm_preds[nk * 2 + 0] = x;
+      hm_preds[nk * 2 + 1] = y;
+    }
+    if (preds) {
+      const int n = nk / K;
+      float ox, oy;
+      xform_xy(x, y, center + n * 2, scale + n * 2, W, H, 0, ox, oy);
+      preds[nk * 2 + 0] = ox;
+      preds[nk * 2 + 1] = oy;
+    }
+  }
+}
+
+__global__ void k_refine(const float* __restrict__ hm, float* __restrict__ preds, int NK, int H, int W, int mode) {
+  const int nk = blockIdx.x * blockDim.x + threadIdx.x;
+  if (nk >= NK) return;
+  float x = preds[nk * 2], y = preds[nk * 2 + 1];
+  refine_xy(hm + (int64_t)nk * H * W, H, W, mode, x, y);
+  preds[nk * 2] = x;
+  preds[nk * 2 + 1] = y;
+}
+
+__global__ void k_transform(const float* __restrict__ coords, const float* __restrict__ center,
+                            const float* __restrict__ scale, float* __restrict__ out, int NK, int K, int W, int H, int udp) {
+  const int nk = blockIdx.x * blockDim.x + threadIdx.x;
+  if (nk >= NK) return;
+  const int n = nk / K;
+  float ox, oy;
+  xform_xy(coords[nk * 2], coords[nk * 2 + 1], center + n * 2, scale + n * 2, W, H, udp, ox, oy);
+  out[nk * 2] = ox;
+  out[nk * 2 + 1] = oy;
+}
+
+// ------------------------------------------------------------------ k x k max-pool peak keep (separable)
+// HeatmapParser.py:41-50: h *= (maxpool_kxk(h) == h); -inf padding as in F.max_pool2d.
+__global__ void __launch_bounds__(256) k_nms(float* __restrict__ hm, float* __restrict__ scratch, int H, int W, int k) {
+  const int nk = blockIdx.x, p = k / 2, HW = H * W;
+  float* m = hm + (int64_t)nk * HW;
+  float* s = scratch + (int64_t)nk * HW;
+  for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+    const int x = i % W, y = i / W;
+    float mx = -INFINITY;
+    for (int d = -p; d <= p; ++d) {
+      const int xx = x + d;
+      if (xx >= 0 && xx < W) mx = fmaxf(mx, m[y * W + xx]);
+    }
+    s[i] = mx;
+  }
+  __syncthreads();  // one block owns the whole map; pass 2 reads only `s` and its own m[i]
+  for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+    const int x = i % W, y = i / W;
+    float mx = -INFINITY;
+    for (int d = -p; d <= p; ++d) {
+      const int yy = y + d;
+      if (yy >= 0 && yy < H) mx = fmaxf(mx, s[yy * W + x]);
+    }
+    const float v = m[i];
+    m[i] = (mx == v) ? v : v * 0.f;
+  }
+}
+
+// ------------------------------------------------------------------ PCK (single block)
+__global__ void __launch_bounds__(256) k_pck(const float* __restrict__ pred, const float* __restrict__ gt,
+                                             const uint8_t* __restrict__ mask, const float* __restrict__ normalize,
+                                             float thr, float* __restrict__ acc, float* __restrict__ avg_cnt, int N, int K) {
+  __shared__ float s_acc[1024];
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    int valid = 0, hit = 0;
+    for (int n = 0; n < N; ++n) {
+      float n0 = normalize[n * 2], n1 = normalize[n * 2 + 1];
+      bool mk = mask[n * K + k] != 0;
+      if (n0 == 0.f || n1 == 0.f) mk = false;
+      if (!mk) continue;
+      if (n0 <= 0.f) n0 = 1e6f;
+      if (n1 <= 0.f) n1 = 1e6f;
+      const float dx = (pred[(n * K + k) * 2] - gt[(n * K + k) * 2]) / n0;
+      const float dy = (pred[(n * K + k) * 2 + 1] - gt[(n * K + k) * 2 + 1]) / n1;
+      const float d = sqrtf(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
+      ++valid;
+      hit += d < thr;
+    }
+    const float a = valid > 0 ? (float)((double)hit / (double)valid) : -1.f;
+    acc[k] = a;
+    s_acc[k] = a;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0;
+    int c = 0;
+    for (int k = 0; k < K; ++k)
+      if (s_acc[k] >= 0.f) {
+        s += (double)s_acc[k];
+        ++c;
+      }
+    avg_cnt[0] = c > 0 ? (float)(s / c) : 0.f;
+    avg_cnt[1] = (float)c;
+  }
+}
+
+// ------------------------------------------------------------------ balanced MSE
+// l = (o-t)^2 * w[n,k];  pos = t > 0.5;  loss = lw * (pf * S_pos + nf * S_neg) / numel
+// pf = numel/(n_pos+1)*0.1, nf = numel/(n_neg+1)   (heatmapLoss.py:252-259)
+__global__ void __launch_bounds__(256) k_loss_fwd(const float* __restrict__ o, const float* __restrict__ t,
+                                                  const float* __restrict__ w, double* __restrict__ acc, int64_t NK, int HW) {
+  double sp = 0, sn = 0;
+  unsigned long long np = 0;
+  const int64_t total4 = NK * HW / 4;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total4; q += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = q * 4;
+    const float wk = w[e / HW];
+    const f4 a = *reinterpret_cast<const f4*>(o + e), b = *reinterpret_cast<const f4*>(t + e);
+    const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float d = av[j] - bv[j];
+      const float l = __fmul_rn(__fmul_rn(d, d), wk);
+      if (bv[j] > 0.5f) {
+        sp += (double)l;
+        ++np;
+      } else {
+        sn += (double)l;
+      }
+    }
+  }
+  sp = lhn_wave_sum_d(sp);
+  sn = lhn_wave_sum_d(sn);
+  double npd = lhn_wave_sum_d((double)np);
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(acc + 0, sp);
+    atomicAdd(acc + 1, sn);
+    atomicAdd(acc + 2, npd);
+  }
+}
+__global__ void k_loss_final(const double* __restrict__ acc, float* __restrict__ loss, double numel, float lw, int balance) {
+  const double npos = acc[2], nneg = numel - npos;
+  // the reference multiplies float32 loss elements by float32 factors; factors rounded to f32 here too
+  const float pf = balance ? __fmul_rn((float)numel / (float)(npos + 1.0), 0.1f) : 1.f;
+  const float nf = balance ? (float)numel / (float)(nneg + 1.0) : 1.f;
+  loss[0] = lw * (float)(((double)pf * acc[0] + (double)nf * acc[1]) / numel);
+}
+__global__ void __launch_bounds__(256) k_loss_bwd(const float* __restrict__ o, const float* __restrict__ t,
+                                                  const float* __restrict__ w, const double* __restrict__ acc,
+                                                  const float* __restrict__ dloss, float* __restrict__ g, int64_t NK, int HW,
+                                                  float lw, int balance) {
+  const double numel = (double)NK * HW;
+  const double npos = acc[2], nneg = numel - npos;
+  const float pf = balance ? __fmul_rn((float)numel / (float)(npos + 1.0), 0.1f) : 1.f;
+  const float nf = balance ? (float)numel / (float)(nneg + 1.0) : 1.f;
+  const float up = (dloss ? dloss[0] : 1.f) * lw;
+  const float kp = (float)((double)up * 2.0 * (double)pf / numel), kn = (float)((double)up * 2.0 * (double)nf / numel);
+  const int64_t total4 = NK * HW / 4;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total4; q += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = q * 4;
+    const float wk = w[e / HW];
+    const f4 a = *reinterpret_cast<const f4*>(o + e), b = *reinterpret_cast<const f4*>(t + e);
+    f4 r;
+    r.x = (a.x - b.x) * wk * (b.x > 0.5f ? kp : kn);
+    r.y = (a.y - b.y) * wk * (b.y > 0.5f ? kp : kn);
+    r.z = (a.z - b.z) * wk * (b.z > 0.5f ? kp : kn);
+    r.w = (a.w - b.w) * wk * (b.w > 0.5f ? kp : kn);
+    *reinterpret_cast<f4*>(g + e) = r;
+  }
+}
+
+// ------------------------------------------------------------------ C ABI
+extern "C" {
+
+int lhn_heatmap_encode(const float* joints, const float* visible, float* target, float* weight, int N, int K, int H,
+                       int W, float img_w, float img_h, float sigma, int unbiased, void* stream) {
+  LHN_CHECK_ARG(joints && visible && target && weight, "lhn_heatmap_encode: null pointer");
+  LHN_CHECK_ARG(N > 0 && K > 0 && H > 0 && W > 0 && (H * W) % 4 == 0, "lhn_heatmap_encode: bad shape N=%d K=%d H=%d W=%d", N, K, H, W);
+  LHN_CHECK_ARG(sigma > 0.f, "lhn_heatmap_encode: sigma must be > 0");
+  hipLaunchKernelGGL(k_encode, dim3(N * K), dim3(256), 0, (hipStream_t)stream, joints, visible, target, weight, N * K,
+                     H, W, (double)img_w / (double)W, (double)img_h / (double)H, sigma, unbiased);
+  LHN_CHECK_LAUNCH("lhn_heatmap_encode");
+  return 0;
+}
+
+int lhn_heatmap_argmax(const float* hm, float* preds, float* maxvals, int32_t* index, int N, int K, int H, int W,
+                       void* stream) {
+  LHN_CHECK_ARG(hm && preds && maxvals, "lhn_heatmap_argmax: null pointer");
+  LHN_CHECK_ARG(N > 0 && K > 0 && H > 0 && W > 0 && (H * W) % 4 == 0, "lhn_heatmap_argmax: bad shape");
+  hipLaunchKernelGGL(k_decode, dim3(N * K), dim3(256), 0, (hipStream_t)stream, hm, (const float*)nullptr,
+                     (const float*)nullptr, preds, (float*)nullptr, maxvals, index, K, H, W, 0);
+  LHN_CHECK_LAUNCH("lhn_heatmap_argmax");
+  return 0;
+}
+
+int lhn_heatmap_refine(const float* hm, float* preds, int N, int K, int H, int W, int mode, void* stream) {
+  LHN_CHECK_ARG(hm && preds, "lhn_heatmap_refine: null pointer");
+  LHN_CHECK_ARG(mode == 0 || mode == 1, "lhn_heatmap_refine: mode %d", mode);
+  const int NK = N * K;
+  hipLaunchKernelGGL(k_refine, dim3((NK + 255) / 256), dim3(256), 0, (hipStream_t)stream, hm, preds, NK, H, W, mode);
+  LHN_CHECK_LAUNCH("lhn_heatmap_refine");
+  return 0;
+}
+
+int lhn_transform_preds(const float* coords, const float* center, const float* scale, float* out, int N, int K, int W,
+                        int H, int use_udp, void* stream) {
+  LHN_CHECK_ARG(coords && center && scale && out, "lhn_transform_preds: null pointer");
+  const int NK = N * K;
+  hipLaunchKernelGGL(k_transform, dim3((NK + 255) / 256), dim3(256), 0, (hipStream_t)stream, coords, center, scale, out,
+                     NK, K, W, H, use_udp);
+  LHN_CHECK_LAUNCH("lhn_transform_preds");
+  return 0;
+}
+
+int lhn_heatmap_decode(const float* hm, const float* center, const float* scale, float* hm_preds, float* preds,
+                       float* maxvals, int N, int K, int H, int W, int post_process, void* stream) {
+  LHN_CHECK_ARG(hm && center && scale && hm_preds && preds && maxvals, "lhn_heatmap_decode: null pointer");
+  LHN_CHECK_ARG(post_process == 0 || post_process == 1, "lhn_heatmap_decode: post_process %d (0 none, 1 default)", post_process);
+  LHN_CHECK_ARG((H * W) % 4 == 0, "lhn_heatmap_decode: H*W must be a multiple of 4");
+  hipLaunchKernelGGL(k_decode, dim3(N * K), dim3(256), 0, (hipStream_t)stream, hm, center, scale, hm_preds, preds,
+                     maxvals, (int32_t*)nullptr, K, H, W, post_process);
+  LHN_CHECK_LAUNCH("lhn_heatmap_decode");
+  return 0;
+}
+
+int lhn_heatmap_nms(float* hm, float* scratch, int N, int K, int H, int W, int kernel, void* stream) {
+  LHN_CHECK_ARG(hm && scratch, "lhn_heatmap_nms: null pointer");
+  LHN_CHECK_ARG(kernel % 2 == 1 && kernel > 0, "lhn_heatmap_nms: kernel must be odd");
+  hipLaunchKernelGGL(k_nms, dim3(N * K), dim3(256), 0, (hipStream_t)stream, hm, scratch, H, W, kernel);
+  LHN_CHECK_LAUNCH("lhn_heatmap_nms");
+  return 0;
+}
+
+int lhn_pck_accuracy(const float* pred, const float* gt, const uint8_t* mask, const float* normalize, float thr,
+                     float* acc, float* avg_cnt, int N, int K, void* stream) {
+  LHN_CHECK_ARG(pred && gt && mask && normalize && acc && avg_cnt, "lhn_pck_accuracy: null pointer");
+  LHN_CHECK_ARG(K <= 1024, "lhn_pck_accuracy: K <= 1024");
+  hipLaunchKernelGGL(k_pck, dim3(1), dim3(256), 0, (hipStream_t)stream, pred, gt, mask, normalize, thr, acc, avg_cnt, N, K);
+  LHN_CHECK_LAUNCH("lhn_pck_accuracy");
+  return 0;
+}
+
+int lhn_loss_balanced_mse_fwd(const float* out, const float* target, const float* weight, double* acc, float* loss,
+                              int64_t NK, int64_t HW, float loss_weight, int balance, void* stream) {
+  LHN_CHECK_ARG(out && target && weight && acc && loss, "lhn_loss_balanced_mse_fwd: null pointer");
+  LHN_CHECK_ARG(NK > 0 && HW > 0 && HW % 4 == 0, "lhn_loss_balanced_mse_fwd: bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(acc, 0, 4 * sizeof(double), s) != hipSuccess) {
+    lhn_set_error("lhn_loss_balanced_mse_fwd: memset failed");
+    return 2;
+  }
+  const int64_t total4 = NK * HW / 4;
+  const int grid = (int)((total4 + 255) / 256 < (int64_t)lhn_num_cus() * 8 ? (total4 + 255) / 256 : (int64_t)lhn_num_cus() * 8);
+  hipLaunchKernelGGL(k_loss_fwd, dim3(grid), dim3(256), 0, s, out, target, weight, acc, NK, (int)HW);
+  hipLaunchKernelGGL(k_loss_final, dim3(1), dim3(1), 0, s, acc, loss, (double)NK * (double)HW, loss_weight, balance);
+  LHN_CHECK_LAUNCH("lhn_loss_balanced_mse_fwd");
+  return 0;
+}
+
+int lhn_loss_balanced_mse_bwd(const float* out, const float* target, const float* weight, const double* acc,
+                              const float* dloss, float* dout, int64_t NK, int64_t HW, float loss_weight, int balance,
+                              void* stream) {
+  LHN_CHECK_ARG(out && target && weight && acc && dout, "lhn_loss_balanced_mse_bwd: null pointer");
+  LHN_CHECK_ARG(NK > 0 && HW > 0 && HW % 4 == 0, "lhn_loss_balanced_mse_bwd: bad shape");
+  const int64_t total4 = NK * HW / 4;
+  const int grid = (int)((total4 + 255) / 256 < (int64_t)lhn_num_cus() * 8 ? (total4 + 255) / 256 : (int64_t)lhn_num_cus() * 8);
+  hipLaunchKernelGGL(k_loss_bwd, dim3(grid), dim3(256), 0, (hipStream_t)stream, out, target, weight, acc, dloss, dout,
+                     NK, (int)HW, loss_weight, balance);
+  LHN_CHECK_LAUNCH("lhn_loss_balanced_mse_bwd");
+  return 0;
+}
+}  // extern "C"

@@ -1,0 +1,656 @@
+// BatchNorm finalize, elementwise combine (+nearest upsample), 2x2 max-pool, adaptive average pool,
+// channel-attention MLP -- forward and backward.  All HBM/latency-bound, NHWC fp32, float4 per thread.
+#include "lhn_common.h"
+
+static inline int grid_cap(int64_t blocks, int cap_per_cu) {
+  const int64_t cap = (int64_t)lhn_num_cus() * cap_per_cu;
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  return (int)blocks;
+}
+static inline bool pow2i(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+// ------------------------------------------------------------------ BatchNorm finalize
+// torch.nn.BatchNorm2d: normalise with the biased batch variance, update running_var with the
+// unbiased one, eps inside the sqrt, momentum = exponential average factor.
+__global__ void k_bn_finalize(const double* __restrict__ stats, const float* __restrict__ gamma,
+                              const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
+                              int64_t* __restrict__ nbt, float* __restrict__ table, int cs, int coff, int C,
+                              float* __restrict__ save, double count, float eps, float momentum, float slope, int training) {
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    double mean, var;
+    if (training) {
+      mean = stats[c] / count;
+      var = stats[C + c] / count - mean * mean;
+      if (var < 0) var = 0;
+      if (rmean) {
+        rmean[c] = (float)((1.0 - (double)momentum) * (double)rmean[c] + (double)momentum * mean);
+        const double unb = count > 1 ? var * count / (count - 1.0) : var;
+        rvar[c] = (float)((1.0 - (double)momentum) * (double)rvar[c] + (double)momentum * unb);
+      }
+    } else {
+      mean = rmean[c];
+      var = rvar[c];
+    }
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const float sc = g * invstd;
+    table[coff + c] = sc;
+    table[cs + coff + c] = b - (float)mean * sc;
+    table[2 * cs + coff + c] = slope;
+    if (save) {
+      save[c] = (float)mean;
+      save[C + c] = invstd;
+    }
+  }
+  if (training && nbt && threadIdx.x == 0) nbt[0] += 1;
+}
+
+__global__ void k_table_fill(float* __restrict__ table, int cs, int coff, int C, float sc, float sh, float sl) {
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    table[coff + c] = sc;
+    table[cs + coff + c] = sh;
+    table[2 * cs + coff + c] = sl;
+  }
+}
+
+// ------------------------------------------------------------------ elementwise combine
+// dst = lrelu_{out_slope}( sum_i value_i(nearest-resampled to dst geometry) ), dst stored plain.
+struct EwSrcs {
+  lhn_view v[3];
+};
+__device__ __forceinline__ int nearest_src(int d, int in, int out) {
+  if (in == out) return d;
+  const float sc = (float)in / (float)out;
+  const int s = (int)floorf((float)d * sc);
+  return s < in - 1 ? s : in - 1;
+}
+__global__ void __launch_bounds__(256) k_ew_fwd(EwSrcs S, int nsrc, lhn_view dst, float out_slope) {
+  const int C4 = dst.C >> 2;
+  const int64_t total = (int64_t)dst.N * dst.H * dst.W * C4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    const int64_t pix = i / C4;
+    const int w = (int)(pix % dst.W);
+    const int64_t t = pix / dst.W;
+    const int h = (int)(t % dst.H), n = (int)(t / dst.H);
+    f4 acc = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      if (k >= nsrc) break;
+      const lhn_view& v = S.v[k];
+      const int hs = nearest_src(h, v.H, dst.H), ws = nearest_src(w, v.W, dst.W);
+      const int ca = v.coff + 4 * c4;
+      const Xf4 xf = lhn_load_xf(v, ca);
+      acc += lhn_load_val(v, xf, ((int64_t)n * v.H + hs) * v.W + ws, n, ca);
+    }
+    acc.x = lhn_lrelu(acc.x, out_slope);
+    acc.y = lhn_lrelu(acc.y, out_slope);
+    acc.z = lhn_lrelu(acc.z, out_slope);
+    acc.w = lhn_lrelu(acc.w, out_slope);
+    *reinterpret_cast<f4*>(dst.data + pix * dst.cstride + dst.coff + 4 * c4) = acc;
+  }
+}
+
+// backward of the combine: d(value_i) (+)= d(dst) * lrelu'(dst); upsampled sources sum their fan-out.
+// One launch per source (gather form: each source element sums the dst elements that read it).
+__global__ void __launch_bounds__(256) k_ew_bwd_src(lhn_view src, lhn_view dst, const float* __restrict__ ddst,
+                                                    const float* __restrict__ dst_dpool, float out_slope,
+                                                    float* __restrict__ dsrc, int accumulate) {
+  const int C4 = src.C >> 2;
+  const int64_t total = (int64_t)src.N * src.H * src.W * C4;
+  const int fh = dst.H / src.H, fw = dst.W / src.W;  // integer fan-out (host checks divisibility)
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    const int64_t pix = i / C4;
+    const int w = (int)(pix % src.W);
+    const int64_t t = pix / src.W;
+    const int h = (int)(t % src.H), n = (int)(t / src.H);
+    f4 g = (f4){0.f, 0.f, 0.f, 0.f};
+    const int cd = dst.coff + 4 * c4;
+    for (int a = 0; a < fh; ++a)
+      for (int b = 0; b < fw; ++b) {
+        const int hd = h * fh + a, wd = w * fw + b;
+        const int64_t pd = ((int64_t)n * dst.H + hd) * dst.W + wd;
+        f4 e = *reinterpret_cast<const f4*>(ddst + pd * dst.cstride + cd);
+        if (dst.gate) e *= *reinterpret_cast<const f4*>(dst.gate + (int64_t)n * dst.cstride + cd);
+        if (dst_dpool) {
+          lhn_gradview gv{nullptr, dst_dpool, nullptr};
+          e += lhn_dpool_sum(gv, dst, n, hd, wd, cd);
+        }
+        if (out_slope != 1.f) {
+          const f4 o = *reinterpret_cast<const f4*>(dst.data + pd * dst.cstride + cd);
+          e.x *= o.x > 0.f ? 1.f : out_slope;
+          e.y *= o.y > 0.f ? 1.f : out_slope;
+          e.z *= o.z > 0.f ? 1.f : out_slope;
+          e.w *= o.w > 0.f ? 1.f : out_slope;
+        }
+        g += e;
+      }
+    float* o = dsrc + pix * src.cstride + src.coff + 4 * c4;
+    if (accumulate) g += *reinterpret_cast<const f4*>(o);
+    *reinterpret_cast<f4*>(o) = g;
+  }
+}
+
+// ------------------------------------------------------------------ 2x2 stride-2 max pool (ceil_mode)
+__global__ void __launch_bounds__(256) k_maxpool2_fwd(lhn_view x, lhn_view y) {
+  const int C4 = y.C >> 2;
+  const int64_t total = (int64_t)y.N * y.H * y.W * C4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    const int64_t pix = i / C4;
+    const int wo = (int)(pix % y.W);
+    const int64_t t = pix / y.W;
+    const int ho = (int)(t % y.H), n = (int)(t / y.H);
+    const int ca = x.coff + 4 * c4;
+    const Xf4 xf = lhn_load_xf(x, ca);
+    f4 m = (f4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int ih = 2 * ho + a, iw = 2 * wo + b;
+        if (ih < x.H && iw < x.W) {
+          const f4 v = lhn_load_val(x, xf, ((int64_t)n * x.H + ih) * x.W + iw, n, ca);
+          m.x = v.x > m.x || v.x != v.x ? v.x : m.x;
+          m.y = v.y > m.y || v.y != v.y ? v.y : m.y;
+          m.z = v.z > m.z || v.z != v.z ? v.z : m.z;
+          m.w = v.w > m.w || v.w != v.w ? v.w : m.w;
+        }
+      }
+    *reinterpret_cast<f4*>(y.data + pix * y.cstride + y.coff + 4 * c4) = m;
+  }
+}
+// gradient goes to the first window element (scan order) that equals the max
+__global__ void __launch_bounds__(256) k_maxpool2_bwd(lhn_view x, lhn_view y, const float* __restrict__ dy,
+                                                      float* __restrict__ dx, int accumulate) {
+  const int C4 = x.C >> 2;
+  const int64_t total = (int64_t)x.N * x.H * x.W * C4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    const int64_t pix = i / C4;
+    const int w = (int)(pix % x.W);
+    const int64_t t = pix / x.W;
+    const int h = (int)(t % x.H), n = (int)(t / x.H);
+    const int ho = h >> 1, wo = w >> 1;
+    const int ca = x.coff + 4 * c4;
+    const Xf4 xf = lhn_load_xf(x, ca);
+    const int64_t po = ((int64_t)n * y.H + ho) * y.W + wo;
+    const f4 mx = *reinterpret_cast<const f4*>(y.data + po * y.cstride + y.coff + 4 * c4);
+    const f4 g = *reinterpret_cast<const f4*>(dy + po * y.cstride + y.coff + 4 * c4);
+    const f4 mine = lhn_load_val(x, xf, pix, n, ca);
+    // am I the first element of the window equal to the max?
+    bool first[4] = {mine.x == mx.x, mine.y == mx.y, mine.z == mx.z, mine.w == mx.w};
+    const int myord = (h & 1) * 2 + (w & 1);
+    for (int o = 0; o < myord; ++o) {
+      const int ih = 2 * ho + (o >> 1), iw = 2 * wo + (o & 1);
+      if (ih < x.H && iw < x.W) {
+        const f4 v = lhn_load_val(x, xf, ((int64_t)n * x.H + ih) * x.W + iw, n, ca);
+        first[0] = first[0] && !(v.x == mx.x);
+        first[1] = first[1] && !(v.y == mx.y);
+        first[2] = first[2] && !(v.z == mx.z);
+        first[3] = first[3] && !(v.w == mx.w);
+      }
+    }
+    f4 r = (f4){first[0] ? g.x : 0.f, first[1] ? g.y : 0.f, first[2] ? g.z : 0.f, first[3] ? g.w : 0.f};
+    float* o = dx + pix * x.cstride + ca;
+    if (accumulate) r += *reinterpret_cast<const f4*>(o);
+    *reinterpret_cast<f4*>(o) = r;
+  }
+}
+
+// ------------------------------------------------------------------ adaptive average pool -> dense [N,OH,OW,C]
+__global__ void __launch_bounds__(256) k_avgpool_fwd(lhn_view x, float* __restrict__ out, int OH, int OW) {
+  __shared__ f4 red[256];
+  const int C4 = x.C >> 2, PL = 256 / C4;
+  const int b = blockIdx.x;
+  const int ow = b % OW, oh = (b / OW) % OH, n = b / (OW * OH);
+  const int h0 = (oh * x.H) / OH, h1 = ((oh + 1) * x.H + OH - 1) / OH;
+  const int w0 = (ow * x.W) / OW, w1 = ((ow + 1) * x.W + OW - 1) / OW;
+  const int bw = w1 - w0, cnt = (h1 - h0) * bw;
+  const int c4 = threadIdx.x % C4, pl = threadIdx.x / C4;
+  const int ca = x.coff + 4 * c4;
+  const Xf4 xf = lhn_load_xf(x, ca);
+  f4 s = (f4){0.f, 0.f, 0.f, 0.f};
+  for (int p = pl; p < cnt; p += PL) {
+    const int h = h0 + p / bw, w = w0 + p % bw;
+    s += lhn_load_val(x, xf, ((int64_t)n * x.H + h) * x.W + w, n, ca);
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x < C4) {
+    f4 t = (f4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < PL; ++j) t += red[j * C4 + threadIdx.x];
+    const float inv = 1.f / (float)cnt;
+    *reinterpret_cast<f4*>(out + (int64_t)b * x.C + 4 * threadIdx.x) = t * inv;
+  }
+}
+// d(value of x) (+)= sum over bins containing the pixel of dout[bin]/|bin|   (plain x only: no pending act)
+__global__ void __launch_bounds__(256) k_avgpool_bwd(lhn_view x, const float* __restrict__ dout, int OH, int OW,
+                                                     float* __restrict__ dx, int accumulate) {
+  const int C4 = x.C >> 2;
+  const int64_t total = (int64_t)x.N * x.H * x.W * C4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    const int64_t pix = i / C4;
+    const int w = (int)(pix % x.W);
+    const int64_t t = pix / x.W;
+    const int h = (int)(t % x.H), n = (int)(t / x.H);
+    f4 g = (f4){0.f, 0.f, 0.f, 0.f};
+    for (int oh = 0; oh < OH; ++oh) {
+      const int h0 = (oh * x.H) / OH, h1 = ((oh + 1) * x.H + OH - 1) / OH;
+      if (h < h0 || h >= h1) continue;
+      for (int ow = 0; ow < OW; ++ow) {
+        const int w0 = (ow * x.W) / OW, w1 = ((ow + 1) * x.W + OW - 1) / OW;
+        if (w < w0 || w >= w1) continue;
+        const float inv = 1.f / (float)((h1 - h0) * (w1 - w0));
+        g += *reinterpret_cast<const f4*>(dout + (((int64_t)n * OH + oh) * OW + ow) * x.C + 4 * c4) * inv;
+      }
+    }
+    float* o = dx + pix * x.cstride + x.coff + 4 * c4;
+    if (accumulate) g += *reinterpret_cast<const f4*>(o);
+    *reinterpret_cast<f4*>(o) = g;
+  }
+}
+
+// ------------------------------------------------------------------ channel attention MLP (common.py:40-66)
+// save layout (floats): a[N*C] | ahat[N*C] | h[N*C/2] | g[N*C] | mean[C] | invstd[C]
+__global__ void __launch_bounds__(256) k_ca1(const float* __restrict__ pooled, const float* __restrict__ w3,
+                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                             float* __restrict__ rmean, float* __restrict__ rvar, int64_t* __restrict__ nbt,
+                                             const float* __restrict__ mask, float* __restrict__ save, int N, int C,
+                                             float eps, float momentum, int training) {
+  float* a = save;
+  float* ahat = save + (int64_t)N * C;
+  float* smean = save + (int64_t)N * C * 3 + (int64_t)N * (C / 2);
+  float* sinv = smean + C;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float wt[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wt[t] = w3[c * 9 + t];
+    double s = 0, q = 0;
+    for (int n = 0; n < N; ++n) {
+      float v = 0.f;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) v += pooled[((int64_t)n * 9 + t) * C + c] * wt[t];
+      a[(int64_t)n * C + c] = v;
+      s += v;
+      q += (double)v * v;
+    }
+    double mean, var;
+    if (training) {
+      mean = s / N;
+      var = q / N - mean * mean;
+      if (var < 0) var = 0;
+      rmean[c] = (float)((1.0 - (double)momentum) * rmean[c] + (double)momentum * mean);
+      rvar[c] = (float)((1.0 - (double)momentum) * rvar[c] + (double)momentum * (N > 1 ? var * N / (N - 1.0) : var));
+    } else {
+      mean = rmean[c];
+      var = rvar[c];
+    }
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    smean[c] = (float)mean;
+    sinv[c] = invstd;
+    const float sc = gamma[c] * invstd, sh = beta[c] - (float)mean * sc;
+    for (int n = 0; n < N; ++n) {
+      float v = a[(int64_t)n * C + c] * sc + sh;
+      if (mask) v *= mask[(int64_t)n * C + c];
+      ahat[(int64_t)n * C + c] = v;
+    }
+  }
+  if (training && nbt && threadIdx.x == 0) nbt[0] += 1;
+}
+__global__ void __launch_bounds__(256) k_ca2(const float* __restrict__ w1, const float* __restrict__ b1,
+                                             const float* __restrict__ w2, const float* __restrict__ b2,
+                                             float* __restrict__ save, float* __restrict__ gate, int gs, int gcoff, int N,
+                                             int C) {
+  __shared__ float sa[256], shh[128];
+  const int n = blockIdx.x, Ch = C / 2;
+  const float* ahat = save + (int64_t)N * C + (int64_t)n * C;
+  float* h = save + (int64_t)N * C * 2 + (int64_t)n * Ch;
+  float* g = save + (int64_t)N * C * 2 + (int64_t)N * Ch + (int64_t)n * C;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) sa[c] = ahat[c];
+  __syncthreads();
+  for (int j = threadIdx.x; j < Ch; j += blockDim.x) {
+    float v = b1[j];
+    for (int c = 0; c < C; ++c) v += w1[j * C + c] * sa[c];
+    v = lhn_lrelu(v, 0.01f);
+    h[j] = v;
+    shh[j] = v;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float v = b2[c];
+    for (int j = 0; j < Ch; ++j) v += w2[c * Ch + j] * shh[j];
+    const float sg = 1.f / (1.f + expf(-v));
+    g[c] = sg;
+    gate[(int64_t)n * gs + gcoff + c] = sg;
+  }
+}
+
+// d(gate)[n][c] = sum_pixels dz * value_pre_gate   (one block per image)
+__global__ void __launch_bounds__(256) k_gate_bwd_reduce(lhn_view y, const float* __restrict__ dz,
+                                                         float* __restrict__ dgate) {
+  __shared__ f4 red[256];
+  const int C4 = y.C >> 2, PL = 256 / C4, n = blockIdx.x;
+  const int c4 = threadIdx.x % C4, pl = threadIdx.x / C4;
+  const int ca = y.coff + 4 * c4;
+  const Xf4 xf = lhn_load_xf(y, ca);
+  const int HW = y.H * y.W;
+  const int chunk = (HW + gridDim.y - 1) / gridDim.y;
+  const int p0 = blockIdx.y * chunk, p1 = min(HW, p0 + chunk);
+  f4 s = (f4){0.f, 0.f, 0.f, 0.f};
+  for (int p = p0 + pl; p < p1; p += PL) {
+    const int64_t pix = (int64_t)n * HW + p;
+    const f4 raw = *reinterpret_cast<const f4*>(y.data + pix * y.cstride + ca);
+    const f4 v = lhn_apply_xf(raw, xf);
+    s += v * *reinterpret_cast<const f4*>(dz + pix * y.cstride + ca);
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x < C4) {
+    f4 t = (f4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < PL; ++j) t += red[j * C4 + threadIdx.x];
+    float* o = dgate + (int64_t)n * y.C + 4 * threadIdx.x;
+    atomicAdd(o + 0, t.x);
+    atomicAdd(o + 1, t.y);
+    atomicAdd(o + 2, t.z);
+    atomicAdd(o + 3, t.w);
+  }
+}
+
+// backward of the MLP; writes dpool[n][bin][cs] (already divided by the bin size) and parameter grads
+__global__ void __launch_bounds__(256) k_ca_bwd2(const float* __restrict__ w1, const float* __restrict__ w2,
+                                                 const float* __restrict__ save, const float* __restrict__ dgate,
+                                                 float* __restrict__ dahat /*[N][C]*/, float* __restrict__ dw1,
+                                                 float* __restrict__ db1, float* __restrict__ dw2, float* __restrict__ db2,
+                                                 int N, int C) {
+  __shared__ float sdv[256], sdh[128], sa[256], shh[128];
+  const int n = blockIdx.x, Ch = C / 2;
+  const float* ahat = save + (int64_t)N * C + (int64_t)n * C;
+  const float* h = save + (int64_t)N * C * 2 + (int64_t)n * Ch;
+  const float* g = save + (int64_t)N * C * 2 + (int64_t)N * Ch + (int64_t)n * C;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const float gg = g[c];
+    const float dv = dgate[(int64_t)n * C + c] * gg * (1.f - gg);
+    sdv[c] = dv;
+    sa[c] = ahat[c];
+    atomicAdd(db2 + c, dv);
+  }
+  for (int j = threadIdx.x; j < Ch; j += blockDim.x) shh[j] = h[j];
+  __syncthreads();
+  for (int i = threadIdx.x; i < C * Ch; i += blockDim.x) atomicAdd(dw2 + i, sdv[i / Ch] * shh[i % Ch]);
+  for (int j = threadIdx.x; j < Ch; j += blockDim.x) {
+    float d = 0.f;
+    for (int c = 0; c < C; ++c) d += w2[c * Ch + j] * sdv[c];
+    d *= shh[j] > 0.f ? 1.f : 0.01f;
+    sdh[j] = d;
+    atomicAdd(db1 + j, d);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < Ch * C; i += blockDim.x) atomicAdd(dw1 + i, sdh[i / C] * sa[i % C]);
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float d = 0.f;
+    for (int j = 0; j < Ch; ++j) d += w1[j * C + c] * sdh[j];
+    dahat[(int64_t)n * C + c] = d;
+  }
+}
+__global__ void __launch_bounds__(256) k_ca_bwd1(const float* __restrict__ pooled, const float* __restrict__ w3,
+                                                 const float* __restrict__ gamma, const float* __restrict__ mask,
+                                                 const float* __restrict__ save, const float* __restrict__ dahat,
+                                                 float* __restrict__ dpool, int cs, int coff, int H, int W,
+                                                 float* __restrict__ dw3, float* __restrict__ dgamma,
+                                                 float* __restrict__ dbeta, int N, int C, int training) {
+  const float* a = save;
+  const float* smean = save + (int64_t)N * C * 3 + (int64_t)N * (C / 2);
+  const float* sinv = smean + C;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const float mean = smean[c], invstd = sinv[c], gm = gamma[c];
+    double sd = 0, sdx = 0;
+    for (int n = 0; n < N; ++n) {
+      float d = dahat[(int64_t)n * C + c];
+      if (mask) d *= mask[(int64_t)n * C + c];
+      const float xh = (a[(int64_t)n * C + c] - mean) * invstd;
+      sd += d;
+      sdx += (double)d * xh;
+    }
+    dgamma[c] += (float)sdx;
+    dbeta[c] += (float)sd;
+    float wt[9], dwt[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      wt[t] = w3[c * 9 + t];
+      dwt[t] = 0.f;
+    }
+    for (int n = 0; n < N; ++n) {
+      float d = dahat[(int64_t)n * C + c];
+      if (mask) d *= mask[(int64_t)n * C + c];
+      const float xh = (a[(int64_t)n * C + c] - mean) * invstd;
+      float da = gm * invstd * d;
+      if (training) da = gm * invstd * (d - (float)(sd / N) - xh * (float)(sdx / N));
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        dwt[t] += da * pooled[((int64_t)n * 9 + t) * C + c];
+        const int bi = t / 3, bj = t % 3;
+        const int cnt = (lhn_bin_hi(bi, H) - lhn_bin_lo(bi, H)) * (lhn_bin_hi(bj, W) - lhn_bin_lo(bj, W));
+        dpool[((int64_t)n * 9 + t) * cs + coff + c] = da * wt[t] / (float)cnt;
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) dw3[c * 9 + t] += dwt[t];
+  }
+}
+
+// ------------------------------------------------------------------ BatchNorm backward reductions
+// sums[0][c] = sum du, sums[1][c] = sum du * xhat   over all pixels (du: gradient at the BN output)
+__global__ void __launch_bounds__(256) k_bn_bwd_reduce(lhn_view y, lhn_gradview g, const float* __restrict__ save,
+                                                       double* __restrict__ sums) {
+  __shared__ f4 red[512];
+  const int C4 = y.C >> 2, PL = 256 / C4;
+  const int c4 = threadIdx.x % C4, pl = threadIdx.x / C4;
+  const int ca = y.coff + 4 * c4;
+  const Xf4 xf = lhn_load_xf(y, ca);
+  const f4 mean = *reinterpret_cast<const f4*>(save + 4 * c4);
+  const f4 inv = *reinterpret_cast<const f4*>(save + y.C + 4 * c4);
+  const int64_t total = (int64_t)y.N * y.H * y.W;
+  f4 s = (f4){0.f, 0.f, 0.f, 0.f}, q = s;
+  for (int64_t pix = (int64_t)blockIdx.x * PL + pl; pix < total; pix += (int64_t)gridDim.x * PL) {
+    const int w = (int)(pix % y.W);
+    const int64_t t = pix / y.W;
+    const int h = (int)(t % y.H), n = (int)(t / y.H);
+    const f4 raw = *reinterpret_cast<const f4*>(y.data + pix * y.cstride + ca);
+    const f4 dz = *reinterpret_cast<const f4*>(g.dz + pix * y.cstride + ca);
+    const f4 du = lhn_grad_du(y, g, xf, raw, dz, n, h, w, ca);
+    s += du;
+    q += du * ((raw - mean) * inv);
+  }
+  red[threadIdx.x * 2] = s;
+  red[threadIdx.x * 2 + 1] = q;
+  __syncthreads();
+  if (threadIdx.x < C4) {
+    double sd[4] = {0, 0, 0, 0}, qd[4] = {0, 0, 0, 0};
+    for (int j = 0; j < PL; ++j) {
+      const f4 a = red[(j * C4 + threadIdx.x) * 2], b = red[(j * C4 + threadIdx.x) * 2 + 1];
+      sd[0] += a.x; sd[1] += a.y; sd[2] += a.z; sd[3] += a.w;
+      qd[0] += b.x; qd[1] += b.y; qd[2] += b.z; qd[3] += b.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      atomicAdd(sums + 4 * threadIdx.x + j, sd[j]);
+      atomicAdd(sums + y.C + 4 * threadIdx.x + j, qd[j]);
+    }
+  }
+}
+// dy = A*du + B*y + C with  A = s, B = -s*invstd*dgamma/n, C = -s*dbeta/n + s*invstd*mean*dgamma/n, s = gamma*invstd
+__global__ void k_bn_bwd_finalize(const double* __restrict__ sums, const float* __restrict__ gamma,
+                                  const float* __restrict__ save, float* __restrict__ coef, int cs, int coff, int C,
+                                  double count, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const double db = sums[c], dg = sums[C + c];
+    const double mean = save[c], inv = save[C + c], s = (double)(gamma ? gamma[c] : 1.f) * inv;
+    coef[coff + c] = (float)s;
+    coef[cs + coff + c] = (float)(-s * inv * dg / count);
+    coef[2 * cs + coff + c] = (float)(-s * db / count + s * inv * mean * dg / count);
+    if (dgamma) dgamma[c] += (float)dg;
+    if (dbeta) dbeta[c] += (float)db;
+  }
+}
+
+// ------------------------------------------------------------------ C ABI
+extern "C" {
+
+int lhn_bn_finalize(const double* stats, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                    int64_t* nbt, float* table, int cstride, int coff, int C, float* save, double count, float eps,
+                    float momentum, float slope, int training, void* stream) {
+  LHN_CHECK_ARG(table && C > 0 && coff >= 0 && coff + C <= cstride, "lhn_bn_finalize: bad table slice");
+  LHN_CHECK_ARG(training ? (stats != nullptr) : (running_mean && running_var), "lhn_bn_finalize: missing statistics");
+  LHN_CHECK_ARG(!training || count >= 1, "lhn_bn_finalize: count");
+  hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(C <= 64 ? 64 : (C <= 128 ? 128 : 256)), 0, (hipStream_t)stream, stats,
+                     gamma, beta, running_mean, running_var, nbt, table, cstride, coff, C, save, count, eps, momentum,
+                     slope, training);
+  LHN_CHECK_LAUNCH("lhn_bn_finalize");
+  return 0;
+}
+
+int lhn_table_fill(float* table, int cstride, int coff, int C, float scale, float shift, float slope, void* stream) {
+  LHN_CHECK_ARG(table && C > 0 && coff >= 0 && coff + C <= cstride, "lhn_table_fill: bad table slice");
+  hipLaunchKernelGGL(k_table_fill, dim3(1), dim3(128), 0, (hipStream_t)stream, table, cstride, coff, C, scale, shift, slope);
+  LHN_CHECK_LAUNCH("lhn_table_fill");
+  return 0;
+}
+
+int lhn_ew_fwd(const lhn_view* srcs, int nsrc, const lhn_view* dst, float out_slope, void* stream) {
+  LHN_CHECK_ARG(srcs && nsrc >= 1 && nsrc <= 3 && lhn_view_ok(dst), "lhn_ew_fwd: 1..3 sources, valid dst");
+  EwSrcs S;
+  memset(&S, 0, sizeof(S));
+  for (int i = 0; i < nsrc; ++i) {
+    LHN_CHECK_ARG(lhn_view_ok(&srcs[i]) && srcs[i].C == dst->C && srcs[i].N == dst->N, "lhn_ew_fwd: source %d mismatch", i);
+    S.v[i] = srcs[i];
+  }
+  const int64_t total = (int64_t)dst->N * dst->H * dst->W * (dst->C / 4);
+  hipLaunchKernelGGL(k_ew_fwd, dim3(grid_cap((total + 255) / 256, 8)), dim3(256), 0, (hipStream_t)stream, S, nsrc, *dst, out_slope);
+  LHN_CHECK_LAUNCH("lhn_ew_fwd");
+  return 0;
+}
+
+// dsrcs[i] == NULL skips source i.  dst_dpool (optional, via the last element of `accumulate`? no) -- see lhn_ew_bwd2.
+int lhn_ew_bwd(const lhn_view* srcs, int nsrc, const lhn_view* dst, const float* ddst, float out_slope,
+               float* const* dsrcs, const int* accumulate, void* stream) {
+  LHN_CHECK_ARG(srcs && nsrc >= 1 && nsrc <= 3 && lhn_view_ok(dst) && ddst && dsrcs && accumulate, "lhn_ew_bwd: bad args");
+  for (int i = 0; i < nsrc; ++i) {
+    if (!dsrcs[i]) continue;
+    const lhn_view* s = &srcs[i];
+    LHN_CHECK_ARG(lhn_view_ok(s) && s->C == dst->C, "lhn_ew_bwd: source %d mismatch", i);
+    LHN_CHECK_ARG(dst->H % s->H == 0 && dst->W % s->W == 0, "lhn_ew_bwd: non-integer upsample %dx%d -> %dx%d", s->H, s->W, dst->H, dst->W);
+    const int64_t total = (int64_t)s->N * s->H * s->W * (s->C / 4);
+    hipLaunchKernelGGL(k_ew_bwd_src, dim3(grid_cap((total + 255) / 256, 8)), dim3(256), 0, (hipStream_t)stream, *s, *dst, ddst,
+                       (const float*)nullptr, out_slope, dsrcs[i], accumulate[i]);
+  }
+  LHN_CHECK_LAUNCH("lhn_ew_bwd");
+  return 0;
+}
+// variant used by the plan: dst may carry a channel-attention gate and its pooled-gradient (dpool)
+int lhn_ew_bwd2(const lhn_view* src, const lhn_view* dst, const float* ddst, const float* dst_dpool, float out_slope,
+                float* dsrc, int accumulate, void* stream) {
+  LHN_CHECK_ARG(lhn_view_ok(src) && lhn_view_ok(dst) && ddst && dsrc && src->C == dst->C, "lhn_ew_bwd2: bad args");
+  LHN_CHECK_ARG(dst->H % src->H == 0 && dst->W % src->W == 0, "lhn_ew_bwd2: non-integer upsample");
+  const int64_t total = (int64_t)src->N * src->H * src->W * (src->C / 4);
+  hipLaunchKernelGGL(k_ew_bwd_src, dim3(grid_cap((total + 255) / 256, 8)), dim3(256), 0, (hipStream_t)stream, *src, *dst, ddst,
+                     dst_dpool, out_slope, dsrc, accumulate);
+  LHN_CHECK_LAUNCH("lhn_ew_bwd2");
+  return 0;
+}
+
+int lhn_maxpool2_fwd(const lhn_view* x, const lhn_view* y, void* stream) {
+  LHN_CHECK_ARG(lhn_view_ok(x) && lhn_view_ok(y) && x->C == y->C, "lhn_maxpool2_fwd: bad views");
+  LHN_CHECK_ARG(y->H == (x->H + 1) / 2 && y->W == (x->W + 1) / 2 && y->N == x->N, "lhn_maxpool2_fwd: geometry");
+  const int64_t total = (int64_t)y->N * y->H * y->W * (y->C / 4);
+  hipLaunchKernelGGL(k_maxpool2_fwd, dim3(grid_cap((total + 255) / 256, 8)), dim3(256), 0, (hipStream_t)stream, *x, *y);
+  LHN_CHECK_LAUNCH("lhn_maxpool2_fwd");
+  return 0;
+}
+int lhn_maxpool2_bwd(const lhn_view* x, const lhn_view* y, const float* dy, float* dx, int dx_accumulate, void* stream) {
+  LHN_CHECK_ARG(lhn_view_ok(x) && lhn_view_ok(y) && dy && dx && x->C == y->C, "lhn_maxpool2_bwd: bad args");
+  const int64_t total = (int64_t)x->N * x->H * x->W * (x->C / 4);
+  hipLaunchKernelGGL(k_maxpool2_bwd, dim3(grid_cap((total + 255) / 256, 8)), dim3(256), 0, (hipStream_t)stream, *x, *y, dy, dx, dx_accumulate);
+  LHN_CHECK_LAUNCH("lhn_maxpool2_bwd");
+  return 0;
+}
+
+int lhn_avgpool_fwd(const lhn_view* x, float* out, int OH, int OW, void* stream) {
+  LHN_CHECK_ARG(lhn_view_ok(x) && out && OH > 0 && OW > 0, "lhn_avgpool_fwd: bad args");
+  LHN_CHECK_ARG(pow2i(x->C / 4) && x->C <= 1024, "lhn_avgpool_fwd: C=%d", x->C);
+  hipLaunchKernelGGL(k_avgpool_fwd, dim3(x->N * OH * OW), dim3(256), 0, (hipStream_t)stream, *x, out, OH, OW);
+  LHN_CHECK_LAUNCH("lhn_avgpool_fwd");
+  return 0;
+}
+int lhn_avgpool_bwd(const lhn_view* x, const float* dout, int OH, int OW, float* dx, int dx_accumulate, void* stream) {
+  LHN_CHECK_ARG(lhn_view_ok(x) && dout && dx, "lhn_avgpool_bwd: bad args");
+  const int64_t total = (int64_t)x->N * x->H * x->W * (x->C / 4);
+  hipLaunchKernelGGL(k_avgpool_bwd, dim3(grid_cap((total + 255) / 256, 8)), dim3(256), 0, (hipStream_t)stream, *x, dout, OH, OW, dx, dx_accumulate);
+  LHN_CHECK_LAUNCH("lhn_avgpool_bwd");
+  return 0;
+}
+
+int lhn_ca_mlp_fwd(const float* pooled, const float* w3, const float* gamma, const float* beta, float* rmean, float* rvar,
+                   int64_t* nbt, const float* w1, const float* b1, const float* w2, const float* b2, const float* dropmask,
+                   float* gate, int gate_stride, int gate_coff, float* save, int N, int C, float eps, float momentum,
+                   int training, void* stream) {
+  LHN_CHECK_ARG(pooled && w3 && gamma && beta && rmean && rvar && w1 && b1 && w2 && b2 && gate && save, "lhn_ca_mlp_fwd: null pointer");
+  LHN_CHECK_ARG(C > 0 && C <= 256 && C % 2 == 0 && N > 0, "lhn_ca_mlp_fwd: C=%d (<=256)", C);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_ca1, dim3(1), dim3(C <= 128 ? 128 : 256), 0, s, pooled, w3, gamma, beta, rmean, rvar, nbt, dropmask, save, N, C, eps, momentum, training);
+  hipLaunchKernelGGL(k_ca2, dim3(N), dim3(128), 0, s, w1, b1, w2, b2, save, gate, gate_stride, gate_coff, N, C);
+  LHN_CHECK_LAUNCH("lhn_ca_mlp_fwd");
+  return 0;
+}
+
+int lhn_gate_bwd_reduce(const lhn_view* y, const float* dz, float* dgate, void* stream) {
+  LHN_CHECK_ARG(lhn_view_ok(y) && dz && dgate && pow2i(y->C / 4), "lhn_gate_bwd_reduce: bad args");
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(dgate, 0, (size_t)y->N * y->C * 4, s) != hipSuccess) {
+    lhn_set_error("lhn_gate_bwd_reduce: memset failed");
+    return 2;
+  }
+  int split = (y->H * y->W + 1023) / 1024;
+  if (split < 1) split = 1;
+  if (split > 16) split = 16;
+  hipLaunchKernelGGL(k_gate_bwd_reduce, dim3(y->N, split), dim3(256), 0, s, *y, dz, dgate);
+  LHN_CHECK_LAUNCH("lhn_gate_bwd_reduce");
+  return 0;
+}
+
+// scratch: dahat [N][C] floats taken from the tail of `dpool`'s owner?  No: caller passes save; dahat reuses
+// the `a`-sized region appended after the forward save area (save must have room for N*C extra floats).
+int lhn_ca_mlp_bwd(const float* pooled, const float* w3, const float* gamma, const float* w1, const float* w2,
+                   const float* dropmask, const float* save, const float* dgate, float* dpool, int cstride, int coff, int H,
+                   int W, float* dw3, float* dgamma, float* dbeta, float* dw1, float* db1, float* dw2, float* db2, int N,
+                   int C, void* stream) {
+  LHN_CHECK_ARG(pooled && w3 && gamma && w1 && w2 && save && dgate && dpool && dw3 && dgamma && dbeta && dw1 && db1 && dw2 && db2,
+                "lhn_ca_mlp_bwd: null pointer");
+  LHN_CHECK_ARG(C > 0 && C <= 256 && C % 2 == 0, "lhn_ca_mlp_bwd: C=%d", C);
+  hipStream_t s = (hipStream_t)stream;
+  float* dahat = const_cast<float*>(save) + (int64_t)N * C * 3 + (int64_t)N * (C / 2) + 2 * C;
+  hipLaunchKernelGGL(k_ca_bwd2, dim3(N), dim3(256), 0, s, w1, w2, save, dgate, dahat, dw1, db1, dw2, db2, N, C);
+  hipLaunchKernelGGL(k_ca_bwd1, dim3(1), dim3(C <= 128 ? 128 : 256), 0, s, pooled, w3, gamma, dropmask, save, dahat, dpool, cstride, coff, H, W, dw3, dgamma, dbeta, N, C, 1);
+  LHN_CHECK_LAUNCH("lhn_ca_mlp_bwd");
+  return 0;
+}
+
+int lhn_bn_bwd_reduce(const lhn_view* y, const lhn_gradview* g, const float* save, double* sums, void* stream) {
+  LHN_CHECK_ARG(lhn_view_ok(y) && g && g->dz && save && sums && pow2i(y->C / 4) && y->C <= 1024, "lhn_bn_bwd_reduce: bad args");
+  const int PL = 256 / (y->C / 4);
+  const int64_t total = (int64_t)y->N * y->H * y->W;
+  hipLaunchKernelGGL(k_bn_bwd_reduce, dim3(grid_cap((total + PL - 1) / PL, 8)), dim3(256), 0, (hipStream_t)stream, *y, *g, save, sums);
+  LHN_CHECK_LAUNCH("lhn_bn_bwd_reduce");
+  return 0;
+}
+int lhn_bn_bwd_finalize(const double* sums, const float* gamma, const float* save, float* coef, int cstride, int coff, int C,
+                        double count, float* dgamma, float* dbeta, void* stream) {
+  LHN_CHECK_ARG(sums && save && coef && C > 0 && coff + C <= cstride, "lhn_bn_bwd_finalize: bad args");
+  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(1), dim3(C <= 64 ? 64 : (C <= 128 ? 128 : 256)), 0, (hipStream_t)stream, sums, gamma, save, coef, cstride, coff, C, count, dgamma, dbeta);
+  LHN_CHECK_LAUNCH("lhn_bn_bwd_finalize");
+  return 0;
+}
+}  // extern "C"

@@ -1,0 +1,155 @@
+// Shared host/device helpers for liblhn (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/lhn.h"
+
+#define LHN_WAVE 64
+
+void lhn_set_error(const char* fmt, ...);
+
+#define LHN_CHECK_ARG(cond, ...)                 \
+  do {                                           \
+    if (!(cond)) {                               \
+      lhn_set_error(__VA_ARGS__);                \
+      return 1;                                  \
+    }                                            \
+  } while (0)
+
+#define LHN_CHECK_LAUNCH(name)                                                    \
+  do {                                                                            \
+    hipError_t e__ = hipGetLastError();                                           \
+    if (e__ != hipSuccess) {                                                      \
+      lhn_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));       \
+      return 2;                                                                   \
+    }                                                                             \
+  } while (0)
+
+static inline int lhn_view_ok(const lhn_view* v) {
+  return v && v->data && v->N > 0 && v->H > 0 && v->W > 0 && v->C > 0 && v->coff >= 0 &&
+         v->coff + v->C <= v->cstride && (v->cstride % 4) == 0 && (v->coff % 4) == 0 && (v->C % 4) == 0;
+}
+
+// number of CUs; grid caps for persistent grid-stride kernels
+static inline int lhn_num_cus() {
+  static int n = 0;
+  if (!n) {
+    hipDeviceProp_t p;
+    int d = 0;
+    if (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess) n = p.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+
+#ifdef __HIPCC__
+// ---------------------------------------------------------------- device side
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float lhn_lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
+
+// pending transform of 4 consecutive channels of a view (absolute channel c, multiple of 4)
+struct Xf4 {
+  f4 sc, sh, sl;
+};
+__device__ __forceinline__ Xf4 lhn_load_xf(const lhn_view& v, int c_abs) {
+  Xf4 t;
+  if (v.table) {
+    t.sc = *reinterpret_cast<const f4*>(v.table + c_abs);
+    t.sh = *reinterpret_cast<const f4*>(v.table + v.cstride + c_abs);
+    t.sl = *reinterpret_cast<const f4*>(v.table + 2 * v.cstride + c_abs);
+  } else {
+    t.sc = (f4){1.f, 1.f, 1.f, 1.f};
+    t.sh = (f4){0.f, 0.f, 0.f, 0.f};
+    t.sl = (f4){1.f, 1.f, 1.f, 1.f};
+  }
+  return t;
+}
+__device__ __forceinline__ f4 lhn_apply_xf(f4 raw, const Xf4& t) {
+  f4 u = raw * t.sc + t.sh;
+  f4 r;
+  r.x = lhn_lrelu(u.x, t.sl.x);
+  r.y = lhn_lrelu(u.y, t.sl.y);
+  r.z = lhn_lrelu(u.z, t.sl.z);
+  r.w = lhn_lrelu(u.w, t.sl.w);
+  return r;
+}
+// consumed value of 4 channels at pixel index pix (= (n*H+h)*W+w), image n
+__device__ __forceinline__ f4 lhn_load_val(const lhn_view& v, const Xf4& t, int64_t pix, int n, int c_abs) {
+  f4 raw = *reinterpret_cast<const f4*>(v.data + pix * v.cstride + c_abs);
+  f4 r = lhn_apply_xf(raw, t);
+  if (v.gate) r *= *reinterpret_cast<const f4*>(v.gate + (int64_t)n * v.cstride + c_abs);
+  return r;
+}
+
+// d(loss)/d(BN output u) and d(loss)/d(raw y) for 4 channels of a conv output, given the gradient
+// w.r.t. the consumed value.  eff_dz = gate*dz + sum_bins dpool ;  du = eff_dz * lrelu'(u) ;
+// dy = A*du + B*y + C  (coef == NULL: dy = du)
+struct Gr4 {
+  f4 A, B, Cc;
+};
+__device__ __forceinline__ Gr4 lhn_load_coef(const lhn_gradview& g, int cstride, int c_abs) {
+  Gr4 r;
+  if (g.coef) {
+    r.A = *reinterpret_cast<const f4*>(g.coef + c_abs);
+    r.B = *reinterpret_cast<const f4*>(g.coef + cstride + c_abs);
+    r.Cc = *reinterpret_cast<const f4*>(g.coef + 2 * cstride + c_abs);
+  } else {
+    r.A = (f4){1.f, 1.f, 1.f, 1.f};
+    r.B = (f4){0.f, 0.f, 0.f, 0.f};
+    r.Cc = (f4){0.f, 0.f, 0.f, 0.f};
+  }
+  return r;
+}
+// adaptive-avg-pool(3x3) bin membership: bin i covers [floor(i*S/3), ceil((i+1)*S/3))
+__device__ __forceinline__ int lhn_bin_lo(int i, int S) { return (i * S) / 3; }
+__device__ __forceinline__ int lhn_bin_hi(int i, int S) { return ((i + 1) * S + 2) / 3; }
+
+__device__ __forceinline__ f4 lhn_dpool_sum(const lhn_gradview& g, const lhn_view& v, int n, int h, int w, int c_abs) {
+  f4 s = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int bi = 0; bi < 3; ++bi) {
+    if (h < lhn_bin_lo(bi, v.H) || h >= lhn_bin_hi(bi, v.H)) continue;
+#pragma unroll
+    for (int bj = 0; bj < 3; ++bj) {
+      if (w < lhn_bin_lo(bj, v.W) || w >= lhn_bin_hi(bj, v.W)) continue;
+      s += *reinterpret_cast<const f4*>(g.dpool + ((int64_t)n * 9 + bi * 3 + bj) * v.cstride + c_abs);
+    }
+  }
+  return s;
+}
+// returns du (gradient at the BN output) and, through *val_out, nothing else; raw = y
+__device__ __forceinline__ f4 lhn_grad_du(const lhn_view& v, const lhn_gradview& g, const Xf4& t, f4 raw, f4 dz,
+                                          int n, int h, int w, int c_abs) {
+  f4 e = dz;
+  if (v.gate) e *= *reinterpret_cast<const f4*>(v.gate + (int64_t)n * v.cstride + c_abs);
+  f4 u = raw * t.sc + t.sh;
+  f4 du;
+  du.x = e.x * (u.x > 0.f ? 1.f : t.sl.x);
+  du.y = e.y * (u.y > 0.f ? 1.f : t.sl.y);
+  du.z = e.z * (u.z > 0.f ? 1.f : t.sl.z);
+  du.w = e.w * (u.w > 0.f ? 1.f : t.sl.w);
+  if (g.dpool) {
+    f4 dp = lhn_dpool_sum(g, v, n, h, w, c_abs);   // pooled value is the *post-activation* value
+    du.x += dp.x * (u.x > 0.f ? 1.f : t.sl.x);
+    du.y += dp.y * (u.y > 0.f ? 1.f : t.sl.y);
+    du.z += dp.z * (u.z > 0.f ? 1.f : t.sl.z);
+    du.w += dp.w * (u.w > 0.f ? 1.f : t.sl.w);
+  }
+  return du;
+}
+
+__device__ __forceinline__ float lhn_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double lhn_wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+#endif

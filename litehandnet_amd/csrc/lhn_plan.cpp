@@ -1,0 +1,279 @@
+// Static plan executor: one call enqueues a whole forward or backward pass on a HIP stream.
+// The plan (buffers + op lists) is produced by the Python mirror of the reference's module tree;
+// this file only resolves offsets into the workspace arena / parameter array and calls the launchers.
+#include <vector>
+#include "lhn_common.h"
+
+extern "C" int lhn_ew_bwd2(const lhn_view* src, const lhn_view* dst, const float* ddst, const float* dst_dpool,
+                           float out_slope, float* dsrc, int accumulate, void* stream);
+
+enum {
+  OP_STEM = 1, OP_PW = 2, OP_DW = 3, OP_KXK = 4, OP_FINALIZE = 5, OP_EW = 6, OP_MAXPOOL = 7, OP_AVGPOOL = 8,
+  OP_CA_MLP = 9, OP_TABLE_FILL = 10, OP_MEMSET = 11,
+  OP_STEM_BWD = 101, OP_PW_BWD = 102, OP_DW_BWD = 103, OP_KXK_BWD = 104, OP_BN_BWD = 105, OP_EW_BWD = 106,
+  OP_MAXPOOL_BWD = 107, OP_AVGPOOL_BWD = 108, OP_GATE_REDUCE = 109, OP_CA_MLP_BWD = 110,
+};
+
+struct Plan {
+  std::vector<lhn_buf> bufs;
+  std::vector<lhn_op> fwd, bwd;
+};
+
+static inline char* at(void* ws, int64_t off) { return off < 0 ? nullptr : static_cast<char*>(ws) + off; }
+
+static lhn_view mkview(const Plan* P, void* ws, int buf, int coff, int C, bool with_gate = true) {
+  const lhn_buf& b = P->bufs[buf];
+  lhn_view v;
+  v.data = reinterpret_cast<float*>(at(ws, b.data_off));
+  v.table = reinterpret_cast<const float*>(at(ws, b.table_off));
+  v.gate = with_gate ? reinterpret_cast<const float*>(at(ws, b.gate_off)) : nullptr;
+  v.N = b.N; v.H = b.H; v.W = b.W;
+  v.cstride = b.C; v.coff = coff; v.C = C;
+  return v;
+}
+static lhn_gradview mkgrad(const Plan* P, void* ws, int buf, bool use_coef) {
+  const lhn_buf& b = P->bufs[buf];
+  lhn_gradview g;
+  g.dz = reinterpret_cast<const float*>(at(ws, b.grad_off));
+  g.dpool = reinterpret_cast<const float*>(at(ws, b.dpool_off));
+  g.coef = use_coef ? reinterpret_cast<const float*>(at(ws, b.coef_off)) : nullptr;
+  return g;
+}
+template <typename T>
+static inline T* prm(void* const* arr, int idx) { return idx < 0 ? nullptr : static_cast<T*>(arr[idx]); }
+
+extern "C" {
+
+void* lhn_plan_create(const lhn_buf* bufs, int nbufs, const lhn_op* fwd, int nfwd, const lhn_op* bwd, int nbwd) {
+  if (!bufs || nbufs <= 0 || !fwd || nfwd <= 0) {
+    lhn_set_error("lhn_plan_create: empty plan");
+    return nullptr;
+  }
+  Plan* p = new Plan();
+  p->bufs.assign(bufs, bufs + nbufs);
+  p->fwd.assign(fwd, fwd + nfwd);
+  if (bwd && nbwd > 0) p->bwd.assign(bwd, bwd + nbwd);
+  for (const auto* lst : {&p->fwd, &p->bwd})
+    for (const lhn_op& o : *lst) {
+      bool ok = o.out_buf < nbufs;
+      for (int k = 0; k < 3; ++k) ok = ok && o.in_buf[k] < nbufs;
+      if (!ok) {
+        lhn_set_error("lhn_plan_create: op kind %d references buffer out of range", o.kind);
+        delete p;
+        return nullptr;
+      }
+    }
+  return p;
+}
+
+void lhn_plan_destroy(void* plan) { delete static_cast<Plan*>(plan); }
+
+int lhn_plan_run(void* plan, int phase, void* ws, void* const* params, void* const* grads, void* const* io, int training,
+                 void* stream) {
+  LHN_CHECK_ARG(plan && ws && params && io, "lhn_plan_run: null argument");
+  LHN_CHECK_ARG(phase == 0 || (phase == 1 && grads), "lhn_plan_run: phase %d", phase);
+  const Plan* P = static_cast<const Plan*>(plan);
+  const std::vector<lhn_op>& ops = phase == 0 ? P->fwd : P->bwd;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int rc = 0;
+  for (size_t oi = 0; oi < ops.size() && rc == 0; ++oi) {
+    const lhn_op& o = ops[oi];
+    switch (o.kind) {
+      case OP_MEMSET: {
+        if (hipMemsetAsync(at(ws, o.ws[0]), 0, (size_t)o.ws[1], s) != hipSuccess) {
+          lhn_set_error("lhn_plan_run: memset failed");
+          rc = 2;
+        }
+        break;
+      }
+      case OP_TABLE_FILL: {
+        const lhn_buf& b = P->bufs[o.out_buf];
+        rc = lhn_table_fill(reinterpret_cast<float*>(at(ws, b.table_off)), b.C, o.out_coff, o.out_C, o.f[0], o.f[1], o.f[2], stream);
+        break;
+      }
+      case OP_STEM: {
+        lhn_view y = mkview(P, ws, o.out_buf, o.out_coff, o.out_C);
+        rc = lhn_conv_stem_fwd(static_cast<const float*>(io[0]), prm<const float>(params, o.p[0]), &y,
+                               training ? reinterpret_cast<double*>(at(ws, o.ws[0])) : nullptr, o.i[3], o.i[4], o.i[0], o.i[1],
+                               o.i[2], stream);
+        break;
+      }
+      case OP_PW: {
+        lhn_view x = mkview(P, ws, o.in_buf[0], o.in_coff[0], o.in_C[0]);
+        lhn_view y;
+        float* nchw = nullptr;
+        if (o.i[1]) {  // NCHW head: geometry from the input, channels from out_C
+          y = x;
+          y.data = nullptr; y.table = nullptr; y.gate = nullptr;
+          y.cstride = o.out_C; y.coff = 0; y.C = o.out_C;
+          nchw = static_cast<float*>(io[1]);
+        } else {
+          y = mkview(P, ws, o.out_buf, o.out_coff, o.out_C);
+        }
+        rc = lhn_conv_pw_fwd(&x, prm<const float>(params, o.p[0]), prm<const float>(params, o.p[1]), &y,
+                             (training && o.ws[0] >= 0) ? reinterpret_cast<double*>(at(ws, o.ws[0])) : nullptr, o.i[0], nchw,
+                             stream);
+        break;
+      }
+      case OP_DW: {
+        lhn_view x = mkview(P, ws, o.in_buf[0], o.in_coff[0], o.in_C[0]);
+        lhn_view y = mkview(P, ws, o.out_buf, o.out_coff, o.out_C);
+        rc = lhn_conv_dw_fwd(&x, prm<const float>(params, o.p[0]), &y,
+                             training ? reinterpret_cast<double*>(at(ws, o.ws[0])) : nullptr, o.i[0], o.i[1], o.i[2], o.i[3],
+                             stream);
+        break;
+      }
+      case OP_KXK: {
+        lhn_view x = mkview(P, ws, o.in_buf[0], o.in_coff[0], o.in_C[0]);
+        lhn_view y = mkview(P, ws, o.out_buf, o.out_coff, o.out_C);
+        rc = lhn_conv_kxk_fwd(&x, prm<const float>(params, o.p[0]), &y,
+                              training ? reinterpret_cast<double*>(at(ws, o.ws[0])) : nullptr, o.i[0], stream);
+        break;
+      }
+      case OP_FINALIZE: {
+        const lhn_buf& b = P->bufs[o.out_buf];
+        const int src = o.in_buf[0] >= 0 ? o.in_buf[0] : o.out_buf;   // geometry the statistics were taken over
+        const lhn_buf& sb = P->bufs[src];
+        rc = lhn_bn_finalize(reinterpret_cast<const double*>(at(ws, o.ws[0])), prm<const float>(params, o.p[0]),
+                             prm<const float>(params, o.p[1]), prm<float>(params, o.p[2]), prm<float>(params, o.p[3]),
+                             prm<int64_t>(params, o.p[4]), reinterpret_cast<float*>(at(ws, b.table_off)), b.C, o.out_coff,
+                             o.out_C, reinterpret_cast<float*>(at(ws, o.ws[1])), (double)sb.N * sb.H * sb.W, o.f[0], o.f[1],
+                             o.f[2], training, stream);
+        break;
+      }
+      case OP_EW: {
+        lhn_view srcs[3];
+        for (int k = 0; k < o.i[0]; ++k) srcs[k] = mkview(P, ws, o.in_buf[k], o.in_coff[k], o.in_C[k]);
+        lhn_view d = mkview(P, ws, o.out_buf, o.out_coff, o.out_C);
+        rc = lhn_ew_fwd(srcs, o.i[0], &d, o.f[0], stream);
+        break;
+      }
+      case OP_MAXPOOL: {
+        lhn_view x = mkview(P, ws, o.in_buf[0], o.in_coff[0], o.in_C[0]);
+        lhn_view y = mkview(P, ws, o.out_buf, o.out_coff, o.out_C);
+        rc = lhn_maxpool2_fwd(&x, &y, stream);
+        break;
+      }
+      case OP_AVGPOOL: {
+        lhn_view x = mkview(P, ws, o.in_buf[0], o.in_coff[0], o.in_C[0], o.i[2] == 0);
+        rc = lhn_avgpool_fwd(&x, reinterpret_cast<float*>(at(ws, o.ws[0])), o.i[0], o.i[1], stream);
+        break;
+      }
+      case OP_CA_MLP: {
+        const lhn_buf& b = P->bufs[o.out_buf];
+        rc = lhn_ca_mlp_fwd(reinterpret_cast<const float*>(at(ws, o.ws[0])), prm<const float>(params, o.p[0]),
+                            prm<const float>(params, o.p[1]), prm<const float>(params, o.p[2]), prm<float>(params, o.p[3]),
+                            prm<float>(params, o.p[4]), prm<int64_t>(params, o.p[5]), prm<const float>(params, o.p[6]),
+                            prm<const float>(params, o.p[7]), prm<const float>(params, o.p[8]), prm<const float>(params, o.p[9]),
+                            (training && o.ws[2] >= 0) ? reinterpret_cast<const float*>(at(ws, o.ws[2])) : nullptr,
+                            reinterpret_cast<float*>(at(ws, b.gate_off)), b.C, o.out_coff,
+                            reinterpret_cast<float*>(at(ws, o.ws[1])), b.N, o.out_C, o.f[0], o.f[1], training, stream);
+        break;
+      }
+      // ------------------------------------------------------------------ backward
+      case OP_STEM_BWD: {
+        lhn_view y = mkview(P, ws, o.out_buf, o.out_coff, o.out_C);
+        lhn_gradview g = mkgrad(P, ws, o.out_buf, o.i[5] != 0);
+        rc = lhn_conv_stem_bwd(static_cast<const float*>(io[0]), &y, &g, prm<float>(grads, o.p[1]), o.i[3], o.i[4], o.i[0],
+                               o.i[1], o.i[2], stream);
+        break;
+      }
+      case OP_PW_BWD: {
+        lhn_view x = mkview(P, ws, o.in_buf[0], o.in_coff[0], o.in_C[0]);
+        lhn_view y;
+        lhn_gradview g;
+        const float* nchw = nullptr;
+        if (o.i[1]) {
+          y = x;
+          y.data = nullptr; y.table = nullptr; y.gate = nullptr;
+          y.cstride = o.out_C; y.coff = 0; y.C = o.out_C;
+          g.dz = nullptr; g.dpool = nullptr; g.coef = nullptr;
+          nchw = static_cast<const float*>(io[1]);
+        } else {
+          y = mkview(P, ws, o.out_buf, o.out_coff, o.out_C);
+          g = mkgrad(P, ws, o.out_buf, o.i[5] != 0);
+        }
+        float* dx = o.i[2] ? reinterpret_cast<float*>(at(ws, P->bufs[o.in_buf[0]].grad_off)) : nullptr;
+        rc = lhn_conv_pw_bwd(&x, prm<const float>(params, o.p[0]), &y, &g, dx, o.i[2] == 2, prm<float>(grads, o.p[1]),
+                             prm<float>(grads, o.p[2]), o.i[0], nchw, stream);
+        break;
+      }
+      case OP_DW_BWD: {
+        lhn_view x = mkview(P, ws, o.in_buf[0], o.in_coff[0], o.in_C[0]);
+        lhn_view y = mkview(P, ws, o.out_buf, o.out_coff, o.out_C);
+        lhn_gradview g = mkgrad(P, ws, o.out_buf, o.i[5] != 0);
+        float* dx = o.i[4] ? reinterpret_cast<float*>(at(ws, P->bufs[o.in_buf[0]].grad_off)) : nullptr;
+        rc = lhn_conv_dw_bwd(&x, prm<const float>(params, o.p[0]), &y, &g, dx, o.i[4] == 2, prm<float>(grads, o.p[1]), o.i[0],
+                             o.i[1], o.i[2], o.i[3], stream);
+        break;
+      }
+      case OP_KXK_BWD: {
+        lhn_view x = mkview(P, ws, o.in_buf[0], o.in_coff[0], o.in_C[0]);
+        lhn_view y = mkview(P, ws, o.out_buf, o.out_coff, o.out_C);
+        lhn_gradview g = mkgrad(P, ws, o.out_buf, o.i[5] != 0);
+        float* dx = o.i[2] ? reinterpret_cast<float*>(at(ws, P->bufs[o.in_buf[0]].grad_off)) : nullptr;
+        rc = lhn_conv_kxk_bwd(&x, prm<const float>(params, o.p[0]), &y, &g, dx, o.i[2] == 2, prm<float>(grads, o.p[1]), o.i[0],
+                              stream);
+        break;
+      }
+      case OP_BN_BWD: {
+        const lhn_buf& b = P->bufs[o.out_buf];
+        lhn_view y = mkview(P, ws, o.out_buf, o.out_coff, o.out_C);
+        lhn_gradview g = mkgrad(P, ws, o.out_buf, false);
+        double* sums = reinterpret_cast<double*>(at(ws, o.ws[0]));
+        const float* save = reinterpret_cast<const float*>(at(ws, o.ws[1]));
+        rc = lhn_bn_bwd_reduce(&y, &g, save, sums, stream);
+        if (!rc)
+          rc = lhn_bn_bwd_finalize(sums, prm<const float>(params, o.p[0]), save, reinterpret_cast<float*>(at(ws, b.coef_off)),
+                                   b.C, o.out_coff, o.out_C, (double)b.N * b.H * b.W, prm<float>(grads, o.p[1]),
+                                   prm<float>(grads, o.p[2]), stream);
+        break;
+      }
+      case OP_EW_BWD: {
+        lhn_view src = mkview(P, ws, o.in_buf[0], o.in_coff[0], o.in_C[0]);
+        lhn_view d = mkview(P, ws, o.out_buf, o.out_coff, o.out_C);
+        const lhn_buf& db = P->bufs[o.out_buf];
+        rc = lhn_ew_bwd2(&src, &d, reinterpret_cast<const float*>(at(ws, db.grad_off)),
+                         reinterpret_cast<const float*>(at(ws, db.dpool_off)), o.f[0],
+                         reinterpret_cast<float*>(at(ws, P->bufs[o.in_buf[0]].grad_off)), o.i[0], stream);
+        break;
+      }
+      case OP_MAXPOOL_BWD: {
+        lhn_view x = mkview(P, ws, o.in_buf[0], o.in_coff[0], o.in_C[0]);
+        lhn_view y = mkview(P, ws, o.out_buf, o.out_coff, o.out_C);
+        rc = lhn_maxpool2_bwd(&x, &y, reinterpret_cast<const float*>(at(ws, P->bufs[o.out_buf].grad_off)),
+                              reinterpret_cast<float*>(at(ws, P->bufs[o.in_buf[0]].grad_off)), o.i[0], stream);
+        break;
+      }
+      case OP_AVGPOOL_BWD: {
+        lhn_view x = mkview(P, ws, o.in_buf[0], o.in_coff[0], o.in_C[0]);
+        rc = lhn_avgpool_bwd(&x, reinterpret_cast<const float*>(at(ws, o.ws[0])), o.i[0], o.i[1],
+                             reinterpret_cast<float*>(at(ws, P->bufs[o.in_buf[0]].grad_off)), o.i[2], stream);
+        break;
+      }
+      case OP_GATE_REDUCE: {
+        lhn_view y = mkview(P, ws, o.out_buf, o.out_coff, o.out_C, false);
+        rc = lhn_gate_bwd_reduce(&y, reinterpret_cast<const float*>(at(ws, P->bufs[o.out_buf].grad_off)),
+                                 reinterpret_cast<float*>(at(ws, o.ws[3])), stream);
+        break;
+      }
+      case OP_CA_MLP_BWD: {
+        const lhn_buf& b = P->bufs[o.out_buf];
+        rc = lhn_ca_mlp_bwd(reinterpret_cast<const float*>(at(ws, o.ws[0])), prm<const float>(params, o.p[0]),
+                            prm<const float>(params, o.p[1]), prm<const float>(params, o.p[2]), prm<const float>(params, o.p[3]),
+                            o.ws[2] >= 0 ? reinterpret_cast<const float*>(at(ws, o.ws[2])) : nullptr,
+                            reinterpret_cast<const float*>(at(ws, o.ws[1])), reinterpret_cast<const float*>(at(ws, o.ws[3])),
+                            reinterpret_cast<float*>(at(ws, b.dpool_off)), b.C, o.out_coff, b.H, b.W, prm<float>(grads, o.p[4]),
+                            prm<float>(grads, o.p[5]), prm<float>(grads, o.p[6]), prm<float>(grads, o.p[7]),
+                            prm<float>(grads, o.p[8]), prm<float>(grads, o.p[9]), prm<float>(grads, o.p[10]), b.N, o.out_C,
+                            stream);
+        break;
+      }
+      default:
+        lhn_set_error("lhn_plan_run: unknown op kind %d at index %zu", o.kind, oi);
+        rc = 1;
+    }
+  }
+  return rc;
+}
+}  // extern "C"

@@ -1,0 +1,159 @@
+"""Execution engine: compiles a module tree into a static plan per input shape and runs it through
+`lhn_plan_run` behind one `torch.autograd.Function` (one C call per forward / backward).
+
+Gradients land in ONE flat fp32 buffer (views of it become `param.grad`), so data-parallel training
+is a single RCCL all-reduce of that buffer (train/spawn_dist.py:49-52 uses DDP's bucketed reducer).
+"""
+import torch
+from torch import nn
+
+from . import _lib
+from .plan import CompiledPlan, PlanBuilder
+
+
+class PlanModule(nn.Module):
+    """Base of every mirrored block.  `emit(pb, x, out=None)` appends the block to a plan;
+    calling the module on an NCHW tensor compiles and runs a plan for this block alone."""
+
+    def emit(self, pb, x, out=None):
+        raise NotImplementedError
+
+    def forward(self, x):
+        eng = self.__dict__.get("_engine")
+        if eng is None:
+            eng = Engine(self)
+            self.__dict__["_engine"] = eng
+        return eng(x)
+
+
+def _is_full_model(m):
+    return getattr(m, "consumes_image", False)
+
+
+class _PlanFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, anchor, eng, training, *params):
+        plan = eng.plan_for(x, with_backward=torch.is_grad_enabled() or ctx.needs_input_grad[0] or anchor.requires_grad)
+        ctx.eng, ctx.plan, ctx.training, ctx.via_autograd = eng, plan, training, len(params) > 0
+        plan.refresh_params()
+        xc = x.contiguous()
+        if eng.full:
+            out = torch.empty((x.shape[0], plan.pb.nchw_out_C, plan.out_hw[0], plan.out_hw[1]), dtype=torch.float32,
+                              device=x.device)
+            plan.run(0, xc, out, training)
+            ctx.save_for_backward(xc)
+        else:
+            plan.buf_data(plan.pb.in_ref).copy_(xc.permute(0, 2, 3, 1))
+            plan.run(0, None, None, training)
+            out = plan.buf_data(plan.pb.out_ref).permute(0, 3, 1, 2).contiguous()
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        eng, plan = ctx.eng, ctx.plan
+        if not ctx.training:
+            raise _lib.LhnError("backward through an eval-mode (running-statistics) plan is not supported")
+        if plan.n_bwd == 0:
+            raise _lib.LhnError("plan was compiled without a backward pass")
+        eng.flat_grads.zero_()
+        plan.set_grads(eng.grad_views)
+        dx = None
+        if eng.full:
+            (xc,) = ctx.saved_tensors
+            plan.run(1, xc, dout.contiguous(), True)
+        else:
+            plan.buf_data(plan.pb.out_ref, grad=True).copy_(dout.permute(0, 2, 3, 1))
+            plan.run(1, None, None, True)
+            dx = plan.buf_data(plan.pb.in_ref, grad=True).permute(0, 3, 1, 2).contiguous()
+        if ctx.via_autograd:
+            return (dx, None, None, None) + tuple(eng.param_grad_views)
+        eng.publish_grads()
+        return dx, None, None, None
+
+
+class Engine:
+    def __init__(self, module, p_drop=None):
+        self.module = module
+        self.full = _is_full_model(module)
+        self.plans = {}
+        self.anchor = None
+        self.flat_grads = None
+        self.grads_via_autograd = False     # True: return per-parameter grads through autograd (DDP-hook compatible)
+        self.p_drop = p_drop
+
+    # -------------------------------------------------------------- state
+    def _state(self, device):
+        sd = self.module.state_dict(keep_vars=True)
+        tensors = list(sd.values())
+        for t in tensors:
+            if t.device != device:
+                raise _lib.LhnError("module parameters must live on the input's GPU (call .cuda() first)")
+            if not t.is_contiguous():
+                raise _lib.LhnError("parameters must be contiguous")
+        return tensors
+
+    def _ensure_grads(self, tensors, device):
+        params = [t for t in tensors if isinstance(t, nn.Parameter)]
+        n = sum(p.numel() for p in params)
+        if self.flat_grads is None or self.flat_grads.numel() != n or self.flat_grads.device != device:
+            self.flat_grads = torch.zeros(n, dtype=torch.float32, device=device)
+            self.anchor = torch.zeros(1, dtype=torch.float32, device=device, requires_grad=True)
+        off, views, pviews, plist = 0, [], [], []
+        for t in tensors:
+            if isinstance(t, nn.Parameter):
+                v = self.flat_grads[off:off + t.numel()].view_as(t)
+                off += t.numel()
+                views.append(v)
+                pviews.append(v)
+                plist.append(t)
+            else:
+                views.append(None)
+        self.grad_views, self.param_grad_views, self.param_list = views, pviews, plist
+
+    def publish_grads(self):
+        for p, g in zip(self.param_list, self.param_grad_views):
+            if not p.requires_grad:
+                continue
+            if p.grad is None or p.grad.data_ptr() == g.data_ptr():
+                p.grad = g
+            else:
+                p.grad.add_(g)
+
+    # -------------------------------------------------------------- plans
+    def plan_for(self, x, with_backward):
+        _lib.require_device(x)
+        if x.dim() != 4 or x.dtype != torch.float32:
+            raise _lib.LhnError(f"expected a float32 NCHW tensor, got {tuple(x.shape)} {x.dtype}")
+        p_drop = self.p_drop if self.p_drop is not None else getattr(self.module, "p_drop", 0.0)
+        key = (tuple(x.shape), bool(with_backward), float(p_drop), x.device.index)
+        plan = self.plans.get(key)
+        tensors = self._state(x.device)
+        if plan is not None and len(plan.state_tensors) == len(tensors) and all(
+                a is b for a, b in zip(plan.state_tensors, tensors)):
+            return plan
+        N, Cc, H, W = x.shape
+        self._ensure_grads(tensors, x.device)
+        index = {id(t): j for j, t in enumerate(tensors)}
+        pb = PlanBuilder(N, index, image_hw=(H, W), with_backward=with_backward, p_drop=p_drop)
+        if self.full:
+            if Cc != 3:
+                raise _lib.LhnError("the backbone consumes a 3-channel image")
+            y = self.module.emit(pb, pb.image())
+            out_hw = (y.H, y.W)
+        else:
+            y = self.module.emit(pb, pb.input_tensor(Cc, H, W))
+            pb.set_output(y)
+            out_hw = (y.H, y.W)
+        plan = CompiledPlan(pb, tensors, x.device)
+        plan.out_hw = out_hw
+        self.plans[key] = plan
+        return plan
+
+    def __call__(self, x):
+        training = self.module.training
+        if self.anchor is None or self.anchor.device != x.device:
+            self._ensure_grads(self._state(x.device), x.device)
+        if self.grads_via_autograd and torch.is_grad_enabled():
+            return _PlanFn.apply(x, self.anchor, self, training, *self.param_list)
+        anchor = self.anchor if torch.is_grad_enabled() else self.anchor.detach()
+        return _PlanFn.apply(x, anchor, self, training)

@@ -1,0 +1,173 @@
+"""HIP-backed Gaussian heatmap encode / decode / metric -- mirrors of
+datasets/data_pipeline/generateTarget.py (TopDownGenerateTarget, MSRA branches),
+utils/post_processing/evaluation/top_down_eval.py (_get_max_preds, keypoints_from_heatmaps 'default',
+keypoint_pck_accuracy), datasets/data_pipeline/post_transforms.py (transform_preds),
+utils/post_processing/decoder.py (TopDownDecoder) and utils/HeatmapParser.py:41-50 (nms)."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _dev(x, device=None):
+    if isinstance(x, np.ndarray):
+        x = torch.from_numpy(np.ascontiguousarray(x))
+    if not x.is_cuda:
+        if not torch.cuda.is_available():
+            raise _lib.LhnError("no GPU visible: litehandnet_amd has no CPU fallback")
+        x = x.to(device or "cuda", non_blocking=True)
+    return x
+
+
+# ------------------------------------------------------------------ encode
+def generate_target_batch(joints_3d, joints_3d_visible, image_size, heatmap_size, sigma=2, unbiased_encoding=True):
+    """[N,K,3] joints (image px) + visibility -> target [N,K,H,W], weight [N,K,1] on the GPU."""
+    j = _lib.f32c(_dev(joints_3d))
+    v = _lib.f32c(_dev(joints_3d_visible, j.device))
+    N, K, _ = j.shape
+    W, H = int(heatmap_size[0]), int(heatmap_size[1])
+    target = torch.empty((N, K, H, W), dtype=torch.float32, device=j.device)
+    weight = torch.empty((N, K, 1), dtype=torch.float32, device=j.device)
+    L = _lib.lib()
+    _lib.check(L.lhn_heatmap_encode(_lib.ptr(j), _lib.ptr(v), _lib.ptr(target), _lib.ptr(weight), N, K, H, W,
+                                    C.c_float(image_size[0]), C.c_float(image_size[1]), C.c_float(sigma),
+                                    1 if unbiased_encoding else 0, _lib.stream()), "lhn_heatmap_encode")
+    return target, weight
+
+
+class TopDownGenerateTarget:
+    """generateTarget.py:34-300, MSRA encoding.  `__call__(results)` keeps the per-sample dict contract
+    (numpy in, numpy out); `batch()` is the device-resident path (joints in, targets stay in HBM)."""
+
+    def __init__(self, sigma=2, kernel=(11, 11), target_type="GaussianHeatmap", encoding="MSRA",
+                 unbiased_encoding=False):
+        if encoding != "MSRA" or isinstance(sigma, (list, tuple)):
+            raise _lib.LhnError("TopDownGenerateTarget: only single-sigma MSRA encoding is built")
+        self.sigma, self.kernel, self.unbiased_encoding = sigma, kernel, unbiased_encoding
+        self.target_type, self.encoding = target_type, encoding
+
+    def batch(self, joints_3d, joints_3d_visible, image_size, heatmap_size):
+        return generate_target_batch(joints_3d, joints_3d_visible, image_size, heatmap_size, self.sigma,
+                                     self.unbiased_encoding)
+
+    def __call__(self, results):
+        cfg = results["ann_info"]
+        if cfg.get("use_different_joint_weights", False):
+            raise _lib.LhnError("use_different_joint_weights is not built")
+        t, w = self.batch(np.asarray(results["joints_3d"], np.float32)[None],
+                          np.asarray(results["joints_3d_visible"], np.float32)[None], cfg["image_size"],
+                          cfg["heatmap_size"])
+        results["target"] = t[0].cpu().numpy()
+        results["target_weight"] = w[0].cpu().numpy()
+        return results
+
+
+# ------------------------------------------------------------------ decode
+def _get_max_preds(heatmaps):
+    """top_down_eval.py:199-231 on the GPU: preds [N,K,2] (x, y; -1 where max <= 0), maxvals [N,K,1]."""
+    h = _lib.f32c(_dev(heatmaps))
+    assert h.dim() == 4, "batch_images should be 4-ndim"
+    N, K, H, W = h.shape
+    preds = torch.empty((N, K, 2), dtype=torch.float32, device=h.device)
+    maxvals = torch.empty((N, K, 1), dtype=torch.float32, device=h.device)
+    _lib.check(_lib.lib().lhn_heatmap_argmax(_lib.ptr(h), _lib.ptr(preds), _lib.ptr(maxvals), C.c_void_p(0), N, K, H, W,
+                                             _lib.stream()), "lhn_heatmap_argmax")
+    return preds, maxvals
+
+
+def refine_preds(heatmaps, preds, mode="default"):
+    """+-0.25 shift: 'default' = top_down_eval.py:440-452; 'offset' = heatmap_post_processing.py:6-33."""
+    h = _lib.f32c(_dev(heatmaps))
+    p = _lib.f32c(_dev(preds, h.device)).clone()
+    N, K, H, W = h.shape
+    _lib.check(_lib.lib().lhn_heatmap_refine(_lib.ptr(h), _lib.ptr(p), N, K, H, W, 0 if mode == "default" else 1,
+                                             _lib.stream()), "lhn_heatmap_refine")
+    return p
+
+
+def transform_preds(coords, center, scale, output_size, use_udp=False):
+    """post_transforms.py:6-48, batched: coords [N,K,2], center/scale [N,2]."""
+    c = _lib.f32c(_dev(coords))
+    ce, sc = _lib.f32c(_dev(center, c.device)), _lib.f32c(_dev(scale, c.device))
+    N, K, _ = c.shape
+    out = torch.empty_like(c)
+    _lib.check(_lib.lib().lhn_transform_preds(_lib.ptr(c), _lib.ptr(ce), _lib.ptr(sc), _lib.ptr(out), N, K,
+                                              int(output_size[0]), int(output_size[1]), 1 if use_udp else 0,
+                                              _lib.stream()), "lhn_transform_preds")
+    return out
+
+
+def keypoints_from_heatmaps(heatmaps, center, scale, post_process="default", kernel=11, use_udp=False,
+                            target_type="GaussianHeatmap", only_original_preds=False):
+    """top_down_eval.py:375-463 fused in one kernel (argmax -> shift -> back-transform); device tensors out."""
+    if use_udp or post_process not in (None, "default"):
+        raise _lib.LhnError("keypoints_from_heatmaps: only post_process None|'default' without UDP is built "
+                            "(DARK 'unbiased' is a 'next' row)")
+    h = _lib.f32c(_dev(heatmaps))
+    ce, sc = _lib.f32c(_dev(center, h.device)), _lib.f32c(_dev(scale, h.device))
+    N, K, H, W = h.shape
+    hm_preds = torch.empty((N, K, 2), dtype=torch.float32, device=h.device)
+    preds = torch.empty_like(hm_preds)
+    maxvals = torch.empty((N, K, 1), dtype=torch.float32, device=h.device)
+    _lib.check(_lib.lib().lhn_heatmap_decode(_lib.ptr(h), _lib.ptr(ce), _lib.ptr(sc), _lib.ptr(hm_preds), _lib.ptr(preds),
+                                             _lib.ptr(maxvals), N, K, H, W, 0 if post_process is None else 1,
+                                             _lib.stream()), "lhn_heatmap_decode")
+    if only_original_preds:
+        return preds, maxvals
+    return hm_preds, preds, maxvals
+
+
+def heatmap_nms(heatmaps, kernel=11):
+    """HeatmapParser.py:41-50: h * (maxpool_kxk(h) == h).  Returns a new tensor."""
+    h = _lib.f32c(_dev(heatmaps)).clone()
+    N, K, H, W = h.shape
+    scratch = torch.empty_like(h)
+    _lib.check(_lib.lib().lhn_heatmap_nms(_lib.ptr(h), _lib.ptr(scratch), N, K, H, W, int(kernel), _lib.stream()),
+               "lhn_heatmap_nms")
+    return h
+
+
+def keypoint_pck_accuracy(pred, gt, mask, thr, normalize):
+    """top_down_eval.py:129-165 -> (acc [K] tensor, avg_acc float, cnt int)."""
+    p = _lib.f32c(_dev(pred))
+    g = _lib.f32c(_dev(gt, p.device))
+    m = _dev(mask, p.device).to(torch.uint8).contiguous()
+    nz = _lib.f32c(_dev(normalize, p.device))
+    N, K, _ = p.shape
+    acc = torch.empty(K, dtype=torch.float32, device=p.device)
+    ac = torch.empty(2, dtype=torch.float32, device=p.device)
+    _lib.check(_lib.lib().lhn_pck_accuracy(_lib.ptr(p), _lib.ptr(g), _lib.ptr(m), _lib.ptr(nz), C.c_float(thr),
+                                           _lib.ptr(acc), _lib.ptr(ac), N, K, _lib.stream()), "lhn_pck_accuracy")
+    a = ac.cpu()
+    return acc, float(a[0]), int(a[1])
+
+
+class TopDownDecoder:
+    """utils/post_processing/decoder.py:9-71."""
+
+    def __init__(self, cfg):
+        self.image_size = np.array(cfg.DATASET.image_size)
+        self.heatmap_size = np.array(cfg.DATASET.heatmap_size)
+        self.num_joints = cfg.DATASET.num_joints
+        self.post_process = "unbiased" if cfg.PIPELINE.unbiased_encoding else "default"
+        self.kernel = cfg.PIPELINE.kernel[0]
+        self.use_udp = cfg.PIPELINE.use_udp
+
+    def decode(self, meta, model_output, post_process=None):
+        pp = post_process or self.post_process
+        out = model_output[:, :self.num_joints]
+        center, scale = _dev(meta["center"], out.device).float(), _dev(meta["scale"], out.device).float()
+        hm_preds, preds, maxvals = keypoints_from_heatmaps(out, center, scale, post_process=pp, kernel=self.kernel,
+                                                           use_udp=self.use_udp)
+        n = out.shape[0]
+        all_boxes = torch.zeros((n, 6), dtype=torch.float32, device=out.device)
+        all_boxes[:, 0:2] = center[:, 0:2]
+        all_boxes[:, 2:4] = scale[:, 0:2]
+        all_boxes[:, 4] = torch.prod(scale * 200.0, dim=1)
+        all_boxes[:, 5] = _dev(meta["bbox_score"], out.device).float().reshape(-1)
+        ids = meta["bbox_id"]
+        return dict(preds=torch.cat([preds, maxvals], dim=2), hm_preds=torch.cat([hm_preds * 4, maxvals], dim=2),
+                    boxes=all_boxes, image_paths=meta.get("image_file"),
+                    bbox_ids=ids.tolist() if hasattr(ids, "tolist") else list(ids), output_heatmap=out)

@@ -1,0 +1,108 @@
+"""HIP-backed mirror of loss/loss.py:69-114 (TopdownHeatmapLoss) and loss/heatmapLoss.py:228-265
+(DistanceLoss, L2 / mean / class-balanced).  One pass over (output, target) forward, one backward."""
+import ctypes as C
+
+import torch
+from torch import nn
+
+from . import _lib
+
+
+class DeviceScalar:
+    """A loss value that stays on the GPU.  The reference calls `.item()` every step (loss.py:113), a host
+    sync on the hot loop; this object converts lazily (float(), format, +)."""
+
+    def __init__(self, t):
+        self.t = t.detach()
+
+    def item(self):
+        return float(self.t.item())
+
+    __float__ = item
+
+    def __add__(self, o):
+        return float(self) + float(o)
+
+    __radd__ = __add__
+
+    def __format__(self, spec):
+        return format(float(self), spec)
+
+    def __repr__(self):
+        return f"DeviceScalar({float(self):.6g})"
+
+
+class _BalancedMSE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, output, target, weight, loss_weight, balance):
+        _lib.require_device(output)
+        o, t = _lib.f32c(output), _lib.f32c(target)
+        if t.shape != o.shape:
+            raise _lib.LhnError(f"target shape {tuple(t.shape)} != output shape {tuple(o.shape)}")
+        N, K, H, W = o.shape
+        w = _lib.f32c(weight).reshape(N, K)
+        acc = torch.empty(4, dtype=torch.float64, device=o.device)
+        loss = torch.empty(1, dtype=torch.float32, device=o.device)
+        L = _lib.lib()
+        _lib.check(L.lhn_loss_balanced_mse_fwd(_lib.ptr(o), _lib.ptr(t), _lib.ptr(w), _lib.ptr(acc), _lib.ptr(loss),
+                                               C.c_int64(N * K), C.c_int64(H * W), C.c_float(loss_weight),
+                                               C.c_int(1 if balance else 0), _lib.stream()), "lhn_loss_balanced_mse_fwd")
+        ctx.save_for_backward(o, t, w, acc)
+        ctx.lw, ctx.balance = float(loss_weight), bool(balance)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, dloss):
+        o, t, w, acc = ctx.saved_tensors
+        N, K, H, W = o.shape
+        g = torch.empty_like(o)
+        dl = _lib.f32c(dloss.reshape(1))
+        L = _lib.lib()
+        _lib.check(L.lhn_loss_balanced_mse_bwd(_lib.ptr(o), _lib.ptr(t), _lib.ptr(w), _lib.ptr(acc), _lib.ptr(dl),
+                                               _lib.ptr(g), C.c_int64(N * K), C.c_int64(H * W), C.c_float(ctx.lw),
+                                               C.c_int(1 if ctx.balance else 0), _lib.stream()), "lhn_loss_balanced_mse_bwd")
+        return g, None, None, None, None
+
+
+class DistanceLoss(nn.Module):
+    """heatmapLoss.py:228-265 with loss_type 'L2' and reduction 'mean' (the forms the hot path uses)."""
+
+    def __init__(self, loss_type="L2", reduction="mean", balance=True, value=0.5):
+        super().__init__()
+        if loss_type.lower() != "l2" or reduction != "mean" or value != 0.5:
+            raise _lib.LhnError("DistanceLoss: only loss_type='L2', reduction='mean', value=0.5 are built")
+        self.balance = balance
+
+    def forward(self, output, target, target_weight, loss_weight=1.0):
+        return _BalancedMSE.apply(output, target, target_weight, loss_weight, self.balance)
+
+
+class TopdownHeatmapLoss(nn.Module):
+    """loss.py:69-114.  meta['target'] [N,K,H,W], meta['target_weight'] [N,K,1] may live on CPU or device."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.heatmap_loss = DistanceLoss(loss_type=cfg.LOSS.get("dl_type", "L2"), reduction="mean",
+                                         balance=cfg.MODEL.name != "atthandnet")
+        if cfg.PIPELINE.simdr_split_ratio > 0:
+            raise _lib.LhnError("SimDR loss is outside the hot path (simdr_split_ratio must be 0)")
+        self.loss_weight = cfg.LOSS.loss_weight
+        if cfg.LOSS.auto_weight:
+            raise _lib.LhnError("LOSS.auto_weight is outside the hot path")
+
+    def forward(self, output, meta):
+        device = output.device
+        target = meta["target"].to(device, non_blocking=True)
+        weight = meta["target_weight"].to(device, non_blocking=True)
+        loss = self.heatmap_loss(output, target, weight, float(self.loss_weight[0]))
+        return loss, {"heatmap": DeviceScalar(loss)}
+
+
+topdownheatmaploss = TopdownHeatmapLoss
+
+
+def get_loss(cfg):
+    name = cfg.LOSS.type.lower()
+    if name != "topdownheatmaploss":
+        raise _lib.LhnError(f"loss <{cfg.LOSS.type}> is outside the hot path")
+    return TopdownHeatmapLoss(cfg)

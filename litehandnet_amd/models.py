@@ -1,0 +1,14 @@
+"""Model registry -- models/__init__.py:11-26 restricted to the hot path."""
+from . import _lib
+
+__all__ = ["litehandnet", "litehourglass"]
+
+
+def get_model(cfg):
+    name = cfg.MODEL.name
+    assert name in __all__, f"model <{name}> should be one of {__all__}"
+    if name == "litehourglass":
+        from .litehourglass import LiteHandNet
+        return LiteHandNet(cfg)
+    from .liteHandNet import LiteHandNet
+    return LiteHandNet(cfg)

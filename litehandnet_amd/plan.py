@@ -1,0 +1,468 @@
+"""Static execution plan for the litehandnet backbone on one MI355X.
+
+The reference runs ~330 unfused torch ops per forward.  Here the Python
+mirror of the module tree (`liteHandNet.py`, `litehourglass.py`, ...) is walked ONCE per input
+shape by a `PlanBuilder`; the result is a flat list of kernel calls over one workspace arena that
+`lhn_plan_run` (csrc/lhn_plan.cpp) enqueues with a single C call per forward / backward.
+
+Conventions
+  * activations: NHWC fp32 buffers in the arena, each with a per-channel table (scale, shift,
+    slope) and optionally a per-(n,c) gate; a conv writes its RAW output plus BatchNorm statistics,
+    `FINALIZE` turns the statistics into the table, consumers apply it on load (no BN/act pass).
+  * cat / chunk / channel slices are (buffer, coff, C) views -- producers write into slices.
+  * gradients: one grad buffer per activation buffer holding d(loss)/d(consumed value); the
+    backward list is generated here by walking the forward records in reverse and tracking which
+    channel ranges have been written (store) or must be accumulated.
+"""
+import ctypes as C
+from dataclasses import dataclass, field
+
+import torch
+
+from . import _lib
+from ._lib import Buf, Op
+
+# op kinds (must match csrc/lhn_plan.cpp)
+STEM, PW, DW, KXK, FINALIZE, EW, MAXPOOL, AVGPOOL, CA_MLP, TABLE_FILL, MEMSET = range(1, 12)
+STEM_BWD, PW_BWD, DW_BWD, KXK_BWD, BN_BWD, EW_BWD, MAXPOOL_BWD, AVGPOOL_BWD, GATE_REDUCE, CA_MLP_BWD = range(101, 111)
+
+ALIGN = 256
+
+
+def _al(n):
+    return (n + ALIGN - 1) // ALIGN * ALIGN
+
+
+@dataclass
+class TRef:
+    """A (buffer, channel-slice) view.  buf == -1 is the NCHW input image."""
+    buf: int
+    coff: int
+    C: int
+    H: int
+    W: int
+
+
+@dataclass
+class _BufRec:
+    H: int
+    W: int
+    C: int
+    gate: bool = False
+    coef: bool = False
+    dpool: bool = False
+    off: dict = field(default_factory=dict)
+
+
+class _Arena:
+    def __init__(self):
+        self.size = 0
+
+    def take(self, nbytes):
+        off = self.size
+        self.size += _al(nbytes)
+        return off
+
+
+class PlanBuilder:
+    def __init__(self, N, state_index, image_hw=None, with_backward=True, p_drop=0.0):
+        self.N = N
+        self.state_index = state_index      # id(tensor) -> index in the params array
+        self.bufs = []
+        self.recs = []                      # forward records (python dicts)
+        self.with_backward = with_backward
+        self.p_drop = p_drop
+        self.image_hw = image_hw
+        # arenas: zf = zeroed at the start of every forward, zb = zeroed at the start of every backward
+        self.ar = {"zf": _Arena(), "zb": _Arena(), "mask": _Arena(), "misc": _Arena()}
+        self.out_ref = None
+        self.nchw_out_C = None
+        self.in_ref = None
+
+    # ------------------------------------------------------------------ declarations
+    def image(self):
+        H, W = self.image_hw
+        return TRef(-1, 0, 3, H, W)
+
+    def buffer(self, H, W, C):
+        self.bufs.append(_BufRec(H, W, C))
+        return len(self.bufs) - 1
+
+    def new(self, H, W, C):
+        return TRef(self.buffer(H, W, C), 0, C, H, W)
+
+    def input_tensor(self, C, H, W):
+        self.in_ref = self.new(H, W, C)
+        return self.in_ref
+
+    def slice(self, x, coff, C):
+        assert 0 <= coff and coff + C <= x.C and coff % 4 == 0 and C % 4 == 0, (coff, C, x)
+        return TRef(x.buf, x.coff + coff, C, x.H, x.W)
+
+    def _ws(self, arena, nbytes):
+        return (arena, self.ar[arena].take(nbytes))
+
+    def _p(self, t):
+        return -1 if t is None else self.state_index[id(t)]
+
+    # ------------------------------------------------------------------ forward emitters
+    def conv(self, x, conv, bn=None, slope=1.0, out=None, nchw_out=False):
+        """conv (+ train/eval BatchNorm + leaky slope as a pending transform).  Returns the output view."""
+        cout, cin_g, kh, kw = conv.weight.shape
+        s, p, d, g = conv.stride[0], conv.padding[0], conv.dilation[0], conv.groups
+        Ho = (x.H + 2 * p - d * (kh - 1) - 1) // s + 1
+        Wo = (x.W + 2 * p - d * (kw - 1) - 1) // s + 1
+        if x.buf == -1:
+            kind = STEM
+        elif g == cout and cin_g == 1 and x.C == cout:
+            kind = DW
+        elif kh == 1 and g == 1:
+            kind = PW
+            assert p == 0
+        elif kh == 3 and g == 1 and p == 1 and d == 1:
+            kind = KXK
+        else:
+            raise _lib.LhnError(f"unsupported convolution {tuple(conv.weight.shape)} groups={g}")
+        if kind != STEM and kind != DW:
+            assert cin_g == x.C, (cin_g, x.C)
+        if nchw_out:
+            assert kind == PW and bn is None and out is None
+            out = TRef(-2, 0, cout, Ho, Wo)
+            self.nchw_out_C = cout
+        elif out is None:
+            out = self.new(Ho, Wo, cout)
+        assert (out.H, out.W, out.C) == (Ho, Wo, cout), (out, Ho, Wo, cout)
+        rec = dict(op=kind, x=x, out=out, conv=conv, bn=bn, slope=float(slope), k=kh, stride=s, pad=p, dil=d,
+                   nchw=nchw_out)
+        if bn is not None:
+            rec["stats"] = self._ws("zf", 2 * cout * 8)
+            rec["save"] = self._ws("misc", 2 * cout * 4)
+            if self.with_backward:
+                rec["sums"] = self._ws("zb", 2 * cout * 8)
+                self.bufs[out.buf].coef = True
+        self.recs.append(rec)
+        return out
+
+    def ew(self, srcs, out_slope=1.0, out=None):
+        """out = lrelu_{out_slope}(sum of sources); smaller sources are nearest-upsampled.  Plain output."""
+        assert 1 <= len(srcs) <= 3
+        H, W = max(s.H for s in srcs), max(s.W for s in srcs)
+        if out is None:
+            out = self.new(H, W, srcs[0].C)
+        assert all(s.C == out.C for s in srcs)
+        self.recs.append(dict(op=EW, srcs=list(srcs), out=out, slope=float(out_slope)))
+        return out
+
+    def maxpool(self, x, out=None):
+        Ho, Wo = (x.H + 1) // 2, (x.W + 1) // 2
+        if out is None:
+            out = self.new(Ho, Wo, x.C)
+        self.recs.append(dict(op=MAXPOOL, x=x, out=out))
+        return out
+
+    def avgpool(self, x, OH, OW):
+        """adaptive_avg_pool2d of the consumed value -> a plain [N,OH,OW,C] buffer."""
+        out = self.new(OH, OW, x.C)
+        self.recs.append(dict(op=AVGPOOL, x=x, out=out, OH=OH, OW=OW, ca=False))
+        return out
+
+    def channel_attention(self, y, ca):
+        """common.py:40-66 on the WHOLE buffer behind `y`: sets the buffer's gate.  Returns y."""
+        b = self.bufs[y.buf]
+        assert y.coff == 0 and y.C == b.C, "channel attention gates a whole buffer"
+        assert not b.gate, "buffer is already gated"
+        Cc = y.C
+        pooled = self._ws("misc", self.N * 9 * Cc * 4)
+        save = self._ws("misc", (5 * self.N * Cc + self.N * (Cc // 2) + 2 * Cc) * 4)
+        mask = self._ws("mask", self.N * Cc * 4) if self.p_drop > 0 else None
+        rec = dict(op=CA_MLP, y=y, ca=ca, pooled=pooled, save=save, mask=mask)
+        if self.with_backward:
+            rec["dgate"] = self._ws("misc", self.N * Cc * 4)
+            b.dpool = True
+        self.recs.append(rec)
+        b.gate = True
+        return y
+
+    def set_output(self, y):
+        """Generic (block-level) output: materialise the consumed value into a plain buffer."""
+        self.out_ref = self.ew([y])
+        return self.out_ref
+
+    # ------------------------------------------------------------------ lowering
+    def _layout(self):
+        N = self.N
+        base = 0
+        self.arena_base = {}
+        for name in ("zf", "zb", "mask", "misc"):
+            self.arena_base[name] = base
+            base += _al(self.ar[name].size)
+        self.table_base = base
+        for b in self.bufs:
+            b.off["table"] = base
+            base += _al(3 * b.C * 4)
+        self.table_end = base
+        for b in self.bufs:
+            if b.gate:
+                b.off["gate"] = base
+                base += _al(N * b.C * 4)
+            if self.with_backward and b.coef:
+                b.off["coef"] = base
+                base += _al(3 * b.C * 4)
+            if self.with_backward and b.dpool:
+                b.off["dpool"] = base
+                base += _al(N * 9 * b.C * 4)
+        for b in self.bufs:
+            b.off["data"] = base
+            base += _al(N * b.H * b.W * b.C * 4)
+        self.act_bytes = base
+        if self.with_backward:
+            for b in self.bufs:
+                b.off["grad"] = base
+                base += _al(N * b.H * b.W * b.C * 4)
+        self.total_bytes = base
+
+    def _abs(self, ref):
+        return -1 if ref is None else self.arena_base[ref[0]] + ref[1]
+
+    @staticmethod
+    def _mk(kind, ins=(), out=None, p=(), ws=(), i=(), f=()):
+        o = Op()
+        o.kind = kind
+        for k in range(3):
+            o.in_buf[k] = -1
+        for k, t in enumerate(ins):
+            o.in_buf[k], o.in_coff[k], o.in_C[k] = t.buf, t.coff, t.C
+        if out is not None:
+            o.out_buf, o.out_coff, o.out_C = out.buf, out.coff, out.C
+        else:
+            o.out_buf = -1
+        for k in range(12):
+            o.p[k] = p[k] if k < len(p) else -1
+        for k in range(6):
+            o.ws[k] = ws[k] if k < len(ws) else -1
+        for k in range(8):
+            o.i[k] = i[k] if k < len(i) else 0
+        for k in range(4):
+            o.f[k] = f[k] if k < len(f) else 0.0
+        return o
+
+    def _grad_mode(self, written, t):
+        """1 = store, 2 = accumulate for a write of d(value) into view t; updates the tracker."""
+        ranges = written.setdefault(t.buf, [])
+        lo, hi = t.coff, t.coff + t.C
+        overlap = [r for r in ranges if r[0] < hi and lo < r[1]]
+        if not overlap:
+            ranges.append((lo, hi))
+            return 1
+        covered = sorted(overlap)
+        cur = lo
+        for a, b in covered:
+            if a > cur:
+                break
+            cur = max(cur, b)
+        if cur >= hi:
+            return 2
+        # partial overlap: fall back to a zeroed gradient buffer with accumulate-only writes
+        self._needs_zero_grad.add(t.buf)
+        ranges.append((lo, hi))
+        return 2
+
+    def finalize(self):
+        self._layout()
+        N = self.N
+        fwd, bwd = [], []
+        mk = self._mk
+        # ---------------- forward
+        if self.ar["zf"].size:
+            fwd.append(mk(MEMSET, ws=(self.arena_base["zf"], self.ar["zf"].size)))
+        for r in self.recs:
+            k = r["op"]
+            if k in (STEM, PW, DW, KXK):
+                conv, bn, x, out = r["conv"], r["bn"], r["x"], r["out"]
+                stats = self._abs(r.get("stats"))
+                pw = self._p(conv.weight)
+                if k == STEM:
+                    fwd.append(mk(STEM, out=out, p=(pw,), ws=(stats,), i=(r["k"], r["stride"], r["pad"], x.H, x.W)))
+                elif k == PW:
+                    o = TRef(-1, 0, out.C, out.H, out.W) if r["nchw"] else out
+                    fwd.append(mk(PW, ins=(x,), out=o, p=(pw, self._p(conv.bias)), ws=(stats,),
+                                  i=(r["stride"], 1 if r["nchw"] else 0)))
+                elif k == DW:
+                    fwd.append(mk(DW, ins=(x,), out=out, p=(pw,), ws=(stats,), i=(r["k"], r["stride"], r["pad"], r["dil"])))
+                else:
+                    fwd.append(mk(KXK, ins=(x,), out=out, p=(pw,), ws=(stats,), i=(r["stride"],)))
+                if bn is not None:
+                    fwd.append(mk(FINALIZE, out=out,
+                                  p=(self._p(bn.weight), self._p(bn.bias), self._p(bn.running_mean),
+                                     self._p(bn.running_var), self._p(bn.num_batches_tracked)),
+                                  ws=(stats, self._abs(r["save"])), f=(bn.eps, bn.momentum, r["slope"])))
+            elif k == EW:
+                fwd.append(mk(EW, ins=r["srcs"], out=r["out"], i=(len(r["srcs"]),), f=(r["slope"],)))
+            elif k == MAXPOOL:
+                fwd.append(mk(MAXPOOL, ins=(r["x"],), out=r["out"]))
+            elif k == AVGPOOL:
+                fwd.append(mk(AVGPOOL, ins=(r["x"],), ws=(self.bufs[r["out"].buf].off["data"],), i=(r["OH"], r["OW"], 0)))
+            elif k == CA_MLP:
+                y, ca = r["y"], r["ca"]
+                fwd.append(mk(AVGPOOL, ins=(y,), ws=(self._abs(r["pooled"]),), i=(3, 3, 1)))
+                bn = ca.conv3x3.bn
+                fwd.append(mk(CA_MLP, out=y,
+                              p=(self._p(ca.conv3x3.conv.weight), self._p(bn.weight), self._p(bn.bias),
+                                 self._p(bn.running_mean), self._p(bn.running_var), self._p(bn.num_batches_tracked),
+                                 self._p(ca.conv1x1[1].weight), self._p(ca.conv1x1[1].bias),
+                                 self._p(ca.conv1x1[3].weight), self._p(ca.conv1x1[3].bias)),
+                              ws=(self._abs(r["pooled"]), self._abs(r["save"]), self._abs(r["mask"])),
+                              f=(bn.eps, bn.momentum)))
+            else:
+                raise AssertionError(k)
+        # ---------------- backward
+        if self.with_backward:
+            written = {}
+            self._needs_zero_grad = set()
+            body = []
+            for r in reversed(self.recs):
+                k = r["op"]
+                if k in (STEM, PW, DW, KXK):
+                    conv, bn, x, out = r["conv"], r["bn"], r["x"], r["out"]
+                    pw = self._p(conv.weight)
+                    use_coef = 1 if bn is not None else 0
+                    if bn is not None:
+                        body.append(mk(BN_BWD, out=out, p=(self._p(bn.weight), self._p(bn.weight), self._p(bn.bias)),
+                                       ws=(self._abs(r["sums"]), self._abs(r["save"]))))
+                    if k == STEM:
+                        body.append(mk(STEM_BWD, out=out, p=(pw, pw), i=(r["k"], r["stride"], r["pad"], x.H, x.W, use_coef)))
+                        continue
+                    need_dx = x.buf != self._no_grad_buf
+                    mode = self._grad_mode(written, x) if need_dx else 0
+                    if k == PW:
+                        if r["stride"] != 1 and mode == 1:   # strided dgrad touches a subset of pixels
+                            self._needs_zero_grad.add(x.buf)
+                            mode = 2
+                        o = TRef(-1, 0, out.C, out.H, out.W) if r["nchw"] else out
+                        body.append(mk(PW_BWD, ins=(x,), out=o, p=(pw, pw, self._p(conv.bias)),
+                                       i=(r["stride"], 1 if r["nchw"] else 0, mode, 0, 0, use_coef)))
+                    elif k == DW:
+                        body.append(mk(DW_BWD, ins=(x,), out=out, p=(pw, pw),
+                                       i=(r["k"], r["stride"], r["pad"], r["dil"], mode, use_coef)))
+                    else:
+                        body.append(mk(KXK_BWD, ins=(x,), out=out, p=(pw, pw), i=(r["stride"], 0, mode, 0, 0, use_coef)))
+                elif k == EW:
+                    for s in r["srcs"]:
+                        if s.buf == self._no_grad_buf:
+                            continue
+                        mode = self._grad_mode(written, s)
+                        body.append(mk(EW_BWD, ins=(s,), out=r["out"], i=(1 if mode == 2 else 0,), f=(r["slope"],)))
+                elif k == MAXPOOL:
+                    mode = self._grad_mode(written, r["x"])
+                    body.append(mk(MAXPOOL_BWD, ins=(r["x"],), out=r["out"], i=(1 if mode == 2 else 0,)))
+                elif k == AVGPOOL:
+                    mode = self._grad_mode(written, r["x"])
+                    body.append(mk(AVGPOOL_BWD, ins=(r["x"],), ws=(self.bufs[r["out"].buf].off["grad"],),
+                                   i=(r["OH"], r["OW"], 1 if mode == 2 else 0)))
+                elif k == CA_MLP:
+                    y, ca = r["y"], r["ca"]
+                    bn = ca.conv3x3.bn
+                    body.append(mk(GATE_REDUCE, out=y, ws=(-1, -1, -1, self._abs(r["dgate"]))))
+                    body.append(mk(CA_MLP_BWD, out=y,
+                                   p=(self._p(ca.conv3x3.conv.weight), self._p(bn.weight), self._p(ca.conv1x1[1].weight),
+                                      self._p(ca.conv1x1[3].weight),
+                                      self._p(ca.conv3x3.conv.weight), self._p(bn.weight), self._p(bn.bias),
+                                      self._p(ca.conv1x1[1].weight), self._p(ca.conv1x1[1].bias),
+                                      self._p(ca.conv1x1[3].weight), self._p(ca.conv1x1[3].bias)),
+                                   ws=(self._abs(r["pooled"]), self._abs(r["save"]), self._abs(r["mask"]),
+                                       self._abs(r["dgate"]))))
+            if self.ar["zb"].size:
+                bwd.append(mk(MEMSET, ws=(self.arena_base["zb"], self.ar["zb"].size)))
+            for b in sorted(self._needs_zero_grad):
+                rec = self.bufs[b]
+                bwd.append(mk(MEMSET, ws=(rec.off["grad"], N * rec.H * rec.W * rec.C * 4)))
+            if self._needs_zero_grad:
+                # every write into a zero-initialised gradient buffer must accumulate
+                for o in body:
+                    if o.kind in (PW_BWD, KXK_BWD) and o.in_buf[0] in self._needs_zero_grad and o.i[2]:
+                        o.i[2] = 2
+                    elif o.kind == DW_BWD and o.in_buf[0] in self._needs_zero_grad and o.i[4]:
+                        o.i[4] = 2
+                    elif o.kind in (EW_BWD, MAXPOOL_BWD) and o.in_buf[0] in self._needs_zero_grad:
+                        o.i[0] = 1
+                    elif o.kind == AVGPOOL_BWD and o.in_buf[0] in self._needs_zero_grad:
+                        o.i[2] = 1
+            bwd += body
+        # ---------------- C arrays
+        cb = (Buf * len(self.bufs))()
+        for j, b in enumerate(self.bufs):
+            cb[j].data_off = b.off["data"]
+            cb[j].table_off = b.off["table"]
+            cb[j].gate_off = b.off.get("gate", -1)
+            cb[j].grad_off = b.off.get("grad", -1)
+            cb[j].dpool_off = b.off.get("dpool", -1)
+            cb[j].coef_off = b.off.get("coef", -1)
+            cb[j].N, cb[j].H, cb[j].W, cb[j].C = N, b.H, b.W, b.C
+        cf = (Op * len(fwd))(*fwd)
+        cbw = (Op * max(1, len(bwd)))(*bwd) if bwd else None
+        return cb, cf, cbw, len(fwd), len(bwd)
+
+    _no_grad_buf = -1   # the image never needs a gradient
+
+
+class CompiledPlan:
+    """Owns the C plan + the workspace arena (a torch uint8 tensor) for one (module, input shape)."""
+
+    def __init__(self, pb: PlanBuilder, state_tensors, device):
+        self.pb = pb
+        cb, cf, cbw, nf, nb = pb.finalize()
+        self._keep = (cb, cf, cbw)
+        L = _lib.lib()
+        self.handle = L.lhn_plan_create(cb, len(pb.bufs), cf, nf, cbw, nb)
+        if not self.handle:
+            raise _lib.LhnError("lhn_plan_create: " + L.lhn_last_error().decode())
+        self.n_fwd, self.n_bwd = nf, nb
+        self.ws = torch.empty(pb.total_bytes, dtype=torch.uint8, device=device)
+        # tables start as the identity transform (scale 1, shift 0, slope 1); FINALIZE overwrites BN slices
+        for b in pb.bufs:
+            t = self.view_f32(b.off["table"], 3 * b.C).view(3, b.C)
+            t[0].fill_(1.0)
+            t[1].zero_()
+            t[2].fill_(1.0)
+        self.state_tensors = state_tensors
+        self._params = (C.c_void_p * len(state_tensors))()
+        self._grads = (C.c_void_p * len(state_tensors))()
+        self._io = (C.c_void_p * 2)()
+        self.mask_view = None
+        if pb.ar["mask"].size:
+            self.mask_view = self.view_f32(pb.arena_base["mask"], pb.ar["mask"].size // 4)
+
+    def view_f32(self, byte_off, numel):
+        return self.ws[byte_off:byte_off + numel * 4].view(torch.float32)
+
+    def buf_data(self, ref, grad=False):
+        b = self.pb.bufs[ref.buf]
+        v = self.view_f32(b.off["grad" if grad else "data"], self.pb.N * b.H * b.W * b.C)
+        return v.view(self.pb.N, b.H, b.W, b.C)[..., ref.coff:ref.coff + ref.C]
+
+    def refresh_params(self):
+        for j, t in enumerate(self.state_tensors):
+            self._params[j] = t.data_ptr()
+
+    def set_grads(self, grad_tensors):
+        for j, g in enumerate(grad_tensors):
+            self._grads[j] = 0 if g is None else g.data_ptr()
+
+    def run(self, phase, io0, io1, training):
+        self._io[0] = 0 if io0 is None else io0.data_ptr()
+        self._io[1] = 0 if io1 is None else io1.data_ptr()
+        if phase == 0 and training and self.mask_view is not None:
+            keep = 1.0 - self.pb.p_drop
+            self.mask_view.bernoulli_(keep).mul_(1.0 / keep)
+        L = _lib.lib()
+        rc = L.lhn_plan_run(C.c_void_p(self.handle), phase, _lib.ptr(self.ws), self._params, self._grads, self._io,
+                            1 if training else 0, _lib.stream())
+        _lib.check(rc, "lhn_plan_run")
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                _lib.lib().lhn_plan_destroy(C.c_void_p(self.handle))
+                self.handle = None
+        except Exception:
+            pass

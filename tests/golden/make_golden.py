@@ -137,6 +137,8 @@ def main():
     rB2, oB2 = ref_b.LiteHandNet(cfgB2), torch_ref.get_model(cfgB2)
     _model_case(rB2, oB2, 2, 64, 7, "Bca_64", out)
     for tag, rm, om in (("B", refB, oraB), ("A", refA, oraA)):
+        sd = synth.synth_state_dict(rm, {"B": 5, "A": 6}[tag])     # fresh running statistics
+        rm.load_state_dict(sd); om.load_state_dict(sd)
         rm.eval(); om.eval()
         x = synth.synth_images(2, 64, 11)
         with torch.no_grad():

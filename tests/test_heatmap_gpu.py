@@ -1,0 +1,134 @@
+"""GPU parity: heatmap encode / decode / loss kernels (through the C ABI) against the numpy oracle and the
+committed golden vectors.  Integer results (argmax coordinates, weights, counts) must be bit-exact."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import heatmap_np as onp
+from oracle import synth, torch_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def _ulp_close(a, b, ulps=2):
+    a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
+    return np.all(np.abs(a - b) <= ulps * np.spacing(np.maximum(np.abs(a), np.abs(b))))
+
+
+def test_encode_golden(dev, golden_dir):
+    from litehandnet_amd import heatmap
+    g = np.load(os.path.join(golden_dir, "encode.npz"))
+    for unb, tag in ((True, "unbiased"), (False, "biased")):
+        t, w = heatmap.generate_target_batch(g["joints"], g["visible"], [256, 256], [64, 64], 2, unb)
+        t, w = t.cpu().numpy(), w.cpu().numpy()
+        flat = t.reshape(t.shape[0], 21, -1)
+        assert np.array_equal(w, g[f"{tag}_weight"])                      # visibility / in-bounds test: exact
+        assert np.array_equal(flat.argmax(2), g[f"{tag}_argmax"])         # INT: exact
+        assert _ulp_close(flat.max(2), g[f"{tag}_max"], 1)
+        assert _ulp_close(t[:2], g[f"{tag}_full_first2"], 1 if unb else 2)   # fp64 exp rounded / fp32 expf
+        assert np.allclose(flat.astype(np.float64).sum(2), g[f"{tag}_sum"], rtol=1e-6)
+
+
+def test_encode_vs_oracle_full_batch(dev):
+    from litehandnet_amd import heatmap
+    j = synth.synth_joints(64, 21, 256, 3, margin=0.2)
+    v = np.ones_like(j)
+    v[5, :, 0] = 0
+    t, w = heatmap.generate_target_batch(j, v, [256, 256], [64, 64], 2, True)
+    ref = [onp.msra_generate_target(a, b, [256, 256], [64, 64]) for a, b in zip(j, v)]
+    rt, rw = np.stack([r[0] for r in ref]), np.stack([r[1] for r in ref])
+    assert np.array_equal(w.cpu().numpy(), rw)
+    assert _ulp_close(t.cpu().numpy(), rt, 1)
+    # round trip at full size: decode(encode(j)) == round(j / 4) wherever the peak is inside the map
+    p, mv = heatmap._get_max_preds(t)
+    p = p.cpu().numpy()
+    exp = np.floor(j[..., :2] / 4 + 0.5)
+    inside = (rw[..., 0] > 0) & (exp[..., 0] >= 0) & (exp[..., 0] < 64) & (exp[..., 1] >= 0) & (exp[..., 1] < 64)
+    frac = np.abs((j[..., :2] / 4) % 1 - 0.5).min(-1) > 1e-3      # away from exact ties
+    sel = inside & frac
+    assert np.array_equal(p[sel], exp[sel])
+
+
+def test_call_contract(dev):
+    from litehandnet_amd import heatmap
+    gt = heatmap.TopDownGenerateTarget(sigma=2, unbiased_encoding=True)
+    j = synth.synth_joints(1, 21, 256, 5)[0]
+    res = gt(dict(joints_3d=j, joints_3d_visible=np.ones_like(j),
+                  ann_info=dict(num_joints=21, image_size=np.array([256, 256]), heatmap_size=[64, 64],
+                                joint_weights=None, use_different_joint_weights=False)))
+    assert res["target"].shape == (21, 64, 64) and res["target_weight"].shape == (21, 1)
+
+
+def test_decode_golden(dev, golden_dir):
+    from litehandnet_amd import heatmap
+    g = np.load(os.path.join(golden_dir, "decode.npz"))
+    p, mv = heatmap._get_max_preds(g["heatmaps"])
+    assert np.array_equal(p.cpu().numpy(), g["argmax_xy"])                # INT coordinates: bit-exact
+    assert np.array_equal(mv.cpu().numpy(), g["maxvals"])
+    hp, pr, mv2 = heatmap.keypoints_from_heatmaps(g["heatmaps"], g["center"], g["scale"], post_process="default")
+    assert np.array_equal(hp.cpu().numpy(), g["hm_preds"])               # +-0.25 shift: exact
+    assert np.array_equal(pr.cpu().numpy(), g["preds"])                  # fp32 back-transform, same op order: exact
+    r = heatmap.refine_preds(g["heatmaps"], g["argmax_xy"], "default")
+    assert np.array_equal(r.cpu().numpy(), g["hm_preds"])
+    t = heatmap.transform_preds(g["hm_preds"], g["center"], g["scale"], [64, 64])
+    assert np.array_equal(t.cpu().numpy(), g["preds"])
+    acc, pck, cnt = heatmap.keypoint_pck_accuracy(g["preds"], g["gt"], g["mask"], 0.2, g["normalize"])
+    assert np.allclose(acc.cpu().numpy(), g["pck_acc"], atol=1e-7) and abs(pck - float(g["pck"])) < 1e-6
+    assert cnt == int(g["pck_cnt"])
+
+
+def test_decode_legacy_offset_and_nms(dev):
+    from litehandnet_amd import heatmap
+    r = np.random.Generator(np.random.PCG64(5))
+    hm = r.random((3, 21, 64, 64)).astype(np.float32)
+    p, _ = onp.get_max_preds(hm)
+    got = heatmap.refine_preds(hm, p, "offset").cpu().numpy()
+    assert np.array_equal(got, onp.refine_offset_legacy(hm, p))
+    assert np.array_equal(heatmap.heatmap_nms(hm, 11).cpu().numpy(), onp.heatmap_nms(hm, 11))
+
+
+def test_argmax_full_size_properties(dev):
+    """bs64 x 21 x 64 x 64: permutation consistency + agreement with torch's argmax on ties-free data."""
+    from litehandnet_amd import heatmap
+    g = torch.Generator(device="cpu").manual_seed(0)
+    hm = torch.randn(64, 21, 64, 64, generator=g)
+    p, mv = heatmap._get_max_preds(hm.cuda())
+    idx = hm.view(64, 21, -1).argmax(2)
+    assert torch.equal(p[..., 0].cpu(), (idx % 64).float()) and torch.equal(p[..., 1].cpu(), (idx // 64).float())
+    assert torch.equal(mv.cpu().view(64, 21), hm.view(64, 21, -1).max(2).values)
+
+
+def test_loss_golden_and_oracle(dev, golden_dir):
+    from litehandnet_amd.config import litehandnet_cfg
+    from litehandnet_amd.loss import TopdownHeatmapLoss
+    g = np.load(os.path.join(golden_dir, "loss.npz"))
+    r = np.random.Generator(np.random.PCG64(int(g["seed"])))
+    o_np = r.standard_normal((2, 21, 64, 64)).astype(np.float32)
+    tw = [onp.msra_generate_target(a, v, [256, 256], [64, 64]) for a, v in zip(g["joints"], g["visible"])]
+    t = torch.from_numpy(np.stack([a for a, _ in tw]))
+    w = torch.from_numpy(np.stack([b for _, b in tw]))
+    o = torch.from_numpy(o_np).cuda().requires_grad_()
+    crit = TopdownHeatmapLoss(litehandnet_cfg("A"))
+    loss, d = crit(o, {"target": t, "target_weight": w})
+    assert abs(float(loss) - float(g["loss"])) <= 2e-6 * abs(float(g["loss"]))     # fp32 tolerance (sum order)
+    assert abs(float(d["heatmap"]) - float(g["loss"])) <= 2e-6 * abs(float(g["loss"]))
+    loss.backward()
+    gr = o.grad.cpu().numpy()
+    assert np.allclose(gr[:, ::5, ::16, ::16], g["grad_sample"], rtol=2e-6, atol=1e-12)
+    assert abs(np.abs(gr).sum() - float(g["grad_abs_sum"])) <= 1e-5 * float(g["grad_abs_sum"])
+    # full size vs oracle, incl. invisible joints
+    o2 = torch.randn(64, 21, 64, 64)
+    j = synth.synth_joints(64, 21, 256, 2)
+    tt = torch.from_numpy(np.stack([onp.msra_generate_target(a, np.ones_like(a), [256, 256], [64, 64])[0] for a in j]))
+    ww = torch.ones(64, 21, 1)
+    ww[::7, 3] = 0
+    oc = o2.clone().requires_grad_()
+    lref = torch_ref.distance_loss(oc, tt, ww)
+    lref.backward()
+    og = o2.cuda().requires_grad_()
+    lg, _ = crit(og, {"target": tt, "target_weight": ww})
+    lg.backward()
+    assert abs(float(lg) - float(lref)) <= 5e-6 * abs(float(lref))
+    assert torch.allclose(og.grad.cpu(), oc.grad, rtol=1e-5, atol=1e-12)

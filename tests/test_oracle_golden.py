@@ -1,0 +1,117 @@
+"""CPU: the oracle restatement against the committed golden vectors (generated from the real reference
+by tests/golden/make_golden.py).  Nothing here touches /root/reference."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from litehandnet_amd.config import litehandnet_cfg
+from oracle import heatmap_np as onp
+from oracle import synth, torch_ref
+
+
+def _no_dropout(m):
+    for x in m.modules():
+        if isinstance(x, torch.nn.Dropout2d):
+            x.p = 0.0
+
+
+def test_known_answers(golden_dir):
+    ka = json.load(open(os.path.join(golden_dir, "known_answers.json")))
+    a = torch_ref.get_model(litehandnet_cfg("A"))
+    b = torch_ref.get_model(litehandnet_cfg("B"))
+    # 2,272,981 is the reference's own published count (test_models_performance.ipynb:247)
+    assert sum(p.numel() for p in a.parameters()) == ka["litehandnet_A_params"] == 2272981
+    assert sum(p.numel() for p in b.parameters()) == ka["litehourglass_B_params"]
+    assert len(a.state_dict()) == ka["A_keys"] and len(b.state_dict()) == ka["B_keys"]
+
+
+def _run_case(golden_dir, tag, variant, **kw):
+    g = np.load(os.path.join(golden_dir, f"model_{tag}.npz"))
+    cfg = litehandnet_cfg(variant, **kw)
+    m = torch_ref.get_model(cfg)
+    n, size, seed = int(g["n"]), int(g["size"]), int(g["seed"])
+    m.load_state_dict(synth.synth_state_dict(m, seed))
+    m.train()
+    _no_dropout(m)
+    x = synth.synth_images(n, size, seed)
+    y = m(x)
+    assert np.abs(y.detach().numpy() - g["heatmap"]).max() <= 1e-5 * np.abs(g["heatmap"]).max()
+    hs = size // 4
+    j = synth.synth_joints(n, 21, size, seed + 1)
+    tgt = np.stack([onp.msra_generate_target(a, np.ones_like(a), [size, size], [hs, hs])[0] for a in j])
+    meta = {"target": torch.from_numpy(tgt), "target_weight": torch.from_numpy(g["target_weight"])}
+    loss, _ = torch_ref.TopdownHeatmapLoss(cfg)(y, meta)
+    assert abs(float(loss) - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
+    loss.backward()
+    gn = dict(zip(g["grad_keys"].tolist(), g["grad_norms"].tolist()))
+    for k, p in m.named_parameters():
+        assert abs(float(p.grad.norm()) - gn[k]) <= 2e-4 * (gn[k] + 1e-6), k
+    bk = str(g["bn_key"])
+    assert np.allclose(m.state_dict()[bk].numpy(), g["bn_running_mean"], rtol=1e-5, atol=1e-6)
+
+
+def test_model_B_64(golden_dir):
+    _run_case(golden_dir, "B_64", "B")
+
+
+def test_model_A_64(golden_dir):
+    _run_case(golden_dir, "A_64", "A")
+
+
+def test_model_Bca_64(golden_dir):
+    _run_case(golden_dir, "Bca_64", "B", rbu_ca="ca")
+
+
+def test_eval_mode(golden_dir):
+    for tag, variant, wseed in (("B", "B", 5), ("A", "A", 6)):
+        g = np.load(os.path.join(golden_dir, f"model_{tag}_64_eval.npz"))
+        m = torch_ref.get_model(litehandnet_cfg(variant))
+        m.load_state_dict(synth.synth_state_dict(m, wseed))
+        m.eval()
+        with torch.no_grad():
+            y = m(synth.synth_images(2, 64, int(g["seed"]))).numpy()
+        assert np.abs(y - g["heatmap"]).max() <= 1e-5 * np.abs(g["heatmap"]).max()
+
+
+def test_encode(golden_dir):
+    g = np.load(os.path.join(golden_dir, "encode.npz"))
+    for unb, tag in ((True, "unbiased"), (False, "biased")):
+        for i, (j, v) in enumerate(zip(g["joints"], g["visible"])):
+            t, w = onp.msra_generate_target(j, v, [256, 256], [64, 64], 2, unb)
+            flat = t.reshape(21, -1)
+            assert np.array_equal(w, g[f"{tag}_weight"][i])
+            assert np.array_equal(flat.argmax(1), g[f"{tag}_argmax"][i])
+            assert np.array_equal(flat.max(1), g[f"{tag}_max"][i])
+            if i < 2:
+                assert np.array_equal(t, g[f"{tag}_full_first2"][i])
+
+
+def test_decode_and_metrics(golden_dir):
+    g = np.load(os.path.join(golden_dir, "decode.npz"))
+    p0, mv = onp.get_max_preds(g["heatmaps"])
+    assert np.array_equal(p0, g["argmax_xy"]) and np.array_equal(mv, g["maxvals"])
+    hp, pr, _ = onp.keypoints_from_heatmaps(g["heatmaps"], g["center"], g["scale"], "default")
+    assert np.array_equal(hp, g["hm_preds"]) and np.array_equal(pr, g["preds"])
+    acc, pck, cnt = onp.keypoint_pck_accuracy(g["preds"].copy(), g["gt"].copy(), g["mask"].copy(), 0.2, g["normalize"].copy())
+    assert np.array_equal(acc, g["pck_acc"]) and pck == float(g["pck"]) and cnt == int(g["pck_cnt"])
+    assert abs(onp.keypoint_auc(g["preds"].copy(), g["gt"].copy(), g["mask"].copy(), 30) - float(g["auc"])) < 1e-12
+    assert abs(onp.keypoint_epe(g["preds"].copy(), g["gt"].copy(), g["mask"].copy()) - float(g["epe"])) < 1e-6
+    p0i = g["argmax_xy"][1]
+    tay = np.stack([onp.taylor(g["taylor_in"][k], p0i[k].copy()) for k in range(21)])
+    assert np.allclose(tay, g["taylor_out"], rtol=1e-6, atol=1e-6)
+
+
+def test_loss(golden_dir):
+    g = np.load(os.path.join(golden_dir, "loss.npz"))
+    r = np.random.Generator(np.random.PCG64(int(g["seed"])))
+    o = torch.from_numpy(r.standard_normal((2, 21, 64, 64)).astype(np.float32)).requires_grad_()
+    tw = [onp.msra_generate_target(a, v, [256, 256], [64, 64]) for a, v in zip(g["joints"], g["visible"])]
+    t = torch.from_numpy(np.stack([a for a, _ in tw]))
+    w = torch.from_numpy(np.stack([b for _, b in tw]))
+    assert int((t > 0.5).sum()) == int(g["npos"])
+    l = torch_ref.distance_loss(o, t, w)
+    assert abs(float(l) - float(g["loss"])) < 1e-6 * abs(float(g["loss"]))
+    l.backward()
+    assert np.allclose(o.grad.numpy()[:, ::5, ::16, ::16], g["grad_sample"], rtol=1e-5, atol=1e-9)
