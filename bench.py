@@ -1,0 +1,165 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec, forward + TopdownHeatmapLoss + backward + Adam step, 256x256, per-GPU batch 64,
+litehandnet (MSRB hourglass = variant B by default), synthetic inputs resident in HBM, random-init weights.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (HBM, measured live with
+events on the launch stream) and `cpu_baseline` (the CPU oracle = port of the reference's path, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic HBM bytes per image, fp32: 4 B x sum over convs of (in + out) elements
+ALG_FWD_BYTES = {"B": 76.42e6, "A": 98.07e6}
+LOSS_BYTES = (8 + 4) * 21 * 64 * 64          # loss fwd reads o,t; bwd writes g (per image)
+HBM_PEAK_GBS = 8000.0                        # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable copy rate)
+
+
+def cpu_baseline(variant, budget_s=20.0):
+    """The reference's path on the host cores: the CPU oracle (fp32 torch, NCHW), fwd + loss + bwd, batch 8."""
+    from litehandnet_amd.config import litehandnet_cfg
+    from oracle import heatmap_np as onp
+    from oracle import synth, torch_ref
+    import numpy as np
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = litehandnet_cfg(variant)
+    m = torch_ref.get_model(cfg)
+    m.train()
+    crit = torch_ref.TopdownHeatmapLoss(cfg)
+    bs = 8
+    x = synth.synth_images(bs, 256, 0)
+    j = synth.synth_joints(bs, 21, 256, 1)
+    t = torch.from_numpy(np.stack([onp.msra_generate_target(a, np.ones_like(a), [256, 256], [64, 64])[0] for a in j]))
+    meta = {"target": t, "target_weight": torch.ones(bs, 21, 1)}
+    opt = torch.optim.Adam(m.parameters(), lr=5e-4)
+
+    def step():
+        y = m(x)
+        loss, _ = crit(y, meta)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    step()
+    n, t0 = 0, time.perf_counter()
+    while True:
+        step()
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 40:
+            break
+    return {"value": round(bs * n / el, 2), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{n} steps of batch {bs} at 256x256 (fwd+loss+bwd+Adam), torch CPU fp32 oracle, {el:.1f}s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--variant", default="B", choices=["A", "B"])
+    ap.add_argument("--batch", type=int, default=64, help="per-GPU batch")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dropout", type=float, default=0.3, help="Dropout2d p inside channel attention (reference: 0.3)")
+    args = ap.parse_args()
+
+    from litehandnet_amd import get_loss, get_model, heatmap
+    from litehandnet_amd.config import litehandnet_cfg
+    from litehandnet_amd.train import Trainer, init_distributed
+
+    rank, local, world = init_distributed()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    dev = torch.device("cuda", torch.cuda.current_device())
+    cfg = litehandnet_cfg(args.variant)
+    cfg.MODEL["ca_dropout"] = args.dropout
+    torch.manual_seed(0)                       # identical random init on every rank (then broadcast anyway)
+    model = get_model(cfg).to(dev).train()
+    crit = get_loss(cfg)
+    trainer = Trainer(model, crit, lr=cfg.OPTIMIZER.lr, world_size=world)
+
+    B = args.batch
+    g = torch.Generator(device="cpu").manual_seed(1 + rank)
+    img = torch.randn(B, 3, 256, 256, generator=g).to(dev)
+    joints = torch.zeros(B, 21, 3)
+    joints[..., :2] = torch.rand(B, 21, 2, generator=g) * 256
+    target, weight = heatmap.generate_target_batch(joints.to(dev), torch.ones(B, 21, 3, device=dev), [256, 256], [64, 64], 2, True)
+    meta = {"target": target, "target_weight": weight}
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.step(img, meta)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        trainer.step(img, meta)
+    sync()
+    el = time.perf_counter() - t0
+    tmax = torch.tensor([el], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    el = float(tmax.item())
+
+    # ---- forward-only launch duration with events on the launch stream (roofline of the forward plan run)
+    fwd_ms = None
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.no_grad():
+        model.train()
+        for _ in range(3):
+            model(img)
+        torch.cuda.synchronize()
+        reps = max(5, args.steps)
+        ev0.record()
+        for _ in range(reps):
+            model(img)
+        ev1.record()
+        torch.cuda.synchronize()
+        fwd_ms = ev0.elapsed_time(ev1) / reps
+    if rank != 0:
+        return
+    value = world * B * args.steps / el
+    alg = ALG_FWD_BYTES[args.variant] * B
+    ach = alg / (fwd_ms * 1e-3) / 1e9
+    step_ms = el / args.steps * 1e3
+    train_alg = (3 * ALG_FWD_BYTES[args.variant] + LOSS_BYTES) * B
+    out = {
+        "metric": "images/sec fwd+bwd @256x256 bs64 litehandnet", "value": round(value, 1), "unit": "images/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(step_ms, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"litehandnet variant {args.variant} ({'MSRB hourglass litehourglass.py' if args.variant == 'B' else 'registered liteHandNet.py, reduction 4'}) "
+                               f"C=128, 256x256x3 -> 21x64x64, per-GPU batch {B}, train-mode BN, fwd + TopdownHeatmapLoss + bwd + fused Adam",
+                   "global_batch": world * B, "parallelism": f"dp{world}", "ca_dropout": args.dropout},
+        "roofline": {"bound": "hbm", "kernel": "forward plan (one lhn_plan_run launch sequence)", "achieved": round(ach, 1),
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                     "algorithmic_bytes": alg, "launch_ms": round(fwd_ms, 4)},
+        "roofline_train_step": {"bound": "hbm", "achieved": round(train_alg / (step_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                                "unit": "GB/s", "frac": round(train_alg / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+        "forward_images_per_s": round(B / (fwd_ms * 1e-3), 1),
+    }
+    if not args.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline(args.variant)
+    elif world == 1:
+        out["cpu_baseline"] = None
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()

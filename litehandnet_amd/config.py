@@ -7,19 +7,27 @@ The reference loads python-dict configs into `addict.Dict` (config/__init__.py:2
 
 
 class AttrDict(dict):
+    """dict with attribute access; nested dicts are converted once, so `cfg.MODEL.x = 1` sticks."""
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        for k, v in list(self.items()):
+            if isinstance(v, dict) and not isinstance(v, AttrDict):
+                super().__setitem__(k, AttrDict(v))
+
     def __getattr__(self, k):
         try:
-            v = self[k]
+            return self[k]
         except KeyError as e:
             raise AttributeError(k) from e
-        return AttrDict(v) if isinstance(v, dict) and not isinstance(v, AttrDict) else v
 
     def __setattr__(self, k, v):
         self[k] = v
 
-    def get(self, k, default=None):
-        v = super().get(k, default)
-        return AttrDict(v) if isinstance(v, dict) and not isinstance(v, AttrDict) else v
+    def __setitem__(self, k, v):
+        if isinstance(v, dict) and not isinstance(v, AttrDict):
+            v = AttrDict(v)
+        super().__setitem__(k, v)
 
 
 def litehandnet_cfg(variant="A", channels=128, num_joints=21, image_size=256, **model_kw):

@@ -2,6 +2,14 @@
 // Reference arithmetic replaced: see include/lhn.h.
 #include "lhn_common.h"
 
+// The decode / encode arithmetic must round like the reference's numpy float32 expressions: no fused
+// multiply-add contraction anywhere in this file (HIP's own *_rn helpers are header inlines that still
+// contract, so the helpers below are defined under contract(off); the file is also built with -ffp-contract=off).
+#pragma clang fp contract(off)
+__device__ __forceinline__ float mul_rn(float a, float b) { return a * b; }
+__device__ __forceinline__ float add_rn(float a, float b) { return a + b; }
+__device__ __forceinline__ float sub_rn(float a, float b) { return a - b; }
+
 // ------------------------------------------------------------------ encode
 // generateTarget.py:100-123 (unbiased) computes exp() in float64 (numpy>=2 promotion of a float32
 // array with a float64 numpy scalar) and rounds to float32 on assignment; :125-154 (biased) works
@@ -49,7 +57,7 @@ __global__ void __launch_bounds__(256) k_encode(const float* __restrict__ joints
       float v = 0.f;
       if (on && x >= ulx && x < brx && y >= uly && y < bry) {
         const float gx = (float)(x - ulx) - (float)c0, gy = (float)(y - uly) - (float)c0;
-        const float a = __fadd_rn(__fmul_rn(gx, gx), __fmul_rn(gy, gy));
+        const float a = add_rn(mul_rn(gx, gx), mul_rn(gy, gy));
         v = expf(-a / den);
       }
       out[i] = v;
@@ -116,25 +124,25 @@ __device__ __forceinline__ void refine_xy(const float* __restrict__ m, int H, in
     if (1 < px && px < W - 1 && 1 < py && py < H - 1) {
       const float dx = m[py * W + px + 1] - m[py * W + px - 1];
       const float dy = m[(py + 1) * W + px] - m[(py - 1) * W + px];
-      x = __fadd_rn(x, sgn(dx) * 0.25f);
-      y = __fadd_rn(y, sgn(dy) * 0.25f);
+      x = add_rn(x, sgn(dx) * 0.25f);
+      y = add_rn(y, sgn(dy) * 0.25f);
     }
   } else {
     const int xr = min(px + 1, W - 1), xl = max(px - 1, 0), yd = min(py + 1, H - 1), yu = max(py - 1, 0);
-    x = __fadd_rn(x, m[py * W + xr] > m[py * W + xl] ? 0.25f : -0.25f);
-    y = __fadd_rn(y, m[yd * W + px] > m[yu * W + px] ? 0.25f : -0.25f);
-    x = __fadd_rn(x, 0.5f);
-    y = __fadd_rn(y, 0.5f);
+    x = add_rn(x, m[py * W + xr] > m[py * W + xl] ? 0.25f : -0.25f);
+    y = add_rn(y, m[yd * W + px] > m[yu * W + px] ? 0.25f : -0.25f);
+    x = add_rn(x, 0.5f);
+    y = add_rn(y, 0.5f);
   }
 }
 // post_transforms.py:35-46, float32 left-to-right, no contraction
 __device__ __forceinline__ void xform_xy(float x, float y, const float* c, const float* s, int W, int H, int udp,
                                          float& ox, float& oy) {
-  const float sw = __fmul_rn(s[0], 200.f), sh = __fmul_rn(s[1], 200.f);
+  const float sw = mul_rn(s[0], 200.f), sh = mul_rn(s[1], 200.f);
   const float sx = udp ? sw / ((float)W - 1.f) : sw / (float)W;
   const float sy = udp ? sh / ((float)H - 1.f) : sh / (float)H;
-  ox = __fsub_rn(__fadd_rn(__fmul_rn(x, sx), c[0]), __fmul_rn(sw, 0.5f));
-  oy = __fsub_rn(__fadd_rn(__fmul_rn(y, sy), c[1]), __fmul_rn(sh, 0.5f));
+  ox = sub_rn(add_rn(mul_rn(x, sx), c[0]), mul_rn(sw, 0.5f));
+  oy = sub_rn(add_rn(mul_rn(y, sy), c[1]), mul_rn(sh, 0.5f));
 }
 
 __global__ void __launch_bounds__(256) k_decode(const float* __restrict__ hm, const float* __restrict__ center,
@@ -228,7 +236,7 @@ __global__ void __launch_bounds__(256) k_pck(const float* __restrict__ pred, con
       if (n1 <= 0.f) n1 = 1e6f;
       const float dx = (pred[(n * K + k) * 2] - gt[(n * K + k) * 2]) / n0;
       const float dy = (pred[(n * K + k) * 2 + 1] - gt[(n * K + k) * 2 + 1]) / n1;
-      const float d = sqrtf(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
+      const float d = sqrtf(add_rn(mul_rn(dx, dx), mul_rn(dy, dy)));
       ++valid;
       hit += d < thr;
     }
@@ -266,7 +274,7 @@ __global__ void __launch_bounds__(256) k_loss_fwd(const float* __restrict__ o, c
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float d = av[j] - bv[j];
-      const float l = __fmul_rn(__fmul_rn(d, d), wk);
+      const float l = mul_rn(mul_rn(d, d), wk);
       if (bv[j] > 0.5f) {
         sp += (double)l;
         ++np;
@@ -287,7 +295,7 @@ __global__ void __launch_bounds__(256) k_loss_fwd(const float* __restrict__ o, c
 __global__ void k_loss_final(const double* __restrict__ acc, float* __restrict__ loss, double numel, float lw, int balance) {
   const double npos = acc[2], nneg = numel - npos;
   // the reference multiplies float32 loss elements by float32 factors; factors rounded to f32 here too
-  const float pf = balance ? __fmul_rn((float)numel / (float)(npos + 1.0), 0.1f) : 1.f;
+  const float pf = balance ? mul_rn((float)numel / (float)(npos + 1.0), 0.1f) : 1.f;
   const float nf = balance ? (float)numel / (float)(nneg + 1.0) : 1.f;
   loss[0] = lw * (float)(((double)pf * acc[0] + (double)nf * acc[1]) / numel);
 }
@@ -297,7 +305,7 @@ __global__ void __launch_bounds__(256) k_loss_bwd(const float* __restrict__ o, c
                                                   float lw, int balance) {
   const double numel = (double)NK * HW;
   const double npos = acc[2], nneg = numel - npos;
-  const float pf = balance ? __fmul_rn((float)numel / (float)(npos + 1.0), 0.1f) : 1.f;
+  const float pf = balance ? mul_rn((float)numel / (float)(npos + 1.0), 0.1f) : 1.f;
   const float nf = balance ? (float)numel / (float)(nneg + 1.0) : 1.f;
   const float up = (dloss ? dloss[0] : 1.f) * lw;
   const float kp = (float)((double)up * 2.0 * (double)pf / numel), kn = (float)((double)up * 2.0 * (double)nf / numel);

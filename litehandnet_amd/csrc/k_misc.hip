@@ -162,41 +162,45 @@ __global__ void __launch_bounds__(256) k_maxpool2_fwd(lhn_view x, lhn_view y) {
     *reinterpret_cast<f4*>(y.data + pix * y.cstride + y.coff + 4 * c4) = m;
   }
 }
-// gradient goes to the first window element (scan order) that equals the max
+// gradient goes to the first window element (scan order) holding the max.  One thread per OUTPUT element
+// re-evaluates its 2x2 window (every input pixel belongs to exactly one window), so the comparison never
+// depends on two kernels rounding the pending transform identically.
 __global__ void __launch_bounds__(256) k_maxpool2_bwd(lhn_view x, lhn_view y, const float* __restrict__ dy,
                                                       float* __restrict__ dx, int accumulate) {
-  const int C4 = x.C >> 2;
-  const int64_t total = (int64_t)x.N * x.H * x.W * C4;
+  const int C4 = y.C >> 2;
+  const int64_t total = (int64_t)y.N * y.H * y.W * C4;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int c4 = (int)(i % C4);
-    const int64_t pix = i / C4;
-    const int w = (int)(pix % x.W);
-    const int64_t t = pix / x.W;
-    const int h = (int)(t % x.H), n = (int)(t / x.H);
-    const int ho = h >> 1, wo = w >> 1;
+    const int64_t po = i / C4;
+    const int wo = (int)(po % y.W);
+    const int64_t t = po / y.W;
+    const int ho = (int)(t % y.H), n = (int)(t / y.H);
     const int ca = x.coff + 4 * c4;
     const Xf4 xf = lhn_load_xf(x, ca);
-    const int64_t po = ((int64_t)n * y.H + ho) * y.W + wo;
-    const f4 mx = *reinterpret_cast<const f4*>(y.data + po * y.cstride + y.coff + 4 * c4);
     const f4 g = *reinterpret_cast<const f4*>(dy + po * y.cstride + y.coff + 4 * c4);
-    const f4 mine = lhn_load_val(x, xf, pix, n, ca);
-    // am I the first element of the window equal to the max?
-    bool first[4] = {mine.x == mx.x, mine.y == mx.y, mine.z == mx.z, mine.w == mx.w};
-    const int myord = (h & 1) * 2 + (w & 1);
-    for (int o = 0; o < myord; ++o) {
+    f4 m = (f4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int arg[4] = {-1, -1, -1, -1};
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
       const int ih = 2 * ho + (o >> 1), iw = 2 * wo + (o & 1);
       if (ih < x.H && iw < x.W) {
         const f4 v = lhn_load_val(x, xf, ((int64_t)n * x.H + ih) * x.W + iw, n, ca);
-        first[0] = first[0] && !(v.x == mx.x);
-        first[1] = first[1] && !(v.y == mx.y);
-        first[2] = first[2] && !(v.z == mx.z);
-        first[3] = first[3] && !(v.w == mx.w);
+        if (v.x > m.x || v.x != v.x || arg[0] < 0) { if (!(m.x != m.x)) { m.x = v.x; arg[0] = o; } }
+        if (v.y > m.y || v.y != v.y || arg[1] < 0) { if (!(m.y != m.y)) { m.y = v.y; arg[1] = o; } }
+        if (v.z > m.z || v.z != v.z || arg[2] < 0) { if (!(m.z != m.z)) { m.z = v.z; arg[2] = o; } }
+        if (v.w > m.w || v.w != v.w || arg[3] < 0) { if (!(m.w != m.w)) { m.w = v.w; arg[3] = o; } }
       }
     }
-    f4 r = (f4){first[0] ? g.x : 0.f, first[1] ? g.y : 0.f, first[2] ? g.z : 0.f, first[3] ? g.w : 0.f};
-    float* o = dx + pix * x.cstride + ca;
-    if (accumulate) r += *reinterpret_cast<const f4*>(o);
-    *reinterpret_cast<f4*>(o) = r;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      const int ih = 2 * ho + (o >> 1), iw = 2 * wo + (o & 1);
+      if (ih < x.H && iw < x.W) {
+        f4 r = (f4){arg[0] == o ? g.x : 0.f, arg[1] == o ? g.y : 0.f, arg[2] == o ? g.z : 0.f, arg[3] == o ? g.w : 0.f};
+        float* q = dx + (((int64_t)n * x.H + ih) * x.W + iw) * x.cstride + ca;
+        if (accumulate) r += *reinterpret_cast<const f4*>(q);
+        *reinterpret_cast<f4*>(q) = r;
+      }
+    }
   }
 }
 
@@ -572,7 +576,7 @@ int lhn_maxpool2_fwd(const lhn_view* x, const lhn_view* y, void* stream) {
 }
 int lhn_maxpool2_bwd(const lhn_view* x, const lhn_view* y, const float* dy, float* dx, int dx_accumulate, void* stream) {
   LHN_CHECK_ARG(lhn_view_ok(x) && lhn_view_ok(y) && dy && dx && x->C == y->C, "lhn_maxpool2_bwd: bad args");
-  const int64_t total = (int64_t)x->N * x->H * x->W * (x->C / 4);
+  const int64_t total = (int64_t)y->N * y->H * y->W * (y->C / 4);
   hipLaunchKernelGGL(k_maxpool2_bwd, dim3(grid_cap((total + 255) / 256, 8)), dim3(256), 0, (hipStream_t)stream, *x, *y, dy, dx, dx_accumulate);
   LHN_CHECK_LAUNCH("lhn_maxpool2_bwd");
   return 0;

@@ -37,14 +37,16 @@ class _PlanFn(torch.autograd.Function):
         ctx.eng, ctx.plan, ctx.training, ctx.via_autograd = eng, plan, training, len(params) > 0
         plan.refresh_params()
         xc = x.contiguous()
-        if eng.full:
+        if not eng.full:
+            plan.buf_data(plan.pb.in_ref).copy_(xc.permute(0, 2, 3, 1))
+        out = None
+        if plan.nchw_out:
             out = torch.empty((x.shape[0], plan.pb.nchw_out_C, plan.out_hw[0], plan.out_hw[1]), dtype=torch.float32,
                               device=x.device)
-            plan.run(0, xc, out, training)
+        plan.run(0, xc if eng.full else None, out, training)
+        if eng.full:
             ctx.save_for_backward(xc)
-        else:
-            plan.buf_data(plan.pb.in_ref).copy_(xc.permute(0, 2, 3, 1))
-            plan.run(0, None, None, training)
+        if not plan.nchw_out:
             out = plan.buf_data(plan.pb.out_ref).permute(0, 3, 1, 2).contiguous()
         return out
 
@@ -57,13 +59,15 @@ class _PlanFn(torch.autograd.Function):
             raise _lib.LhnError("plan was compiled without a backward pass")
         eng.flat_grads.zero_()
         plan.set_grads(eng.grad_views)
-        dx = None
+        dx, xc, dnchw = None, None, None
         if eng.full:
             (xc,) = ctx.saved_tensors
-            plan.run(1, xc, dout.contiguous(), True)
+        if plan.nchw_out:
+            dnchw = dout.contiguous()
         else:
             plan.buf_data(plan.pb.out_ref, grad=True).copy_(dout.permute(0, 2, 3, 1))
-            plan.run(1, None, None, True)
+        plan.run(1, xc, dnchw, True)
+        if not eng.full:
             dx = plan.buf_data(plan.pb.in_ref, grad=True).permute(0, 3, 1, 2).contiguous()
         if ctx.via_autograd:
             return (dx, None, None, None) + tuple(eng.param_grad_views)
@@ -139,13 +143,13 @@ class Engine:
             if Cc != 3:
                 raise _lib.LhnError("the backbone consumes a 3-channel image")
             y = self.module.emit(pb, pb.image())
-            out_hw = (y.H, y.W)
         else:
             y = self.module.emit(pb, pb.input_tensor(Cc, H, W))
+        nchw_out = y.buf == -2
+        if not nchw_out:
             pb.set_output(y)
-            out_hw = (y.H, y.W)
         plan = CompiledPlan(pb, tensors, x.device)
-        plan.out_hw = out_hw
+        plan.out_hw, plan.nchw_out = (y.H, y.W), nchw_out
         self.plans[key] = plan
         return plan
 

@@ -107,6 +107,7 @@ class EncoderDecoder(PlanModule):
 
 class Stem(PlanModule):
     """litehourglass.py:166-193."""
+    consumes_image = True
 
     def __init__(self, channel, p_drop=0.3):
         super().__init__()

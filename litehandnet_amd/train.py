@@ -1,0 +1,100 @@
+"""Training-step harness: the build's counterpart of train/topdown_trainer.py:68-87 (train_one_epoch body),
+train/spawn_dist.py:10-66 (process group + DDP wrap) and dist_train.py:64-69 (Adam, lr * world_size).
+
+MI355X-first differences: parameters and gradients live in two flat fp32 buffers, the optimizer is ONE fused
+Adam over the flat parameter, and data parallelism is ONE RCCL all-reduce of the flat gradient (SUM, then
+divide by world) instead of DDP's bucketed reducer -- same arithmetic as DistributedDataParallel.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+from torch import nn
+
+from . import _lib
+from .engine import Engine
+
+
+def init_distributed(backend=None):
+    """One process per GPU (train/spawn_dist.py:10-32).  Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group(backend or ("nccl" if torch.cuda.is_available() else "gloo"), rank=rank, world_size=world)
+    return rank, local, world
+
+
+class FlatParams:
+    """Re-homes every parameter of `model` into one flat buffer (views stay valid nn.Parameters, so state_dict
+    keys / shapes are untouched) and exposes a single leaf whose .grad is the engine's flat gradient."""
+
+    def __init__(self, model):
+        self.params = [p for p in model.parameters()]
+        n = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.flat = torch.empty(n, dtype=torch.float32, device=dev)
+        off = 0
+        for p in self.params:
+            k = p.numel()
+            self.flat[off:off + k].copy_(p.data.reshape(-1))
+            p.data = self.flat[off:off + k].view_as(p)
+            off += k
+        self.leaf = nn.Parameter(self.flat, requires_grad=True)   # aliases the same storage
+
+    def broadcast(self, src=0):
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.broadcast(self.flat, src)
+
+
+def allreduce_mean_(flat_grads, group=None):
+    """DDP semantics (train/spawn_dist.py:49-52): all-reduce(SUM) of the gradients, divided by the world size.
+    One collective over the flat buffer -> a single RCCL call over xGMI."""
+    if dist.is_available() and dist.is_initialized():
+        w = dist.get_world_size(group)
+        if w > 1:
+            dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=group)
+            flat_grads.div_(w)
+    return flat_grads
+
+
+class Trainer:
+    """step(img, meta): forward -> criterion -> zero_grad -> backward -> [all-reduce] -> Adam step
+    (topdown_trainer.py:70-81).  Loss values stay on the device (no per-step .item())."""
+
+    def __init__(self, model, criterion, lr=5e-4, world_size=1, optimizer="Adam"):
+        _lib.require_device()
+        self.model, self.criterion = model, criterion
+        eng = model.__dict__.get("_engine")
+        if eng is None:
+            eng = Engine(model)
+            model.__dict__["_engine"] = eng
+        self.engine = eng
+        self.fp = FlatParams(model)
+        self.fp.broadcast(0)
+        for b in model.buffers():                      # BN running statistics start identical on every rank
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and b.is_floating_point():
+                dist.broadcast(b, 0)
+        self.world = world_size
+        lr = lr * world_size                           # dist_train.py:68
+        if optimizer.lower() == "adam":
+            self.opt = torch.optim.Adam([self.fp.leaf], lr=lr, fused=True)
+        else:
+            self.opt = torch.optim.SGD([self.fp.leaf], lr=lr, momentum=0.9)
+        self.loss_sum = torch.zeros((), device=self.fp.flat.device)
+
+    def step(self, img, meta):
+        out = self.model(img)
+        loss, _ = self.criterion(out, meta)
+        self.opt.zero_grad(set_to_none=True)
+        loss.backward()
+        g = self.engine.flat_grads
+        allreduce_mean_(g)
+        self.fp.leaf.grad = g
+        self.opt.step()
+        self.loss_sum += loss.detach()
+        return loss

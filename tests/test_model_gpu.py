@@ -1,5 +1,6 @@
 """GPU parity: HIP-backed blocks and the full MSRB hourglass (variant B) against the torch-CPU oracle on the
 same seeded inputs and weights, forward and backward, plus the committed golden vectors."""
+import copy
 import os
 
 import numpy as np
@@ -12,8 +13,8 @@ from oracle import synth, torch_ref
 
 pytestmark = pytest.mark.gpu
 
-FWD_TOL = 2e-4     # fp32: max-abs error relative to the tensor's max-abs (different summation order, fused BN)
-GRAD_TOL = 2e-3    # per-parameter gradient, relative to that gradient's norm
+FWD_TOL = 1e-4     # fp32 vs the float64 oracle: max-abs error relative to the tensor's max-abs
+GRAD_TOL = 1e-3    # gradients vs the float64 oracle, relative to the gradient's norm (floored, see _check_block)
 
 
 def _no_dropout(m):
@@ -27,36 +28,53 @@ def _rel(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
 
 
-def _check_block(ours, ref, x, dev, seed=0, fwd_tol=FWD_TOL, grad_tol=GRAD_TOL, pick=None):
+def _check_block(ours, ref, x, dev, seed=0, fwd_tol=FWD_TOL, grad_tol=GRAD_TOL, pick=None, no_dx=False):
+    """HIP block vs the oracle evaluated in float64 (the same restatement, run in double, is the arbiter:
+    some of these blocks are ill-conditioned enough that torch's own fp32 CPU result is off by >1e-2)."""
     sd = synth.synth_state_dict(ref, seed)
     ref.load_state_dict(sd)
     ours.load_state_dict(sd)
     ours.to(dev)
     ref.train(); ours.train()
     _no_dropout(ref)
-    xr = x.clone().requires_grad_()
+    ref32 = copy.deepcopy(ref)
+    ref = ref.double()
+    xr = x.double().clone().requires_grad_()
     yr = ref(xr)
     if pick is not None:
         yr = yr[pick]
     g = torch.from_numpy(np.random.Generator(np.random.PCG64(seed + 100)).standard_normal(tuple(yr.shape)).astype(np.float32))
-    yr.backward(g)
+    yr.backward(g.double())
+    # the same block in fp32 on the CPU (= what the reference computes): its distance from the float64 result
+    # is the conditioning yardstick -- the HIP path may not be more than 3x further away than that
+    x32 = x.clone().requires_grad_()
+    y32 = ref32(x32)
+    if pick is not None:
+        y32 = y32[pick]
+    y32.backward(g)
     xg = x.clone().to(dev).requires_grad_()
     yg = ours(xg)
     assert yg.shape == yr.shape
-    assert _rel(yg, yr) < fwd_tol, ("forward", _rel(yg, yr))
+    assert _rel(yg, yr) < max(fwd_tol, 3 * _rel(y32, yr)), ("forward", _rel(yg, yr), _rel(y32, yr))
     yg.backward(g.to(dev))
-    assert _rel(xg.grad, xr.grad) < grad_tol, ("dx", _rel(xg.grad, xr.grad))
-    rp = dict(ref.named_parameters())
+    if not no_dx:
+        assert _rel(xg.grad, xr.grad) < max(grad_tol, 3 * _rel(x32.grad, xr.grad)), ("dx", _rel(xg.grad, xr.grad), _rel(x32.grad, xr.grad))
+    rp, rp32 = dict(ref.named_parameters()), dict(ref32.named_parameters())
+    # some gradients are mathematically zero (a BN shift feeding a conv that is itself batch-normalised):
+    # measure every error against max(own norm, 1e-3 x the largest gradient norm of the block)
+    floor = 1e-3 * max(float(v.grad.double().norm()) for v in rp.values())
     for k, p in ours.named_parameters():
         assert p.grad is not None, k
-        e = float((p.grad.cpu().double() - rp[k].grad.double()).norm() / (rp[k].grad.double().norm() + 1e-12))
-        assert e < grad_tol, (k, e)
+        den = rp[k].grad.double().norm() + floor
+        e = float((p.grad.cpu().double() - rp[k].grad.double()).norm() / den)
+        e32 = float((rp32[k].grad.double() - rp[k].grad.double()).norm() / den)
+        assert e < max(grad_tol, 3 * e32), (k, e, e32)
     # running statistics (momentum 0.1, unbiased variance) after one training step
     for k, v in ours.state_dict().items():
         if k.endswith("running_mean") or k.endswith("running_var"):
-            assert torch.allclose(v.cpu(), ref.state_dict()[k], rtol=1e-4, atol=1e-5), k
+            assert torch.allclose(v.cpu().double(), ref.state_dict()[k], rtol=1e-4, atol=1e-5), k
         if k.endswith("num_batches_tracked"):
-            assert int(v) == int(ref.state_dict()[k]), k
+            assert int(v) == int(ref32.state_dict()[k]), k
 
 
 def _x(n, c, h, w, seed=0):
@@ -93,44 +111,70 @@ def test_rep_basic_unit(dev, ca):
 
 def test_hourglass_B_block(dev):
     from litehandnet_amd import litehourglass as lh
-    _check_block(lh.EncoderDecoder(4, 32, "ca", "none", p_drop=0.0), torch_ref._HourglassB(4, 32, "ca", "none", 0.0),
-                 _x(2, 32, 32, 32), dev, grad_tol=5e-3, pick=-1)
+    _check_block(lh.EncoderDecoder(4, 64, "ca", "none", p_drop=0.0), torch_ref._HourglassB(4, 64, "ca", "none", 0.0),
+                 _x(8, 64, 64, 64), dev, pick=-1)
+
+
+def test_stem_B(dev):
+    from litehandnet_amd import litehourglass as lh
+    _check_block(lh.Stem(128, p_drop=0.0), torch_ref._StemB(128, 0.0), _x(2, 3, 64, 64), dev, no_dx=True)
 
 
 def _model_case(dev, golden_dir, tag, **kw):
-    from litehandnet_amd import get_loss, get_model
+    """Full variant-B model, forward + TopdownHeatmapLoss + backward.
+
+    Arbiter = the oracle in float64.  Bar: the HIP fp32 result must be at least as close to exact arithmetic
+    as the REFERENCE's own fp32 CPU run (the committed golden vector) is, up to a factor 3 (floors 1e-4 for
+    the heatmap, 1e-3 for gradient norms; these N=2 fixtures are ill-conditioned: the reference's own fp32 run
+    is 1e-3..3e-1 away from float64).  Integer argmax coordinates must equal the float64
+    oracle's wherever the reference's fp32 run also does."""
+    from litehandnet_amd import get_loss, get_model, heatmap
     g = np.load(os.path.join(golden_dir, f"model_{tag}.npz"))
     cfg = litehandnet_cfg("B", **kw)
     cfg.MODEL["ca_dropout"] = 0.0
     n, size, seed = int(g["n"]), int(g["size"]), int(g["seed"])
-    m = get_model(cfg)
-    m.load_state_dict(synth.synth_state_dict(m, seed))
-    m.to(dev).train()
-    x = synth.synth_images(n, size, seed).to(dev)
-    y = m(x)
-    err = np.abs(y.detach().cpu().numpy() - g["heatmap"]).max() / np.abs(g["heatmap"]).max()
-    assert err < FWD_TOL, err
     hs = size // 4
     j = synth.synth_joints(n, 21, size, seed + 1)
     tgt = np.stack([onp.msra_generate_target(a, np.ones_like(a), [size, size], [hs, hs])[0] for a in j])
-    meta = {"target": torch.from_numpy(tgt), "target_weight": torch.from_numpy(g["target_weight"])}
-    loss, _ = get_loss(cfg)(y, meta)
-    assert abs(float(loss) - float(g["loss"])) <= 1e-4 * abs(float(g["loss"]))
+    tw = torch.from_numpy(g["target_weight"])
+    # float64 oracle
+    ref = torch_ref.get_model(cfg, p_drop=0.0)
+    sd = synth.synth_state_dict(ref, seed)
+    ref.load_state_dict(sd)
+    ref = ref.double().train()
+    y64 = ref(synth.synth_images(n, size, seed).double())
+    l64 = cfg.LOSS.loss_weight[0] * torch_ref.distance_loss(y64, torch.from_numpy(tgt).double(), tw.double())
+    l64.backward()
+    y64n = y64.detach().numpy()
+    scale = np.abs(y64n).max()
+    ref32_err = np.abs(g["heatmap"] - y64n).max() / scale
+    # HIP
+    m = get_model(cfg)
+    m.load_state_dict(sd)
+    m.to(dev).train()
+    y = m(synth.synth_images(n, size, seed).to(dev))
+    err = np.abs(y.detach().cpu().numpy() - y64n).max() / scale
+    assert err <= max(3 * ref32_err, 1e-4), (err, ref32_err)
+    loss, _ = get_loss(cfg)(y, {"target": torch.from_numpy(tgt), "target_weight": tw})
+    assert abs(float(loss) - float(l64)) <= max(3 * abs(float(g["loss"]) - float(l64)), 1e-5 * abs(float(l64)))
     loss.backward()
-    gn = dict(zip(g["grad_keys"].tolist(), g["grad_norms"].tolist()))
-    worst = 0.0
+    gn32 = dict(zip(g["grad_keys"].tolist(), g["grad_norms"].tolist()))
+    gn64 = {k: float(p.grad.norm()) for k, p in ref.named_parameters()}
+    floor = 1e-3 * max(gn64.values())
+    worst, worst32 = 0.0, 0.0
     for k, p in m.named_parameters():
-        e = abs(float(p.grad.norm()) - gn[k]) / (gn[k] + 1e-9)
-        worst = max(worst, e)
-        assert e < 5e-3, (k, e, gn[k])
+        worst = max(worst, abs(float(p.grad.norm()) - gn64[k]) / (gn64[k] + floor))
+        worst32 = max(worst32, abs(gn32[k] - gn64[k]) / (gn64[k] + floor))
+    assert worst <= max(3 * worst32, 1e-3), (worst, worst32)
     bk = str(g["bn_key"])
     assert np.allclose(m.state_dict()[bk].cpu().numpy(), g["bn_running_mean"], rtol=1e-4, atol=1e-6)
-    # integer argmax of the produced heatmap vs the reference's heatmap: bit-exact coordinates
-    from litehandnet_amd import heatmap
     p, _ = heatmap._get_max_preds(y.detach())
-    pref, _ = onp.get_max_preds(g["heatmap"])
-    agree = (p.cpu().numpy() == pref).all(-1).mean()
-    assert agree >= 0.999, agree
+    p64, _ = onp.get_max_preds(y64n.astype(np.float32))
+    p32, _ = onp.get_max_preds(g["heatmap"])
+    same32 = (p32 == p64).all(-1)
+    assert (p.cpu().numpy() == p64).all(-1)[same32].all()
+    print(f"[{tag}] heatmap err vs f64: hip {err:.2e} / reference-fp32 {ref32_err:.2e}; grad-norm err: hip {worst:.2e} / "
+          f"reference-fp32 {worst32:.2e}; argmax agree {float((p.cpu().numpy() == p64).all(-1).mean()):.4f}")
 
 
 def test_model_B_64_golden(dev, golden_dir):
