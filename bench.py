@@ -32,7 +32,11 @@ def cpu_baseline(variant, budget_s=20.0):
     from oracle import heatmap_np as onp
     from oracle import synth, torch_ref
     import numpy as np
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))             # a one-GPU box owns a 16-core share of the host
     torch.set_num_threads(cores)
     cfg = litehandnet_cfg(variant)
     m = torch_ref.get_model(cfg)
@@ -57,7 +61,7 @@ def cpu_baseline(variant, budget_s=20.0):
         step()
         n += 1
         el = time.perf_counter() - t0
-        if el > budget_s or n >= 40:
+        if el > budget_s or n >= 40 or (n >= 2 and el > 0.5 * budget_s):
             break
     return {"value": round(bs * n / el, 2), "unit": "images/s", "cores": cores, "kind": "port",
             "sample": f"{n} steps of batch {bs} at 256x256 (fwd+loss+bwd+Adam), torch CPU fp32 oracle, {el:.1f}s"}

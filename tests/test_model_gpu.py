@@ -167,7 +167,9 @@ def _model_case(dev, golden_dir, tag, **kw):
         worst32 = max(worst32, abs(gn32[k] - gn64[k]) / (gn64[k] + floor))
     assert worst <= max(3 * worst32, 1e-3), (worst, worst32)
     bk = str(g["bn_key"])
-    assert np.allclose(m.state_dict()[bk].cpu().numpy(), g["bn_running_mean"], rtol=1e-4, atol=1e-6)
+    rm64 = ref.state_dict()[bk].numpy()
+    rm_tol = max(1e-5, 3 * np.abs(g["bn_running_mean"] - rm64).max())
+    assert np.abs(m.state_dict()[bk].cpu().numpy() - rm64).max() <= rm_tol
     p, _ = heatmap._get_max_preds(y.detach())
     p64, _ = onp.get_max_preds(y64n.astype(np.float32))
     p32, _ = onp.get_max_preds(g["heatmap"])
