@@ -5,10 +5,14 @@
 #include "lhn_common.h"
 
 // ------------------------------------------------------------------ depthwise forward
+// Block = persistent over output rows (n, ho); thread = (c4, pixel lane).  All index math is 32-bit and the
+// row/tap validity is block-uniform; a wave reads 64/C4 neighbouring pixels x C*4 contiguous bytes per tap.
+template <int K>
 __global__ void __launch_bounds__(256) k_dw_fwd(lhn_view x, const float* __restrict__ w, lhn_view y,
-                                                double* __restrict__ stats, int K, int stride, int pad, int dil) {
+                                                double* __restrict__ stats, int stride, int pad, int dil) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int C = x.C, C4 = C >> 2, KK = K * K;
+  const int C = x.C, C4 = C >> 2;
+  constexpr int KK = K * K;
   float* Ws = smem;                                   // [KK][C]
   f4* red = reinterpret_cast<f4*>(smem + KK * C);     // [256][2]
   const int tid = threadIdx.x;
@@ -20,26 +24,36 @@ __global__ void __launch_bounds__(256) k_dw_fwd(lhn_view x, const float* __restr
   const int c4 = tid % C4, pl = tid / C4, PL = 256 / C4;
   const int cin = x.coff + 4 * c4, cout = y.coff + 4 * c4;
   const Xf4 xf = lhn_load_xf(x, cin);
-  const int64_t total = (int64_t)y.N * y.H * y.W;
+  f4 wt[KK];
+#pragma unroll
+  for (int t = 0; t < KK; ++t) wt[t] = *reinterpret_cast<const f4*>(Ws + t * C + 4 * c4);
+  const int rows = y.N * y.H;
   f4 s = (f4){0.f, 0.f, 0.f, 0.f}, q = s;
-  for (int64_t pix = (int64_t)blockIdx.x * PL + pl; pix < total; pix += (int64_t)gridDim.x * PL) {
-    const int wo = (int)(pix % y.W);
-    const int64_t t = pix / y.W;
-    const int ho = (int)(t % y.H), n = (int)(t / y.H);
-    f4 acc = (f4){0.f, 0.f, 0.f, 0.f};
-    for (int kh = 0; kh < K; ++kh) {
-      const int ih = ho * stride - pad + kh * dil;
-      if (ih < 0 || ih >= x.H) continue;
-      for (int kw = 0; kw < K; ++kw) {
-        const int iw = wo * stride - pad + kw * dil;
-        if (iw < 0 || iw >= x.W) continue;
-        const f4 v = lhn_load_val(x, xf, ((int64_t)n * x.H + ih) * x.W + iw, n, cin);
-        acc += v * *reinterpret_cast<const f4*>(Ws + (kh * K + kw) * C + 4 * c4);
+  for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+    const int n = row / y.H, ho = row - n * y.H;
+    const float* xin = x.data + (size_t)n * x.H * x.W * x.cstride + cin;
+    f4 gate = (f4){1.f, 1.f, 1.f, 1.f};
+    if (x.gate) gate = *reinterpret_cast<const f4*>(x.gate + (size_t)n * x.cstride + cin);
+    float* yout = y.data + (size_t)row * y.W * y.cstride + cout;
+    for (int wo = pl; wo < y.W; wo += PL) {
+      f4 acc = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kh = 0; kh < K; ++kh) {
+        const int ih = ho * stride - pad + kh * dil;
+        if (ih < 0 || ih >= x.H) continue;
+        const float* xr = xin + (size_t)ih * x.W * x.cstride;
+#pragma unroll
+        for (int kw = 0; kw < K; ++kw) {
+          const int iw = wo * stride - pad + kw * dil;
+          if (iw < 0 || iw >= x.W) continue;
+          const f4 raw = *reinterpret_cast<const f4*>(xr + iw * x.cstride);
+          acc += lhn_apply_xf(raw, xf) * gate * wt[kh * K + kw];
+        }
       }
+      *reinterpret_cast<f4*>(yout + wo * y.cstride) = acc;
+      s += acc;
+      q += acc * acc;
     }
-    *reinterpret_cast<f4*>(y.data + pix * y.cstride + cout) = acc;
-    s += acc;
-    q += acc * acc;
   }
   if (stats) {
     red[tid * 2] = s;
@@ -145,13 +159,20 @@ extern "C" int lhn_conv_dw_fwd(const lhn_view* x, const float* w, const lhn_view
                                int pad, int dil, void* stream) {
   LHN_CHECK_ARG(lhn_view_ok(x) && lhn_view_ok(y) && w, "lhn_conv_dw_fwd: bad view / null pointer");
   LHN_CHECK_ARG(x->C == y->C && pow2(x->C) && x->C <= 256, "lhn_conv_dw_fwd: channels %d -> %d (power of two <= 256)", x->C, y->C);
-  LHN_CHECK_ARG(k >= 1 && k <= 7 && (k & 1) && stride >= 1 && dil >= 1 && pad >= 0, "lhn_conv_dw_fwd: k=%d stride=%d dil=%d", k, stride, dil);
+  LHN_CHECK_ARG((k == 1 || k == 3 || k == 5 || k == 7) && stride >= 1 && dil >= 1 && pad >= 0, "lhn_conv_dw_fwd: k=%d stride=%d dil=%d", k, stride, dil);
   const int Ho = (x->H + 2 * pad - dil * (k - 1) - 1) / stride + 1, Wo = (x->W + 2 * pad - dil * (k - 1) - 1) / stride + 1;
   LHN_CHECK_ARG(y->N == x->N && y->H == Ho && y->W == Wo, "lhn_conv_dw_fwd: output %dx%d, expected %dx%d", y->H, y->W, Ho, Wo);
-  const int PL = 256 / (x->C / 4);
   const size_t lds = (size_t)(k * k * x->C) * 4 + 256 * 2 * 16;
-  hipLaunchKernelGGL(k_dw_fwd, dim3(grid_for((int64_t)y->N * Ho * Wo, PL, 8)), dim3(256), lds, (hipStream_t)stream, *x, w,
-                     *y, stats, k, stride, pad, dil);
+  const int grid = grid_for((int64_t)y->N * Ho, 1, 8);
+  hipStream_t s = (hipStream_t)stream;
+  if (k == 3)
+    hipLaunchKernelGGL((k_dw_fwd<3>), dim3(grid), dim3(256), lds, s, *x, w, *y, stats, stride, pad, dil);
+  else if (k == 7)
+    hipLaunchKernelGGL((k_dw_fwd<7>), dim3(grid), dim3(256), lds, s, *x, w, *y, stats, stride, pad, dil);
+  else if (k == 1)
+    hipLaunchKernelGGL((k_dw_fwd<1>), dim3(grid), dim3(256), lds, s, *x, w, *y, stats, stride, pad, dil);
+  else if (k == 5)
+    hipLaunchKernelGGL((k_dw_fwd<5>), dim3(grid), dim3(256), lds, s, *x, w, *y, stats, stride, pad, dil);
   LHN_CHECK_LAUNCH("lhn_conv_dw_fwd");
   return 0;
 }
@@ -181,12 +202,25 @@ __device__ __forceinline__ f4 dw_load_dy(const lhn_view& y, const lhn_gradview& 
   return gr.A * du + gr.B * raw + gr.Cc;
 }
 
-// dgrad: one thread = 4 channels of one INPUT pixel
+// row-local dy loader: off = element offset of (n, h, w, channel ca) inside the y buffer
+__device__ __forceinline__ f4 dw_dy_at(const lhn_view& y, const lhn_gradview& g, const Xf4& xf, const Gr4& gr, f4 gate,
+                                       size_t off, int n, int h, int w, int ca) {
+  const f4 raw = *reinterpret_cast<const f4*>(y.data + off);
+  f4 e = *reinterpret_cast<const f4*>(g.dz + off) * gate;
+  const f4 u = raw * xf.sc + xf.sh;
+  const f4 dl = (f4){u.x > 0.f ? 1.f : xf.sl.x, u.y > 0.f ? 1.f : xf.sl.y, u.z > 0.f ? 1.f : xf.sl.z, u.w > 0.f ? 1.f : xf.sl.w};
+  if (g.dpool) e += lhn_dpool_sum(g, y, n, h, w, ca);
+  const f4 du = e * dl;
+  return gr.A * du + gr.B * raw + gr.Cc;
+}
+
+// dgrad: block = persistent over INPUT rows (n, hi); thread = (c4, pixel lane)
+template <int K>
 __global__ void __launch_bounds__(256) k_dw_bwd_data(lhn_view x, const float* __restrict__ w, lhn_view y, lhn_gradview gy,
-                                                     float* __restrict__ dx, int accumulate, int K, int stride, int pad,
-                                                     int dil) {
+                                                     float* __restrict__ dx, int accumulate, int stride, int pad, int dil) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int C = x.C, C4 = C >> 2, KK = K * K;
+  const int C = x.C, C4 = C >> 2;
+  constexpr int KK = K * K;
   float* Ws = smem;
   const int tid = threadIdx.x;
   for (int i = tid; i < KK * C; i += 256) {
@@ -198,33 +232,41 @@ __global__ void __launch_bounds__(256) k_dw_bwd_data(lhn_view x, const float* __
   const int cx = x.coff + 4 * c4, cy = y.coff + 4 * c4;
   const Xf4 yxf = lhn_load_xf(y, cy);
   const Gr4 ygr = lhn_load_coef(gy, y.cstride, cy);
-  const int64_t total = (int64_t)x.N * x.H * x.W;
-  for (int64_t pix = (int64_t)blockIdx.x * PL + pl; pix < total; pix += (int64_t)gridDim.x * PL) {
-    const int wi = (int)(pix % x.W);
-    const int64_t t = pix / x.W;
-    const int hi = (int)(t % x.H), n = (int)(t / x.H);
-    f4 acc = (f4){0.f, 0.f, 0.f, 0.f};
-    for (int kh = 0; kh < K; ++kh) {
-      const int hn = hi + pad - kh * dil;
-      if (hn < 0 || hn % stride) continue;
-      const int ho = hn / stride;
-      if (ho >= y.H) continue;
-      for (int kw = 0; kw < K; ++kw) {
-        const int wn = wi + pad - kw * dil;
-        if (wn < 0 || wn % stride) continue;
-        const int wo = wn / stride;
-        if (wo >= y.W) continue;
-        const f4 dy = dw_load_dy(y, gy, yxf, ygr, ((int64_t)n * y.H + ho) * y.W + wo, n, ho, wo, cy);
-        acc += dy * *reinterpret_cast<const f4*>(Ws + (kh * K + kw) * C + 4 * c4);
+  f4 wt[KK];
+#pragma unroll
+  for (int t = 0; t < KK; ++t) wt[t] = *reinterpret_cast<const f4*>(Ws + t * C + 4 * c4);
+  const int rows = x.N * x.H;
+  for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+    const int n = row / x.H, hi = row - n * x.H;
+    f4 gate = (f4){1.f, 1.f, 1.f, 1.f};
+    if (y.gate) gate = *reinterpret_cast<const f4*>(y.gate + (size_t)n * y.cstride + cy);
+    float* dxr = dx + (size_t)row * x.W * x.cstride + cx;
+    for (int wi = pl; wi < x.W; wi += PL) {
+      f4 acc = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kh = 0; kh < K; ++kh) {
+        const int hn = hi + pad - kh * dil;
+        if (hn < 0 || (stride > 1 && hn % stride)) continue;
+        const int ho = hn / stride;
+        if (ho >= y.H) continue;
+#pragma unroll
+        for (int kw = 0; kw < K; ++kw) {
+          const int wn = wi + pad - kw * dil;
+          if (wn < 0 || (stride > 1 && wn % stride)) continue;
+          const int wo = wn / stride;
+          if (wo >= y.W) continue;
+          const size_t off = ((size_t)(n * y.H + ho) * y.W + wo) * y.cstride + cy;
+          acc += dw_dy_at(y, gy, yxf, ygr, gate, off, n, ho, wo, cy) * wt[kh * K + kw];
+        }
       }
+      float* o = dxr + wi * x.cstride;
+      if (accumulate) acc += *reinterpret_cast<const f4*>(o);
+      *reinterpret_cast<f4*>(o) = acc;
     }
-    float* o = dx + pix * x.cstride + cx;
-    if (accumulate) acc += *reinterpret_cast<const f4*>(o);
-    *reinterpret_cast<f4*>(o) = acc;
   }
 }
 
-// wgrad: one thread = 4 channels, grid-stride over OUTPUT pixels; KR kernel rows [kh0, kh0+KR) per launch
+// wgrad: block = persistent over OUTPUT rows; thread = (c4, pixel lane); KR kernel rows [kh0, kh0+KR) per launch
 template <int K, int KR>
 __global__ void __launch_bounds__(256) k_dw_bwd_weight(lhn_view x, lhn_view y, lhn_gradview gy, float* __restrict__ dw,
                                                        int stride, int pad, int dil, int kh0) {
@@ -237,21 +279,28 @@ __global__ void __launch_bounds__(256) k_dw_bwd_weight(lhn_view x, lhn_view y, l
   f4 acc[KR * K];
 #pragma unroll
   for (int i = 0; i < KR * K; ++i) acc[i] = (f4){0.f, 0.f, 0.f, 0.f};
-  const int64_t total = (int64_t)y.N * y.H * y.W;
-  for (int64_t pix = (int64_t)blockIdx.x * PL + pl; pix < total; pix += (int64_t)gridDim.x * PL) {
-    const int wo = (int)(pix % y.W);
-    const int64_t t = pix / y.W;
-    const int ho = (int)(t % y.H), n = (int)(t / y.H);
-    const f4 dy = dw_load_dy(y, gy, yxf, ygr, pix, n, ho, wo, cy);
+  const int rows = y.N * y.H;
+  for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+    const int n = row / y.H, ho = row - n * y.H;
+    f4 ygate = (f4){1.f, 1.f, 1.f, 1.f}, xgate = ygate;
+    if (y.gate) ygate = *reinterpret_cast<const f4*>(y.gate + (size_t)n * y.cstride + cy);
+    if (x.gate) xgate = *reinterpret_cast<const f4*>(x.gate + (size_t)n * x.cstride + cx);
+    const float* xin = x.data + (size_t)n * x.H * x.W * x.cstride + cx;
+    for (int wo = pl; wo < y.W; wo += PL) {
+      const size_t off = ((size_t)row * y.W + wo) * y.cstride + cy;
+      const f4 dy = dw_dy_at(y, gy, yxf, ygr, ygate, off, n, ho, wo, cy);
 #pragma unroll
-    for (int r = 0; r < KR; ++r) {
-      const int ih = ho * stride - pad + (kh0 + r) * dil;
-      if (ih < 0 || ih >= x.H) continue;
+      for (int r = 0; r < KR; ++r) {
+        const int ih = ho * stride - pad + (kh0 + r) * dil;
+        if (ih < 0 || ih >= x.H) continue;
+        const float* xr = xin + (size_t)ih * x.W * x.cstride;
 #pragma unroll
-      for (int kw = 0; kw < K; ++kw) {
-        const int iw = wo * stride - pad + kw * dil;
-        if (iw < 0 || iw >= x.W) continue;
-        acc[r * K + kw] += dy * lhn_load_val(x, xxf, ((int64_t)n * x.H + ih) * x.W + iw, n, cx);
+        for (int kw = 0; kw < K; ++kw) {
+          const int iw = wo * stride - pad + kw * dil;
+          if (iw < 0 || iw >= x.W) continue;
+          const f4 raw = *reinterpret_cast<const f4*>(xr + iw * x.cstride);
+          acc[r * K + kw] += dy * (lhn_apply_xf(raw, xxf) * xgate);
+        }
       }
     }
   }
@@ -330,13 +379,15 @@ extern "C" int lhn_conv_dw_bwd(const lhn_view* x, const float* w, const lhn_view
   LHN_CHECK_ARG(x->C == y->C && pow2(x->C) && x->C <= 256, "lhn_conv_dw_bwd: channels");
   LHN_CHECK_ARG(k == 3 || k == 7, "lhn_conv_dw_bwd: k=%d (3 or 7)", k);
   hipStream_t s = (hipStream_t)stream;
-  const int PL = 256 / (x->C / 4);
   if (dx) {
     const size_t lds = (size_t)(k * k * x->C) * 4;
-    hipLaunchKernelGGL(k_dw_bwd_data, dim3(grid_for((int64_t)x->N * x->H * x->W, PL, 8)), dim3(256), lds, s, *x, w, *y, *gy, dx,
-                       dx_accumulate, k, stride, pad, dil);
+    const int g = grid_for((int64_t)x->N * x->H, 1, 8);
+    if (k == 3)
+      hipLaunchKernelGGL((k_dw_bwd_data<3>), dim3(g), dim3(256), lds, s, *x, w, *y, *gy, dx, dx_accumulate, stride, pad, dil);
+    else
+      hipLaunchKernelGGL((k_dw_bwd_data<7>), dim3(g), dim3(256), lds, s, *x, w, *y, *gy, dx, dx_accumulate, stride, pad, dil);
   }
-  const int gw = grid_for((int64_t)y->N * y->H * y->W, PL, 4);
+  const int gw = grid_for((int64_t)y->N * y->H, 1, 4);
   if (k == 3) {
     hipLaunchKernelGGL((k_dw_bwd_weight<3, 3>), dim3(gw), dim3(256), 0, s, *x, *y, *gy, dw, stride, pad, dil, 0);
   } else {

@@ -66,29 +66,43 @@ __device__ __forceinline__ int nearest_src(int d, int in, int out) {
   return s < in - 1 ? s : in - 1;
 }
 __global__ void __launch_bounds__(256) k_ew_fwd(EwSrcs S, int nsrc, lhn_view dst, float out_slope) {
-  const int C4 = dst.C >> 2;
-  const int64_t total = (int64_t)dst.N * dst.H * dst.W * C4;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int c4 = (int)(i % C4);
-    const int64_t pix = i / C4;
-    const int w = (int)(pix % dst.W);
-    const int64_t t = pix / dst.W;
-    const int h = (int)(t % dst.H), n = (int)(t / dst.H);
-    f4 acc = (f4){0.f, 0.f, 0.f, 0.f};
+  const int C4 = dst.C >> 2, c4 = threadIdx.x % C4, pl = threadIdx.x / C4, PL = 256 / C4;
+  const int rows = dst.N * dst.H;
+  Xf4 xf[3];
+  int ca[3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      if (k >= nsrc) break;
-      const lhn_view& v = S.v[k];
-      const int hs = nearest_src(h, v.H, dst.H), ws = nearest_src(w, v.W, dst.W);
-      const int ca = v.coff + 4 * c4;
-      const Xf4 xf = lhn_load_xf(v, ca);
-      acc += lhn_load_val(v, xf, ((int64_t)n * v.H + hs) * v.W + ws, n, ca);
+  for (int k = 0; k < 3; ++k)
+    if (k < nsrc) {
+      ca[k] = S.v[k].coff + 4 * c4;
+      xf[k] = lhn_load_xf(S.v[k], ca[k]);
     }
-    acc.x = lhn_lrelu(acc.x, out_slope);
-    acc.y = lhn_lrelu(acc.y, out_slope);
-    acc.z = lhn_lrelu(acc.z, out_slope);
-    acc.w = lhn_lrelu(acc.w, out_slope);
-    *reinterpret_cast<f4*>(dst.data + pix * dst.cstride + dst.coff + 4 * c4) = acc;
+  for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+    const int n = row / dst.H, h = row - n * dst.H;
+    const float* base[3];
+    f4 gate[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if (k < nsrc) {
+        const lhn_view& v = S.v[k];
+        const int hs = nearest_src(h, v.H, dst.H);
+        base[k] = v.data + ((size_t)(n * v.H + hs) * v.W) * v.cstride + ca[k];
+        gate[k] = v.gate ? *reinterpret_cast<const f4*>(v.gate + (size_t)n * v.cstride + ca[k]) : (f4){1.f, 1.f, 1.f, 1.f};
+      }
+    float* out = dst.data + (size_t)row * dst.W * dst.cstride + dst.coff + 4 * c4;
+    for (int w = pl; w < dst.W; w += PL) {
+      f4 acc = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        if (k < nsrc) {
+          const int ws = nearest_src(w, S.v[k].W, dst.W);
+          acc += lhn_apply_xf(*reinterpret_cast<const f4*>(base[k] + (size_t)ws * S.v[k].cstride), xf[k]) * gate[k];
+        }
+      acc.x = lhn_lrelu(acc.x, out_slope);
+      acc.y = lhn_lrelu(acc.y, out_slope);
+      acc.z = lhn_lrelu(acc.z, out_slope);
+      acc.w = lhn_lrelu(acc.w, out_slope);
+      *reinterpret_cast<f4*>(out + (size_t)w * dst.cstride) = acc;
+    }
   }
 }
 
@@ -97,69 +111,64 @@ __global__ void __launch_bounds__(256) k_ew_fwd(EwSrcs S, int nsrc, lhn_view dst
 __global__ void __launch_bounds__(256) k_ew_bwd_src(lhn_view src, lhn_view dst, const float* __restrict__ ddst,
                                                     const float* __restrict__ dst_dpool, float out_slope,
                                                     float* __restrict__ dsrc, int accumulate) {
-  const int C4 = src.C >> 2;
-  const int64_t total = (int64_t)src.N * src.H * src.W * C4;
+  const int C4 = src.C >> 2, c4 = threadIdx.x % C4, pl = threadIdx.x / C4, PL = 256 / C4;
   const int fh = dst.H / src.H, fw = dst.W / src.W;  // integer fan-out (host checks divisibility)
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int c4 = (int)(i % C4);
-    const int64_t pix = i / C4;
-    const int w = (int)(pix % src.W);
-    const int64_t t = pix / src.W;
-    const int h = (int)(t % src.H), n = (int)(t / src.H);
-    f4 g = (f4){0.f, 0.f, 0.f, 0.f};
-    const int cd = dst.coff + 4 * c4;
-    for (int a = 0; a < fh; ++a)
-      for (int b = 0; b < fw; ++b) {
-        const int hd = h * fh + a, wd = w * fw + b;
-        const int64_t pd = ((int64_t)n * dst.H + hd) * dst.W + wd;
-        f4 e = *reinterpret_cast<const f4*>(ddst + pd * dst.cstride + cd);
-        if (dst.gate) e *= *reinterpret_cast<const f4*>(dst.gate + (int64_t)n * dst.cstride + cd);
-        if (dst_dpool) {
-          lhn_gradview gv{nullptr, dst_dpool, nullptr};
-          e += lhn_dpool_sum(gv, dst, n, hd, wd, cd);
+  const int cd = dst.coff + 4 * c4;
+  const int rows = src.N * src.H;
+  for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+    const int n = row / src.H, h = row - n * src.H;
+    const f4 gate = dst.gate ? *reinterpret_cast<const f4*>(dst.gate + (size_t)n * dst.cstride + cd) : (f4){1.f, 1.f, 1.f, 1.f};
+    for (int w = pl; w < src.W; w += PL) {
+      f4 g = (f4){0.f, 0.f, 0.f, 0.f};
+      for (int a = 0; a < fh; ++a)
+        for (int b = 0; b < fw; ++b) {
+          const int hd = h * fh + a, wd = w * fw + b;
+          const size_t pd = ((size_t)(n * dst.H + hd) * dst.W + wd) * dst.cstride + cd;
+          f4 e = *reinterpret_cast<const f4*>(ddst + pd) * gate;
+          if (dst_dpool) {
+            lhn_gradview gv{nullptr, dst_dpool, nullptr};
+            e += lhn_dpool_sum(gv, dst, n, hd, wd, cd);
+          }
+          if (out_slope != 1.f) {
+            const f4 o = *reinterpret_cast<const f4*>(dst.data + pd);
+            e.x *= o.x > 0.f ? 1.f : out_slope;
+            e.y *= o.y > 0.f ? 1.f : out_slope;
+            e.z *= o.z > 0.f ? 1.f : out_slope;
+            e.w *= o.w > 0.f ? 1.f : out_slope;
+          }
+          g += e;
         }
-        if (out_slope != 1.f) {
-          const f4 o = *reinterpret_cast<const f4*>(dst.data + pd * dst.cstride + cd);
-          e.x *= o.x > 0.f ? 1.f : out_slope;
-          e.y *= o.y > 0.f ? 1.f : out_slope;
-          e.z *= o.z > 0.f ? 1.f : out_slope;
-          e.w *= o.w > 0.f ? 1.f : out_slope;
-        }
-        g += e;
-      }
-    float* o = dsrc + pix * src.cstride + src.coff + 4 * c4;
-    if (accumulate) g += *reinterpret_cast<const f4*>(o);
-    *reinterpret_cast<f4*>(o) = g;
+      float* o = dsrc + ((size_t)row * src.W + w) * src.cstride + src.coff + 4 * c4;
+      if (accumulate) g += *reinterpret_cast<const f4*>(o);
+      *reinterpret_cast<f4*>(o) = g;
+    }
   }
 }
 
 // ------------------------------------------------------------------ 2x2 stride-2 max pool (ceil_mode)
 __global__ void __launch_bounds__(256) k_maxpool2_fwd(lhn_view x, lhn_view y) {
-  const int C4 = y.C >> 2;
-  const int64_t total = (int64_t)y.N * y.H * y.W * C4;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int c4 = (int)(i % C4);
-    const int64_t pix = i / C4;
-    const int wo = (int)(pix % y.W);
-    const int64_t t = pix / y.W;
-    const int ho = (int)(t % y.H), n = (int)(t / y.H);
-    const int ca = x.coff + 4 * c4;
-    const Xf4 xf = lhn_load_xf(x, ca);
-    f4 m = (f4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  const int C4 = y.C >> 2, c4 = threadIdx.x % C4, pl = threadIdx.x / C4, PL = 256 / C4;
+  const int ca = x.coff + 4 * c4;
+  const Xf4 xf = lhn_load_xf(x, ca);
+  const int rows = y.N * y.H;
+  for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+    const int n = row / y.H, ho = row - n * y.H;
+    const f4 gate = x.gate ? *reinterpret_cast<const f4*>(x.gate + (size_t)n * x.cstride + ca) : (f4){1.f, 1.f, 1.f, 1.f};
+    for (int wo = pl; wo < y.W; wo += PL) {
+      f4 m = (f4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        const int ih = 2 * ho + a, iw = 2 * wo + b;
+      for (int o = 0; o < 4; ++o) {
+        const int ih = 2 * ho + (o >> 1), iw = 2 * wo + (o & 1);
         if (ih < x.H && iw < x.W) {
-          const f4 v = lhn_load_val(x, xf, ((int64_t)n * x.H + ih) * x.W + iw, n, ca);
+          const f4 v = lhn_apply_xf(*reinterpret_cast<const f4*>(x.data + ((size_t)(n * x.H + ih) * x.W + iw) * x.cstride + ca), xf) * gate;
           m.x = v.x > m.x || v.x != v.x ? v.x : m.x;
           m.y = v.y > m.y || v.y != v.y ? v.y : m.y;
           m.z = v.z > m.z || v.z != v.z ? v.z : m.z;
           m.w = v.w > m.w || v.w != v.w ? v.w : m.w;
         }
       }
-    *reinterpret_cast<f4*>(y.data + pix * y.cstride + y.coff + 4 * c4) = m;
+      *reinterpret_cast<f4*>(y.data + ((size_t)row * y.W + wo) * y.cstride + y.coff + 4 * c4) = m;
+    }
   }
 }
 // gradient goes to the first window element (scan order) holding the max.  One thread per OUTPUT element
@@ -167,38 +176,37 @@ __global__ void __launch_bounds__(256) k_maxpool2_fwd(lhn_view x, lhn_view y) {
 // depends on two kernels rounding the pending transform identically.
 __global__ void __launch_bounds__(256) k_maxpool2_bwd(lhn_view x, lhn_view y, const float* __restrict__ dy,
                                                       float* __restrict__ dx, int accumulate) {
-  const int C4 = y.C >> 2;
-  const int64_t total = (int64_t)y.N * y.H * y.W * C4;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int c4 = (int)(i % C4);
-    const int64_t po = i / C4;
-    const int wo = (int)(po % y.W);
-    const int64_t t = po / y.W;
-    const int ho = (int)(t % y.H), n = (int)(t / y.H);
-    const int ca = x.coff + 4 * c4;
-    const Xf4 xf = lhn_load_xf(x, ca);
-    const f4 g = *reinterpret_cast<const f4*>(dy + po * y.cstride + y.coff + 4 * c4);
-    f4 m = (f4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-    int arg[4] = {-1, -1, -1, -1};
+  const int C4 = y.C >> 2, c4 = threadIdx.x % C4, pl = threadIdx.x / C4, PL = 256 / C4;
+  const int ca = x.coff + 4 * c4;
+  const Xf4 xf = lhn_load_xf(x, ca);
+  const int rows = y.N * y.H;
+  for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+    const int n = row / y.H, ho = row - n * y.H;
+    const f4 gate = x.gate ? *reinterpret_cast<const f4*>(x.gate + (size_t)n * x.cstride + ca) : (f4){1.f, 1.f, 1.f, 1.f};
+    for (int wo = pl; wo < y.W; wo += PL) {
+      const f4 g = *reinterpret_cast<const f4*>(dy + ((size_t)row * y.W + wo) * y.cstride + y.coff + 4 * c4);
+      f4 m = (f4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      int arg[4] = {-1, -1, -1, -1};
 #pragma unroll
-    for (int o = 0; o < 4; ++o) {
-      const int ih = 2 * ho + (o >> 1), iw = 2 * wo + (o & 1);
-      if (ih < x.H && iw < x.W) {
-        const f4 v = lhn_load_val(x, xf, ((int64_t)n * x.H + ih) * x.W + iw, n, ca);
-        if (v.x > m.x || v.x != v.x || arg[0] < 0) { if (!(m.x != m.x)) { m.x = v.x; arg[0] = o; } }
-        if (v.y > m.y || v.y != v.y || arg[1] < 0) { if (!(m.y != m.y)) { m.y = v.y; arg[1] = o; } }
-        if (v.z > m.z || v.z != v.z || arg[2] < 0) { if (!(m.z != m.z)) { m.z = v.z; arg[2] = o; } }
-        if (v.w > m.w || v.w != v.w || arg[3] < 0) { if (!(m.w != m.w)) { m.w = v.w; arg[3] = o; } }
+      for (int o = 0; o < 4; ++o) {
+        const int ih = 2 * ho + (o >> 1), iw = 2 * wo + (o & 1);
+        if (ih < x.H && iw < x.W) {
+          const f4 v = lhn_apply_xf(*reinterpret_cast<const f4*>(x.data + ((size_t)(n * x.H + ih) * x.W + iw) * x.cstride + ca), xf) * gate;
+          if (v.x > m.x || v.x != v.x || arg[0] < 0) { if (!(m.x != m.x)) { m.x = v.x; arg[0] = o; } }
+          if (v.y > m.y || v.y != v.y || arg[1] < 0) { if (!(m.y != m.y)) { m.y = v.y; arg[1] = o; } }
+          if (v.z > m.z || v.z != v.z || arg[2] < 0) { if (!(m.z != m.z)) { m.z = v.z; arg[2] = o; } }
+          if (v.w > m.w || v.w != v.w || arg[3] < 0) { if (!(m.w != m.w)) { m.w = v.w; arg[3] = o; } }
+        }
       }
-    }
 #pragma unroll
-    for (int o = 0; o < 4; ++o) {
-      const int ih = 2 * ho + (o >> 1), iw = 2 * wo + (o & 1);
-      if (ih < x.H && iw < x.W) {
-        f4 r = (f4){arg[0] == o ? g.x : 0.f, arg[1] == o ? g.y : 0.f, arg[2] == o ? g.z : 0.f, arg[3] == o ? g.w : 0.f};
-        float* q = dx + (((int64_t)n * x.H + ih) * x.W + iw) * x.cstride + ca;
-        if (accumulate) r += *reinterpret_cast<const f4*>(q);
-        *reinterpret_cast<f4*>(q) = r;
+      for (int o = 0; o < 4; ++o) {
+        const int ih = 2 * ho + (o >> 1), iw = 2 * wo + (o & 1);
+        if (ih < x.H && iw < x.W) {
+          f4 r = (f4){arg[0] == o ? g.x : 0.f, arg[1] == o ? g.y : 0.f, arg[2] == o ? g.z : 0.f, arg[3] == o ? g.w : 0.f};
+          float* q = dx + ((size_t)(n * x.H + ih) * x.W + iw) * x.cstride + ca;
+          if (accumulate) r += *reinterpret_cast<const f4*>(q);
+          *reinterpret_cast<f4*>(q) = r;
+        }
       }
     }
   }
@@ -230,57 +238,68 @@ __global__ void __launch_bounds__(256) k_avgpool_fwd(lhn_view x, float* __restri
     *reinterpret_cast<f4*>(out + (int64_t)b * x.C + 4 * threadIdx.x) = t * inv;
   }
 }
-// d(value of x) (+)= sum over bins containing the pixel of dout[bin]/|bin|   (plain x only: no pending act)
+// d(value of x) (+)= sum over bins containing the pixel of dout[bin]/|bin|
 __global__ void __launch_bounds__(256) k_avgpool_bwd(lhn_view x, const float* __restrict__ dout, int OH, int OW,
                                                      float* __restrict__ dx, int accumulate) {
-  const int C4 = x.C >> 2;
-  const int64_t total = (int64_t)x.N * x.H * x.W * C4;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int c4 = (int)(i % C4);
-    const int64_t pix = i / C4;
-    const int w = (int)(pix % x.W);
-    const int64_t t = pix / x.W;
-    const int h = (int)(t % x.H), n = (int)(t / x.H);
-    f4 g = (f4){0.f, 0.f, 0.f, 0.f};
-    for (int oh = 0; oh < OH; ++oh) {
-      const int h0 = (oh * x.H) / OH, h1 = ((oh + 1) * x.H + OH - 1) / OH;
-      if (h < h0 || h >= h1) continue;
-      for (int ow = 0; ow < OW; ++ow) {
-        const int w0 = (ow * x.W) / OW, w1 = ((ow + 1) * x.W + OW - 1) / OW;
-        if (w < w0 || w >= w1) continue;
-        const float inv = 1.f / (float)((h1 - h0) * (w1 - w0));
-        g += *reinterpret_cast<const f4*>(dout + (((int64_t)n * OH + oh) * OW + ow) * x.C + 4 * c4) * inv;
+  const int C4 = x.C >> 2, c4 = threadIdx.x % C4, pl = threadIdx.x / C4, PL = 256 / C4;
+  const int rows = x.N * x.H;
+  for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+    const int n = row / x.H, h = row - n * x.H;
+    for (int w = pl; w < x.W; w += PL) {
+      f4 g = (f4){0.f, 0.f, 0.f, 0.f};
+      for (int oh = 0; oh < OH; ++oh) {
+        const int h0 = (oh * x.H) / OH, h1 = ((oh + 1) * x.H + OH - 1) / OH;
+        if (h < h0 || h >= h1) continue;
+        for (int ow = 0; ow < OW; ++ow) {
+          const int w0 = (ow * x.W) / OW, w1 = ((ow + 1) * x.W + OW - 1) / OW;
+          if (w < w0 || w >= w1) continue;
+          const float inv = 1.f / (float)((h1 - h0) * (w1 - w0));
+          g += *reinterpret_cast<const f4*>(dout + ((size_t)(n * OH + oh) * OW + ow) * x.C + 4 * c4) * inv;
+        }
       }
+      float* o = dx + ((size_t)row * x.W + w) * x.cstride + x.coff + 4 * c4;
+      if (accumulate) g += *reinterpret_cast<const f4*>(o);
+      *reinterpret_cast<f4*>(o) = g;
     }
-    float* o = dx + pix * x.cstride + x.coff + 4 * c4;
-    if (accumulate) g += *reinterpret_cast<const f4*>(o);
-    *reinterpret_cast<f4*>(o) = g;
   }
 }
 
 // ------------------------------------------------------------------ channel attention MLP (common.py:40-66)
 // save layout (floats): a[N*C] | ahat[N*C] | h[N*C/2] | g[N*C] | mean[C] | invstd[C]
+// grid = C/32 blocks; thread = (channel lane 0..31, sample lane 0..7)
 __global__ void __launch_bounds__(256) k_ca1(const float* __restrict__ pooled, const float* __restrict__ w3,
                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                              float* __restrict__ rmean, float* __restrict__ rvar, int64_t* __restrict__ nbt,
                                              const float* __restrict__ mask, float* __restrict__ save, int N, int C,
                                              float eps, float momentum, int training) {
+  __shared__ double rs[8][32], rq[8][32];
+  __shared__ float s_sc[32], s_sh[32];
   float* a = save;
   float* ahat = save + (int64_t)N * C;
   float* smean = save + (int64_t)N * C * 3 + (int64_t)N * (C / 2);
   float* sinv = smean + C;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    float wt[9];
+  const int cl = threadIdx.x & 31, nl = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
+  const bool ok = c < C;
+  float wt[9];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) wt[t] = w3[c * 9 + t];
-    double s = 0, q = 0;
-    for (int n = 0; n < N; ++n) {
+  for (int t = 0; t < 9; ++t) wt[t] = ok ? w3[c * 9 + t] : 0.f;
+  double s = 0, q = 0;
+  if (ok)
+    for (int n = nl; n < N; n += 8) {
       float v = 0.f;
 #pragma unroll
       for (int t = 0; t < 9; ++t) v += pooled[((int64_t)n * 9 + t) * C + c] * wt[t];
       a[(int64_t)n * C + c] = v;
       s += v;
       q += (double)v * v;
+    }
+  rs[nl][cl] = s;
+  rq[nl][cl] = q;
+  __syncthreads();
+  if (nl == 0 && ok) {
+    for (int j = 1; j < 8; ++j) {
+      s += rs[j][cl];
+      q += rq[j][cl];
     }
     double mean, var;
     if (training) {
@@ -296,14 +315,19 @@ __global__ void __launch_bounds__(256) k_ca1(const float* __restrict__ pooled, c
     const float invstd = (float)(1.0 / sqrt(var + (double)eps));
     smean[c] = (float)mean;
     sinv[c] = invstd;
-    const float sc = gamma[c] * invstd, sh = beta[c] - (float)mean * sc;
-    for (int n = 0; n < N; ++n) {
+    s_sc[cl] = gamma[c] * invstd;
+    s_sh[cl] = beta[c] - (float)mean * (gamma[c] * invstd);
+  }
+  __syncthreads();
+  if (ok) {
+    const float sc = s_sc[cl], sh = s_sh[cl];
+    for (int n = nl; n < N; n += 8) {
       float v = a[(int64_t)n * C + c] * sc + sh;
       if (mask) v *= mask[(int64_t)n * C + c];
       ahat[(int64_t)n * C + c] = v;
     }
   }
-  if (training && nbt && threadIdx.x == 0) nbt[0] += 1;
+  if (training && nbt && blockIdx.x == 0 && threadIdx.x == 0) nbt[0] += 1;
 }
 __global__ void __launch_bounds__(256) k_ca2(const float* __restrict__ w1, const float* __restrict__ b1,
                                              const float* __restrict__ w2, const float* __restrict__ b2,
@@ -400,34 +424,53 @@ __global__ void __launch_bounds__(256) k_ca_bwd2(const float* __restrict__ w1, c
     dahat[(int64_t)n * C + c] = d;
   }
 }
+// grid = C/32 blocks; thread = (channel lane, sample lane) as in k_ca1
 __global__ void __launch_bounds__(256) k_ca_bwd1(const float* __restrict__ pooled, const float* __restrict__ w3,
                                                  const float* __restrict__ gamma, const float* __restrict__ mask,
                                                  const float* __restrict__ save, const float* __restrict__ dahat,
                                                  float* __restrict__ dpool, int cs, int coff, int H, int W,
                                                  float* __restrict__ dw3, float* __restrict__ dgamma,
                                                  float* __restrict__ dbeta, int N, int C, int training) {
+  __shared__ double rs[8][32], rq[8][32];
+  __shared__ float rw[8][32][9];
   const float* a = save;
   const float* smean = save + (int64_t)N * C * 3 + (int64_t)N * (C / 2);
   const float* sinv = smean + C;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    const float mean = smean[c], invstd = sinv[c], gm = gamma[c];
-    double sd = 0, sdx = 0;
-    for (int n = 0; n < N; ++n) {
+  const int cl = threadIdx.x & 31, nl = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
+  const bool ok = c < C;
+  const float mean = ok ? smean[c] : 0.f, invstd = ok ? sinv[c] : 0.f, gm = ok ? gamma[c] : 0.f;
+  double sd = 0, sdx = 0;
+  if (ok)
+    for (int n = nl; n < N; n += 8) {
       float d = dahat[(int64_t)n * C + c];
       if (mask) d *= mask[(int64_t)n * C + c];
       const float xh = (a[(int64_t)n * C + c] - mean) * invstd;
       sd += d;
       sdx += (double)d * xh;
     }
+  rs[nl][cl] = sd;
+  rq[nl][cl] = sdx;
+  __syncthreads();
+  sd = 0;
+  sdx = 0;
+  for (int j = 0; j < 8; ++j) {
+    sd += rs[j][cl];
+    sdx += rq[j][cl];
+  }
+  if (nl == 0 && ok) {
     dgamma[c] += (float)sdx;
     dbeta[c] += (float)sd;
-    float wt[9], dwt[9];
+  }
+  float wt[9], dwt[9], binv[9];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      wt[t] = w3[c * 9 + t];
-      dwt[t] = 0.f;
-    }
-    for (int n = 0; n < N; ++n) {
+  for (int t = 0; t < 9; ++t) {
+    wt[t] = ok ? w3[c * 9 + t] : 0.f;
+    dwt[t] = 0.f;
+    const int bi = t / 3, bj = t % 3;
+    binv[t] = 1.f / (float)((lhn_bin_hi(bi, H) - lhn_bin_lo(bi, H)) * (lhn_bin_hi(bj, W) - lhn_bin_lo(bj, W)));
+  }
+  if (ok)
+    for (int n = nl; n < N; n += 8) {
       float d = dahat[(int64_t)n * C + c];
       if (mask) d *= mask[(int64_t)n * C + c];
       const float xh = (a[(int64_t)n * C + c] - mean) * invstd;
@@ -436,13 +479,19 @@ __global__ void __launch_bounds__(256) k_ca_bwd1(const float* __restrict__ poole
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         dwt[t] += da * pooled[((int64_t)n * 9 + t) * C + c];
-        const int bi = t / 3, bj = t % 3;
-        const int cnt = (lhn_bin_hi(bi, H) - lhn_bin_lo(bi, H)) * (lhn_bin_hi(bj, W) - lhn_bin_lo(bj, W));
-        dpool[((int64_t)n * 9 + t) * cs + coff + c] = da * wt[t] / (float)cnt;
+        dpool[((int64_t)n * 9 + t) * cs + coff + c] = da * wt[t] * binv[t];
       }
     }
 #pragma unroll
-    for (int t = 0; t < 9; ++t) dw3[c * 9 + t] += dwt[t];
+  for (int t = 0; t < 9; ++t) rw[nl][cl][t] = dwt[t];
+  __syncthreads();
+  if (nl == 0 && ok) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      float v = 0.f;
+      for (int j = 0; j < 8; ++j) v += rw[j][cl][t];
+      dw3[c * 9 + t] += v;
+    }
   }
 }
 
@@ -457,17 +506,22 @@ __global__ void __launch_bounds__(256) k_bn_bwd_reduce(lhn_view y, lhn_gradview 
   const Xf4 xf = lhn_load_xf(y, ca);
   const f4 mean = *reinterpret_cast<const f4*>(save + 4 * c4);
   const f4 inv = *reinterpret_cast<const f4*>(save + y.C + 4 * c4);
-  const int64_t total = (int64_t)y.N * y.H * y.W;
+  const int rows = y.N * y.H;
   f4 s = (f4){0.f, 0.f, 0.f, 0.f}, q = s;
-  for (int64_t pix = (int64_t)blockIdx.x * PL + pl; pix < total; pix += (int64_t)gridDim.x * PL) {
-    const int w = (int)(pix % y.W);
-    const int64_t t = pix / y.W;
-    const int h = (int)(t % y.H), n = (int)(t / y.H);
-    const f4 raw = *reinterpret_cast<const f4*>(y.data + pix * y.cstride + ca);
-    const f4 dz = *reinterpret_cast<const f4*>(g.dz + pix * y.cstride + ca);
-    const f4 du = lhn_grad_du(y, g, xf, raw, dz, n, h, w, ca);
-    s += du;
-    q += du * ((raw - mean) * inv);
+  for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+    const int n = row / y.H, h = row - n * y.H;
+    const f4 gate = y.gate ? *reinterpret_cast<const f4*>(y.gate + (size_t)n * y.cstride + ca) : (f4){1.f, 1.f, 1.f, 1.f};
+    const size_t rbase = (size_t)row * y.W * y.cstride + ca;
+    for (int w = pl; w < y.W; w += PL) {
+      const size_t off = rbase + (size_t)w * y.cstride;
+      const f4 raw = *reinterpret_cast<const f4*>(y.data + off);
+      f4 e = *reinterpret_cast<const f4*>(g.dz + off) * gate;
+      if (g.dpool) e += lhn_dpool_sum(g, y, n, h, w, ca);
+      const f4 u = raw * xf.sc + xf.sh;
+      const f4 du = e * (f4){u.x > 0.f ? 1.f : xf.sl.x, u.y > 0.f ? 1.f : xf.sl.y, u.z > 0.f ? 1.f : xf.sl.z, u.w > 0.f ? 1.f : xf.sl.w};
+      s += du;
+      q += du * ((raw - mean) * inv);
+    }
   }
   red[threadIdx.x * 2] = s;
   red[threadIdx.x * 2 + 1] = q;
@@ -532,8 +586,8 @@ int lhn_ew_fwd(const lhn_view* srcs, int nsrc, const lhn_view* dst, float out_sl
     LHN_CHECK_ARG(lhn_view_ok(&srcs[i]) && srcs[i].C == dst->C && srcs[i].N == dst->N, "lhn_ew_fwd: source %d mismatch", i);
     S.v[i] = srcs[i];
   }
-  const int64_t total = (int64_t)dst->N * dst->H * dst->W * (dst->C / 4);
-  hipLaunchKernelGGL(k_ew_fwd, dim3(grid_cap((total + 255) / 256, 8)), dim3(256), 0, (hipStream_t)stream, S, nsrc, *dst, out_slope);
+  LHN_CHECK_ARG(pow2i(dst->C / 4) && dst->C <= 1024, "lhn_ew_fwd: C=%d", dst->C);
+  hipLaunchKernelGGL(k_ew_fwd, dim3(grid_cap((int64_t)dst->N * dst->H, 8)), dim3(256), 0, (hipStream_t)stream, S, nsrc, *dst, out_slope);
   LHN_CHECK_LAUNCH("lhn_ew_fwd");
   return 0;
 }
@@ -547,8 +601,8 @@ int lhn_ew_bwd(const lhn_view* srcs, int nsrc, const lhn_view* dst, const float*
     const lhn_view* s = &srcs[i];
     LHN_CHECK_ARG(lhn_view_ok(s) && s->C == dst->C, "lhn_ew_bwd: source %d mismatch", i);
     LHN_CHECK_ARG(dst->H % s->H == 0 && dst->W % s->W == 0, "lhn_ew_bwd: non-integer upsample %dx%d -> %dx%d", s->H, s->W, dst->H, dst->W);
-    const int64_t total = (int64_t)s->N * s->H * s->W * (s->C / 4);
-    hipLaunchKernelGGL(k_ew_bwd_src, dim3(grid_cap((total + 255) / 256, 8)), dim3(256), 0, (hipStream_t)stream, *s, *dst, ddst,
+    LHN_CHECK_ARG(pow2i(s->C / 4) && s->C <= 1024, "lhn_ew_bwd: C=%d", s->C);
+    hipLaunchKernelGGL(k_ew_bwd_src, dim3(grid_cap((int64_t)s->N * s->H, 8)), dim3(256), 0, (hipStream_t)stream, *s, *dst, ddst,
                        (const float*)nullptr, out_slope, dsrcs[i], accumulate[i]);
   }
   LHN_CHECK_LAUNCH("lhn_ew_bwd");
@@ -559,8 +613,8 @@ int lhn_ew_bwd2(const lhn_view* src, const lhn_view* dst, const float* ddst, con
                 float* dsrc, int accumulate, void* stream) {
   LHN_CHECK_ARG(lhn_view_ok(src) && lhn_view_ok(dst) && ddst && dsrc && src->C == dst->C, "lhn_ew_bwd2: bad args");
   LHN_CHECK_ARG(dst->H % src->H == 0 && dst->W % src->W == 0, "lhn_ew_bwd2: non-integer upsample");
-  const int64_t total = (int64_t)src->N * src->H * src->W * (src->C / 4);
-  hipLaunchKernelGGL(k_ew_bwd_src, dim3(grid_cap((total + 255) / 256, 8)), dim3(256), 0, (hipStream_t)stream, *src, *dst, ddst,
+  LHN_CHECK_ARG(pow2i(src->C / 4) && src->C <= 1024, "lhn_ew_bwd2: C=%d", src->C);
+  hipLaunchKernelGGL(k_ew_bwd_src, dim3(grid_cap((int64_t)src->N * src->H, 8)), dim3(256), 0, (hipStream_t)stream, *src, *dst, ddst,
                      dst_dpool, out_slope, dsrc, accumulate);
   LHN_CHECK_LAUNCH("lhn_ew_bwd2");
   return 0;
@@ -569,15 +623,15 @@ int lhn_ew_bwd2(const lhn_view* src, const lhn_view* dst, const float* ddst, con
 int lhn_maxpool2_fwd(const lhn_view* x, const lhn_view* y, void* stream) {
   LHN_CHECK_ARG(lhn_view_ok(x) && lhn_view_ok(y) && x->C == y->C, "lhn_maxpool2_fwd: bad views");
   LHN_CHECK_ARG(y->H == (x->H + 1) / 2 && y->W == (x->W + 1) / 2 && y->N == x->N, "lhn_maxpool2_fwd: geometry");
-  const int64_t total = (int64_t)y->N * y->H * y->W * (y->C / 4);
-  hipLaunchKernelGGL(k_maxpool2_fwd, dim3(grid_cap((total + 255) / 256, 8)), dim3(256), 0, (hipStream_t)stream, *x, *y);
+  LHN_CHECK_ARG(pow2i(y->C / 4) && y->C <= 1024, "lhn_maxpool2_fwd: C=%d", y->C);
+  hipLaunchKernelGGL(k_maxpool2_fwd, dim3(grid_cap((int64_t)y->N * y->H, 8)), dim3(256), 0, (hipStream_t)stream, *x, *y);
   LHN_CHECK_LAUNCH("lhn_maxpool2_fwd");
   return 0;
 }
 int lhn_maxpool2_bwd(const lhn_view* x, const lhn_view* y, const float* dy, float* dx, int dx_accumulate, void* stream) {
   LHN_CHECK_ARG(lhn_view_ok(x) && lhn_view_ok(y) && dy && dx && x->C == y->C, "lhn_maxpool2_bwd: bad args");
-  const int64_t total = (int64_t)y->N * y->H * y->W * (y->C / 4);
-  hipLaunchKernelGGL(k_maxpool2_bwd, dim3(grid_cap((total + 255) / 256, 8)), dim3(256), 0, (hipStream_t)stream, *x, *y, dy, dx, dx_accumulate);
+  LHN_CHECK_ARG(pow2i(y->C / 4) && y->C <= 1024, "lhn_maxpool2_bwd: C=%d", y->C);
+  hipLaunchKernelGGL(k_maxpool2_bwd, dim3(grid_cap((int64_t)y->N * y->H, 8)), dim3(256), 0, (hipStream_t)stream, *x, *y, dy, dx, dx_accumulate);
   LHN_CHECK_LAUNCH("lhn_maxpool2_bwd");
   return 0;
 }
@@ -591,8 +645,8 @@ int lhn_avgpool_fwd(const lhn_view* x, float* out, int OH, int OW, void* stream)
 }
 int lhn_avgpool_bwd(const lhn_view* x, const float* dout, int OH, int OW, float* dx, int dx_accumulate, void* stream) {
   LHN_CHECK_ARG(lhn_view_ok(x) && dout && dx, "lhn_avgpool_bwd: bad args");
-  const int64_t total = (int64_t)x->N * x->H * x->W * (x->C / 4);
-  hipLaunchKernelGGL(k_avgpool_bwd, dim3(grid_cap((total + 255) / 256, 8)), dim3(256), 0, (hipStream_t)stream, *x, dout, OH, OW, dx, dx_accumulate);
+  LHN_CHECK_ARG(pow2i(x->C / 4) && x->C <= 1024, "lhn_avgpool_bwd: C=%d", x->C);
+  hipLaunchKernelGGL(k_avgpool_bwd, dim3(grid_cap((int64_t)x->N * x->H, 8)), dim3(256), 0, (hipStream_t)stream, *x, dout, OH, OW, dx, dx_accumulate);
   LHN_CHECK_LAUNCH("lhn_avgpool_bwd");
   return 0;
 }
@@ -604,7 +658,7 @@ int lhn_ca_mlp_fwd(const float* pooled, const float* w3, const float* gamma, con
   LHN_CHECK_ARG(pooled && w3 && gamma && beta && rmean && rvar && w1 && b1 && w2 && b2 && gate && save, "lhn_ca_mlp_fwd: null pointer");
   LHN_CHECK_ARG(C > 0 && C <= 256 && C % 2 == 0 && N > 0, "lhn_ca_mlp_fwd: C=%d (<=256)", C);
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_ca1, dim3(1), dim3(C <= 128 ? 128 : 256), 0, s, pooled, w3, gamma, beta, rmean, rvar, nbt, dropmask, save, N, C, eps, momentum, training);
+  hipLaunchKernelGGL(k_ca1, dim3((C + 31) / 32), dim3(256), 0, s, pooled, w3, gamma, beta, rmean, rvar, nbt, dropmask, save, N, C, eps, momentum, training);
   hipLaunchKernelGGL(k_ca2, dim3(N), dim3(128), 0, s, w1, b1, w2, b2, save, gate, gate_stride, gate_coff, N, C);
   LHN_CHECK_LAUNCH("lhn_ca_mlp_fwd");
   return 0;
@@ -637,16 +691,14 @@ int lhn_ca_mlp_bwd(const float* pooled, const float* w3, const float* gamma, con
   hipStream_t s = (hipStream_t)stream;
   float* dahat = const_cast<float*>(save) + (int64_t)N * C * 3 + (int64_t)N * (C / 2) + 2 * C;
   hipLaunchKernelGGL(k_ca_bwd2, dim3(N), dim3(256), 0, s, w1, w2, save, dgate, dahat, dw1, db1, dw2, db2, N, C);
-  hipLaunchKernelGGL(k_ca_bwd1, dim3(1), dim3(C <= 128 ? 128 : 256), 0, s, pooled, w3, gamma, dropmask, save, dahat, dpool, cstride, coff, H, W, dw3, dgamma, dbeta, N, C, 1);
+  hipLaunchKernelGGL(k_ca_bwd1, dim3((C + 31) / 32), dim3(256), 0, s, pooled, w3, gamma, dropmask, save, dahat, dpool, cstride, coff, H, W, dw3, dgamma, dbeta, N, C, 1);
   LHN_CHECK_LAUNCH("lhn_ca_mlp_bwd");
   return 0;
 }
 
 int lhn_bn_bwd_reduce(const lhn_view* y, const lhn_gradview* g, const float* save, double* sums, void* stream) {
   LHN_CHECK_ARG(lhn_view_ok(y) && g && g->dz && save && sums && pow2i(y->C / 4) && y->C <= 1024, "lhn_bn_bwd_reduce: bad args");
-  const int PL = 256 / (y->C / 4);
-  const int64_t total = (int64_t)y->N * y->H * y->W;
-  hipLaunchKernelGGL(k_bn_bwd_reduce, dim3(grid_cap((total + PL - 1) / PL, 8)), dim3(256), 0, (hipStream_t)stream, *y, *g, save, sums);
+  hipLaunchKernelGGL(k_bn_bwd_reduce, dim3(grid_cap((int64_t)y->N * y->H, 8)), dim3(256), 0, (hipStream_t)stream, *y, *g, save, sums);
   LHN_CHECK_LAUNCH("lhn_bn_bwd_reduce");
   return 0;
 }
