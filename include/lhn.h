@@ -19,6 +19,9 @@ extern "C" {
 #endif
 
 #define LHN_VERSION 1
+/* cross-block accumulators (BN statistics, BN-backward sums) are replicated to spread atomic traffic:
+ * layout double[LHN_STAT_REPLICAS][2][C]; a block adds into replica (blockIdx % LHN_STAT_REPLICAS). */
+#define LHN_STAT_REPLICAS 32
 
 typedef struct lhn_view {
   float*       data;    /* base of the [N,H,W,cstride] buffer                                        */
@@ -84,7 +87,9 @@ int lhn_loss_balanced_mse_bwd(const float* out, const float* target, const float
  * lhn_conv_stem_*  dense k x k on the 3-channel NCHW image           litehourglass.py:170, liteHandNet.py:175
  * lhn_conv_kxk_*   dense 3x3 (BasicBlock / BottleNeck)               liteHandNet.py:23-54
  * lhn_bn_finalize  train/eval BatchNorm2d statistics -> table        torch.nn.BatchNorm2d semantics
- * stats: double[2][Cout] (sum, sum of squares), accumulated with atomics; caller zeroes.
+ * stats: double[LHN_STAT_REPLICAS][2][Cout] (sum, sum of squares), accumulated with atomics; caller zeroes.
+ * weight gradients: `dw` may be replica 0 of `nrep` partial copies `rep_stride` floats apart (a block adds
+ * into replica blockIdx % nrep; lhn_reduce_replicas folds them); nrep = 1 adds straight into dw.
  */
 int lhn_conv_pw_fwd(const lhn_view* x, const float* w /*[Cout,Cin]*/, const float* bias /*or NULL*/,
                     const lhn_view* y, double* stats /*or NULL*/, int stride, float* y_nchw /*or NULL*/,
@@ -120,13 +125,16 @@ int lhn_bn_bwd_finalize(const double* sums, const float* gamma, const float* sav
                         void* stream);
 int lhn_conv_pw_bwd(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy,
                     float* dx /*grad buffer of x, same geometry, or NULL*/, int dx_accumulate, float* dw,
-                    float* dbias, int stride, const float* dy_nchw, void* stream);
+                    float* dbias, int stride, const float* dy_nchw, int nrep, int64_t rep_stride, void* stream);
 int lhn_conv_dw_bwd(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx,
-                    int dx_accumulate, float* dw, int k, int stride, int pad, int dil, void* stream);
+                    int dx_accumulate, float* dw, int k, int stride, int pad, int dil, int nrep, int64_t rep_stride,
+                    void* stream);
 int lhn_conv_stem_bwd(const float* img, const lhn_view* y, const lhn_gradview* gy, float* dw, int Hi, int Wi,
-                      int k, int stride, int pad, void* stream);
+                      int k, int stride, int pad, int nrep, int64_t rep_stride, void* stream);
 int lhn_conv_kxk_bwd(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx,
-                     int dx_accumulate, float* dw, int stride, void* stream);
+                     int dx_accumulate, float* dw, int stride, int nrep, int64_t rep_stride, void* stream);
+/* out[i] = sum_r part[r*rep_stride + i]  (folds the replicated weight-gradient partials into the flat gradient) */
+int lhn_reduce_replicas(float* out, const float* part, int64_t n, int nrep, int64_t rep_stride, void* stream);
 int lhn_ew_bwd(const lhn_view* srcs, int nsrc, const lhn_view* dst, const float* ddst, float out_slope,
                float* const* dsrcs, const int* accumulate, void* stream);
 /* single-source form used by the plan: dst may carry a gate and a pooled gradient (channel attention) */
@@ -165,7 +173,7 @@ void* lhn_plan_create(const lhn_buf* bufs, int nbufs, const lhn_op* fwd, int nfw
 void  lhn_plan_destroy(void* plan);
 /* io: phase 0 {image NCHW, heatmap NCHW out}; phase 1 {image NCHW, d(heatmap) NCHW} */
 int   lhn_plan_run(void* plan, int phase, void* workspace, void* const* params, void* const* grads,
-                   void* const* io, int training, void* stream);
+                   void* const* io, int training, int grad_replicas, int64_t grad_rep_stride, void* stream);
 
 #ifdef __cplusplus
 }

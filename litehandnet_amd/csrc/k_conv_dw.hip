@@ -37,18 +37,26 @@ __global__ void __launch_bounds__(256) k_dw_fwd(lhn_view x, const float* __restr
     float* yout = y.data + (size_t)row * y.W * y.cstride + cout;
     for (int wo = pl; wo < y.W; wo += PL) {
       f4 acc = (f4){0.f, 0.f, 0.f, 0.f};
+      // branch-free taps: clamped (always in-bounds) addresses, so all K*K loads issue back to back
+      f4 raw[KK];
+      bool ok[KK];
 #pragma unroll
       for (int kh = 0; kh < K; ++kh) {
         const int ih = ho * stride - pad + kh * dil;
-        if (ih < 0 || ih >= x.H) continue;
-        const float* xr = xin + (size_t)ih * x.W * x.cstride;
+        const int ihc = min(max(ih, 0), x.H - 1);
+        const float* xr = xin + (size_t)ihc * x.W * x.cstride;
 #pragma unroll
         for (int kw = 0; kw < K; ++kw) {
           const int iw = wo * stride - pad + kw * dil;
-          if (iw < 0 || iw >= x.W) continue;
-          const f4 raw = *reinterpret_cast<const f4*>(xr + iw * x.cstride);
-          acc += lhn_apply_xf(raw, xf) * gate * wt[kh * K + kw];
+          const int iwc = min(max(iw, 0), x.W - 1);
+          ok[kh * K + kw] = (ih == ihc) && (iw == iwc);
+          raw[kh * K + kw] = *reinterpret_cast<const f4*>(xr + iwc * x.cstride);
         }
+      }
+#pragma unroll
+      for (int t = 0; t < KK; ++t) {
+        const f4 v = lhn_apply_xf(raw[t], xf) * gate;
+        acc += (ok[t] ? v : (f4){0.f, 0.f, 0.f, 0.f}) * wt[t];
       }
       *reinterpret_cast<f4*>(yout + wo * y.cstride) = acc;
       s += acc;
@@ -66,10 +74,11 @@ __global__ void __launch_bounds__(256) k_dw_fwd(lhn_view x, const float* __restr
         sd[0] += a.x; sd[1] += a.y; sd[2] += a.z; sd[3] += a.w;
         qd[0] += b.x; qd[1] += b.y; qd[2] += b.z; qd[3] += b.w;
       }
+      double* st = stats + (size_t)(blockIdx.x % LHN_STAT_REPLICAS) * 2 * C;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        atomicAdd(stats + 4 * tid + j, sd[j]);
-        atomicAdd(stats + C + 4 * tid + j, qd[j]);
+        atomicAdd(st + 4 * tid + j, sd[j]);
+        atomicAdd(st + C + 4 * tid + j, qd[j]);
       }
     }
   }
@@ -140,8 +149,9 @@ __global__ void __launch_bounds__(256) k_stem_fwd(const float* __restrict__ img,
         sd += red[(p * CG + g) * 16 + j];
         qd += red[(p * CG + g) * 16 + 8 + j];
       }
-      atomicAdd(stats + tid, sd);
-      atomicAdd(stats + CO + tid, qd);
+      double* st = stats + (size_t)(blockIdx.x % LHN_STAT_REPLICAS) * 2 * CO;
+      atomicAdd(st + tid, sd);
+      atomicAdd(st + CO + tid, qd);
     }
   }
 }
@@ -269,7 +279,8 @@ __global__ void __launch_bounds__(256) k_dw_bwd_data(lhn_view x, const float* __
 // wgrad: block = persistent over OUTPUT rows; thread = (c4, pixel lane); KR kernel rows [kh0, kh0+KR) per launch
 template <int K, int KR>
 __global__ void __launch_bounds__(256) k_dw_bwd_weight(lhn_view x, lhn_view y, lhn_gradview gy, float* __restrict__ dw,
-                                                       int stride, int pad, int dil, int kh0) {
+                                                       int stride, int pad, int dil, int kh0, int nrep, int64_t rep_stride) {
+  dw += (size_t)(blockIdx.x % nrep) * rep_stride;
   __shared__ f4 red[256];
   const int C4 = x.C >> 2;
   const int tid = threadIdx.x, c4 = tid % C4, pl = tid / C4, PL = 256 / C4;
@@ -288,19 +299,26 @@ __global__ void __launch_bounds__(256) k_dw_bwd_weight(lhn_view x, lhn_view y, l
     const float* xin = x.data + (size_t)n * x.H * x.W * x.cstride + cx;
     for (int wo = pl; wo < y.W; wo += PL) {
       const size_t off = ((size_t)row * y.W + wo) * y.cstride + cy;
-      const f4 dy = dw_dy_at(y, gy, yxf, ygr, ygate, off, n, ho, wo, cy);
+      f4 raw[KR * K];
+      bool ok[KR * K];
 #pragma unroll
       for (int r = 0; r < KR; ++r) {
         const int ih = ho * stride - pad + (kh0 + r) * dil;
-        if (ih < 0 || ih >= x.H) continue;
-        const float* xr = xin + (size_t)ih * x.W * x.cstride;
+        const int ihc = min(max(ih, 0), x.H - 1);
+        const float* xr = xin + (size_t)ihc * x.W * x.cstride;
 #pragma unroll
         for (int kw = 0; kw < K; ++kw) {
           const int iw = wo * stride - pad + kw * dil;
-          if (iw < 0 || iw >= x.W) continue;
-          const f4 raw = *reinterpret_cast<const f4*>(xr + iw * x.cstride);
-          acc[r * K + kw] += dy * (lhn_apply_xf(raw, xxf) * xgate);
+          const int iwc = min(max(iw, 0), x.W - 1);
+          ok[r * K + kw] = (ih == ihc) && (iw == iwc);
+          raw[r * K + kw] = *reinterpret_cast<const f4*>(xr + iwc * x.cstride);
         }
+      }
+      const f4 dy = dw_dy_at(y, gy, yxf, ygr, ygate, off, n, ho, wo, cy);
+#pragma unroll
+      for (int t = 0; t < KR * K; ++t) {
+        const f4 v = lhn_apply_xf(raw[t], xxf) * xgate;
+        acc[t] += dy * (ok[t] ? v : (f4){0.f, 0.f, 0.f, 0.f});
       }
     }
   }
@@ -324,7 +342,9 @@ __global__ void __launch_bounds__(256) k_dw_bwd_weight(lhn_view x, lhn_view y, l
 // stem wgrad: thread = (pixel lane, 4 output channels); T = 3*K*K accumulators of float4
 template <int K>
 __global__ void __launch_bounds__(256) k_stem_bwd(const float* __restrict__ img, lhn_view y, lhn_gradview gy,
-                                                  float* __restrict__ dw, int Hi, int Wi, int stride, int pad) {
+                                                  float* __restrict__ dw, int Hi, int Wi, int stride, int pad, int nrep,
+                                                  int64_t rep_stride) {
+  dw += (size_t)(blockIdx.x % nrep) * rep_stride;
   constexpr int T = 3 * K * K;
   __shared__ f4 red[256];
   const int C4 = y.C >> 2;
@@ -374,7 +394,9 @@ __global__ void __launch_bounds__(256) k_stem_bwd(const float* __restrict__ img,
 }
 
 extern "C" int lhn_conv_dw_bwd(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx,
-                               int dx_accumulate, float* dw, int k, int stride, int pad, int dil, void* stream) {
+                               int dx_accumulate, float* dw, int k, int stride, int pad, int dil, int nrep, int64_t rep_stride,
+                               void* stream) {
+  if (nrep < 1) nrep = 1;
   LHN_CHECK_ARG(lhn_view_ok(x) && lhn_view_ok(y) && w && gy && gy->dz && dw, "lhn_conv_dw_bwd: bad view / null pointer");
   LHN_CHECK_ARG(x->C == y->C && pow2(x->C) && x->C <= 256, "lhn_conv_dw_bwd: channels");
   LHN_CHECK_ARG(k == 3 || k == 7, "lhn_conv_dw_bwd: k=%d (3 or 7)", k);
@@ -389,25 +411,26 @@ extern "C" int lhn_conv_dw_bwd(const lhn_view* x, const float* w, const lhn_view
   }
   const int gw = grid_for((int64_t)y->N * y->H, 1, 4);
   if (k == 3) {
-    hipLaunchKernelGGL((k_dw_bwd_weight<3, 3>), dim3(gw), dim3(256), 0, s, *x, *y, *gy, dw, stride, pad, dil, 0);
+    hipLaunchKernelGGL((k_dw_bwd_weight<3, 3>), dim3(gw), dim3(256), 0, s, *x, *y, *gy, dw, stride, pad, dil, 0, nrep, rep_stride);
   } else {
     for (int kh = 0; kh < 7; ++kh)
-      hipLaunchKernelGGL((k_dw_bwd_weight<7, 1>), dim3(gw), dim3(256), 0, s, *x, *y, *gy, dw, stride, pad, dil, kh);
+      hipLaunchKernelGGL((k_dw_bwd_weight<7, 1>), dim3(gw), dim3(256), 0, s, *x, *y, *gy, dw, stride, pad, dil, kh, nrep, rep_stride);
   }
   LHN_CHECK_LAUNCH("lhn_conv_dw_bwd");
   return 0;
 }
 
 extern "C" int lhn_conv_stem_bwd(const float* img, const lhn_view* y, const lhn_gradview* gy, float* dw, int Hi, int Wi, int k,
-                                 int stride, int pad, void* stream) {
+                                 int stride, int pad, int nrep, int64_t rep_stride, void* stream) {
+  if (nrep < 1) nrep = 1;
   LHN_CHECK_ARG(img && lhn_view_ok(y) && gy && gy->dz && dw, "lhn_conv_stem_bwd: bad view / null pointer");
   LHN_CHECK_ARG(pow2(y->C / 4) && y->C <= 256 && (k == 1 || k == 3), "lhn_conv_stem_bwd: Cout=%d k=%d", y->C, k);
   const int PL = 256 / (y->C / 4);
   const int g = grid_for((int64_t)y->N * y->H * y->W, PL, 4);
   if (k == 3)
-    hipLaunchKernelGGL((k_stem_bwd<3>), dim3(g), dim3(256), 0, (hipStream_t)stream, img, *y, *gy, dw, Hi, Wi, stride, pad);
+    hipLaunchKernelGGL((k_stem_bwd<3>), dim3(g), dim3(256), 0, (hipStream_t)stream, img, *y, *gy, dw, Hi, Wi, stride, pad, nrep, rep_stride);
   else
-    hipLaunchKernelGGL((k_stem_bwd<1>), dim3(g), dim3(256), 0, (hipStream_t)stream, img, *y, *gy, dw, Hi, Wi, stride, pad);
+    hipLaunchKernelGGL((k_stem_bwd<1>), dim3(g), dim3(256), 0, (hipStream_t)stream, img, *y, *gy, dw, Hi, Wi, stride, pad, nrep, rep_stride);
   LHN_CHECK_LAUNCH("lhn_conv_stem_bwd");
   return 0;
 }

@@ -151,8 +151,9 @@ __global__ void __launch_bounds__(256) k_pw_fwd(lhn_view x, const float* __restr
         s += (double)red[(wv * 32 * NT + tid) * 2 + 0];
         q += (double)red[(wv * 32 * NT + tid) * 2 + 1];
       }
-      atomicAdd(stats + tid, s);
-      atomicAdd(stats + cout + tid, q);
+      double* st = stats + (size_t)(blockIdx.x % LHN_STAT_REPLICAS) * 2 * cout;
+      atomicAdd(st + tid, s);
+      atomicAdd(st + cout + tid, q);
     }
   }
 }
@@ -229,7 +230,7 @@ template <int CIN, int NTO>
 __global__ void __launch_bounds__(256) k_pw_bwd(lhn_view x, const float* __restrict__ w, lhn_view y, lhn_gradview gy,
                                                 float* __restrict__ dx, int dx_acc, float* __restrict__ dw,
                                                 float* __restrict__ dbias, int stride, const float* __restrict__ dy_nchw,
-                                                int cout, int M, int ntiles) {
+                                                int cout, int M, int ntiles, int nrep, int64_t rep_stride) {
   constexpr int NTI = CIN / 32;
   constexpr int COP = 32 * NTO;
   constexpr int LDW = CIN + 4, LDY = COP + 4, LDX = CIN + 4;
@@ -377,6 +378,7 @@ __global__ void __launch_bounds__(256) k_pw_bwd(lhn_view x, const float* __restr
   }
 
   // ---- flush dW (C/D layout: row = co within tile, col = lane&31 = ci within tile)
+  dw += (size_t)(blockIdx.x % nrep) * rep_stride;
 #pragma unroll
   for (int t = 0; t < NDW; ++t) {
     const int tl = wave + 4 * t;
@@ -421,7 +423,8 @@ __global__ void __launch_bounds__(256) k_bias_grad_nchw(const float* __restrict_
 
 template <int CIN, int NTO>
 static int launch_pw_bwd(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx, int dx_acc,
-                         float* dw, float* dbias, int stride, const float* dy_nchw, int cout, hipStream_t s) {
+                         float* dw, float* dbias, int stride, const float* dy_nchw, int cout, int nrep, int64_t rep_stride,
+                         hipStream_t s) {
   const int M = y->N * y->H * y->W;
   const int ntiles = (M + 63) / 64;
   constexpr int COP = 32 * NTO;
@@ -442,7 +445,7 @@ static int launch_pw_bwd(const lhn_view* x, const float* w, const lhn_view* y, c
   if (grid > ntiles) grid = ntiles;
   lhn_gradview g = *gy;
   hipLaunchKernelGGL((k_pw_bwd<CIN, NTO>), dim3(grid), dim3(256), lds, s, *x, w, *y, g, dx, dx_acc, dw, dbias, stride, dy_nchw,
-                     cout, M, ntiles);
+                     cout, M, ntiles, nrep, rep_stride);
   if (dbias && dy_nchw)
     hipLaunchKernelGGL(k_bias_grad_nchw, dim3(cout, y->N < 16 ? y->N : 16), dim3(256), 0, s, dy_nchw, dbias, y->N, cout,
                        y->H * y->W);
@@ -450,7 +453,9 @@ static int launch_pw_bwd(const lhn_view* x, const float* w, const lhn_view* y, c
 }
 
 extern "C" int lhn_conv_pw_bwd(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx,
-                               int dx_accumulate, float* dw, float* dbias, int stride, const float* dy_nchw, void* stream) {
+                               int dx_accumulate, float* dw, float* dbias, int stride, const float* dy_nchw, int nrep,
+                               int64_t rep_stride, void* stream) {
+  if (nrep < 1) nrep = 1;
   LHN_CHECK_ARG(lhn_view_ok(x) && w && y && gy && dw, "lhn_conv_pw_bwd: bad view / null pointer");
   LHN_CHECK_ARG(stride == 1 || stride == 2, "lhn_conv_pw_bwd: stride %d", stride);
   LHN_CHECK_ARG(stride == 1 || !dx || dx_accumulate, "lhn_conv_pw_bwd: stride-2 dgrad only accumulates into a zeroed gradient");
@@ -459,7 +464,7 @@ extern "C" int lhn_conv_pw_bwd(const lhn_view* x, const float* w, const lhn_view
   hipStream_t s = (hipStream_t)stream;
   int rc = -1;
 #define PWB_CASE(CI, NTV) \
-  if (x->C == CI && nto == NTV) rc = launch_pw_bwd<CI, NTV>(x, w, y, gy, dx, dx_accumulate, dw, dbias, stride, dy_nchw, cout, s);
+  if (x->C == CI && nto == NTV) rc = launch_pw_bwd<CI, NTV>(x, w, y, gy, dx, dx_accumulate, dw, dbias, stride, dy_nchw, cout, nrep, rep_stride, s);
   PWB_CASE(32, 1) PWB_CASE(32, 2) PWB_CASE(32, 4) PWB_CASE(64, 1) PWB_CASE(64, 2) PWB_CASE(64, 4) PWB_CASE(128, 1)
   PWB_CASE(128, 2) PWB_CASE(128, 4)
 #undef PWB_CASE

@@ -20,8 +20,13 @@ __global__ void k_bn_finalize(const double* __restrict__ stats, const float* __r
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     double mean, var;
     if (training) {
-      mean = stats[c] / count;
-      var = stats[C + c] / count - mean * mean;
+      double s1 = 0, s2 = 0;
+      for (int r = 0; r < LHN_STAT_REPLICAS; ++r) {
+        s1 += stats[(size_t)r * 2 * C + c];
+        s2 += stats[(size_t)r * 2 * C + C + c];
+      }
+      mean = s1 / count;
+      var = s2 / count - mean * mean;
       if (var < 0) var = 0;
       if (rmean) {
         rmean[c] = (float)((1.0 - (double)momentum) * (double)rmean[c] + (double)momentum * mean);
@@ -533,10 +538,11 @@ __global__ void __launch_bounds__(256) k_bn_bwd_reduce(lhn_view y, lhn_gradview 
       sd[0] += a.x; sd[1] += a.y; sd[2] += a.z; sd[3] += a.w;
       qd[0] += b.x; qd[1] += b.y; qd[2] += b.z; qd[3] += b.w;
     }
+    double* st = sums + (size_t)(blockIdx.x % LHN_STAT_REPLICAS) * 2 * y.C;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      atomicAdd(sums + 4 * threadIdx.x + j, sd[j]);
-      atomicAdd(sums + y.C + 4 * threadIdx.x + j, qd[j]);
+      atomicAdd(st + 4 * threadIdx.x + j, sd[j]);
+      atomicAdd(st + y.C + 4 * threadIdx.x + j, qd[j]);
     }
   }
 }
@@ -545,7 +551,11 @@ __global__ void k_bn_bwd_finalize(const double* __restrict__ sums, const float* 
                                   const float* __restrict__ save, float* __restrict__ coef, int cs, int coff, int C,
                                   double count, float* __restrict__ dgamma, float* __restrict__ dbeta) {
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    const double db = sums[c], dg = sums[C + c];
+    double db = 0, dg = 0;
+    for (int r = 0; r < LHN_STAT_REPLICAS; ++r) {
+      db += sums[(size_t)r * 2 * C + c];
+      dg += sums[(size_t)r * 2 * C + C + c];
+    }
     const double mean = save[c], inv = save[C + c], s = (double)(gamma ? gamma[c] : 1.f) * inv;
     coef[coff + c] = (float)s;
     coef[cs + coff + c] = (float)(-s * inv * dg / count);
@@ -555,8 +565,25 @@ __global__ void k_bn_bwd_finalize(const double* __restrict__ sums, const float* 
   }
 }
 
+// out[i] = sum_r part[r][i]
+__global__ void __launch_bounds__(256) k_reduce_replicas(float* __restrict__ out, const float* __restrict__ part, int64_t n4,
+                                                         int nrep, int64_t rep_stride) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    f4 s = *reinterpret_cast<const f4*>(part + 4 * i);
+    for (int r = 1; r < nrep; ++r) s += *reinterpret_cast<const f4*>(part + (size_t)r * rep_stride + 4 * i);
+    *reinterpret_cast<f4*>(out + 4 * i) = s;
+  }
+}
+
 // ------------------------------------------------------------------ C ABI
 extern "C" {
+
+int lhn_reduce_replicas(float* out, const float* part, int64_t n, int nrep, int64_t rep_stride, void* stream) {
+  LHN_CHECK_ARG(out && part && n > 0 && n % 4 == 0 && nrep >= 1 && rep_stride % 4 == 0, "lhn_reduce_replicas: bad args (n and stride multiples of 4)");
+  hipLaunchKernelGGL(k_reduce_replicas, dim3(grid_cap((n / 4 + 255) / 256, 8)), dim3(256), 0, (hipStream_t)stream, out, part, n / 4, nrep, rep_stride);
+  LHN_CHECK_LAUNCH("lhn_reduce_replicas");
+  return 0;
+}
 
 int lhn_bn_finalize(const double* stats, const float* gamma, const float* beta, float* running_mean, float* running_var,
                     int64_t* nbt, float* table, int cstride, int coff, int C, float* save, double count, float eps,

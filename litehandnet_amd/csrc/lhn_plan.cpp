@@ -69,7 +69,9 @@ void* lhn_plan_create(const lhn_buf* bufs, int nbufs, const lhn_op* fwd, int nfw
 void lhn_plan_destroy(void* plan) { delete static_cast<Plan*>(plan); }
 
 int lhn_plan_run(void* plan, int phase, void* ws, void* const* params, void* const* grads, void* const* io, int training,
-                 void* stream) {
+                 int grad_replicas, int64_t grad_rep_stride, void* stream) {
+  const int nrep = grad_replicas < 1 ? 1 : grad_replicas;
+  const int64_t rstr = grad_rep_stride;
   LHN_CHECK_ARG(plan && ws && params && io, "lhn_plan_run: null argument");
   LHN_CHECK_ARG(phase == 0 || (phase == 1 && grads), "lhn_plan_run: phase %d", phase);
   const Plan* P = static_cast<const Plan*>(plan);
@@ -175,7 +177,7 @@ int lhn_plan_run(void* plan, int phase, void* ws, void* const* params, void* con
         lhn_view y = mkview(P, ws, o.out_buf, o.out_coff, o.out_C);
         lhn_gradview g = mkgrad(P, ws, o.out_buf, o.i[5] != 0);
         rc = lhn_conv_stem_bwd(static_cast<const float*>(io[0]), &y, &g, prm<float>(grads, o.p[1]), o.i[3], o.i[4], o.i[0],
-                               o.i[1], o.i[2], stream);
+                               o.i[1], o.i[2], nrep, rstr, stream);
         break;
       }
       case OP_PW_BWD: {
@@ -195,7 +197,7 @@ int lhn_plan_run(void* plan, int phase, void* ws, void* const* params, void* con
         }
         float* dx = o.i[2] ? reinterpret_cast<float*>(at(ws, P->bufs[o.in_buf[0]].grad_off)) : nullptr;
         rc = lhn_conv_pw_bwd(&x, prm<const float>(params, o.p[0]), &y, &g, dx, o.i[2] == 2, prm<float>(grads, o.p[1]),
-                             prm<float>(grads, o.p[2]), o.i[0], nchw, stream);
+                             prm<float>(grads, o.p[2]), o.i[0], nchw, nrep, rstr, stream);
         break;
       }
       case OP_DW_BWD: {
@@ -204,7 +206,7 @@ int lhn_plan_run(void* plan, int phase, void* ws, void* const* params, void* con
         lhn_gradview g = mkgrad(P, ws, o.out_buf, o.i[5] != 0);
         float* dx = o.i[4] ? reinterpret_cast<float*>(at(ws, P->bufs[o.in_buf[0]].grad_off)) : nullptr;
         rc = lhn_conv_dw_bwd(&x, prm<const float>(params, o.p[0]), &y, &g, dx, o.i[4] == 2, prm<float>(grads, o.p[1]), o.i[0],
-                             o.i[1], o.i[2], o.i[3], stream);
+                             o.i[1], o.i[2], o.i[3], nrep, rstr, stream);
         break;
       }
       case OP_KXK_BWD: {
@@ -213,7 +215,7 @@ int lhn_plan_run(void* plan, int phase, void* ws, void* const* params, void* con
         lhn_gradview g = mkgrad(P, ws, o.out_buf, o.i[5] != 0);
         float* dx = o.i[2] ? reinterpret_cast<float*>(at(ws, P->bufs[o.in_buf[0]].grad_off)) : nullptr;
         rc = lhn_conv_kxk_bwd(&x, prm<const float>(params, o.p[0]), &y, &g, dx, o.i[2] == 2, prm<float>(grads, o.p[1]), o.i[0],
-                              stream);
+                              nrep, rstr, stream);
         break;
       }
       case OP_BN_BWD: {

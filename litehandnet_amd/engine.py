@@ -4,6 +4,8 @@
 Gradients land in ONE flat fp32 buffer (views of it become `param.grad`), so data-parallel training
 is a single RCCL all-reduce of that buffer (train/spawn_dist.py:49-52 uses DDP's bucketed reducer).
 """
+import ctypes as C
+
 import torch
 from torch import nn
 
@@ -57,8 +59,8 @@ class _PlanFn(torch.autograd.Function):
             raise _lib.LhnError("backward through an eval-mode (running-statistics) plan is not supported")
         if plan.n_bwd == 0:
             raise _lib.LhnError("plan was compiled without a backward pass")
-        eng.flat_grads.zero_()
-        plan.set_grads(eng.grad_views)
+        eng.grad_parts.zero_()
+        plan.set_grads(eng.part_views)
         dx, xc, dnchw = None, None, None
         if eng.full:
             (xc,) = ctx.saved_tensors
@@ -66,7 +68,10 @@ class _PlanFn(torch.autograd.Function):
             dnchw = dout.contiguous()
         else:
             plan.buf_data(plan.pb.out_ref, grad=True).copy_(dout.permute(0, 2, 3, 1))
-        plan.run(1, xc, dnchw, True)
+        plan.run(1, xc, dnchw, True, eng.GRAD_REPLICAS, eng.grad_stride)
+        _lib.check(_lib.lib().lhn_reduce_replicas(_lib.ptr(eng.flat_grads), _lib.ptr(eng.grad_parts),
+                                                  C.c_int64(eng.grad_stride), eng.GRAD_REPLICAS, C.c_int64(eng.grad_stride),
+                                                  _lib.stream()), "lhn_reduce_replicas")
         if not eng.full:
             dx = plan.buf_data(plan.pb.in_ref, grad=True).permute(0, 3, 1, 2).contiguous()
         if ctx.via_autograd:
@@ -76,6 +81,8 @@ class _PlanFn(torch.autograd.Function):
 
 
 class Engine:
+    GRAD_REPLICAS = 16      # weight-gradient partial copies (spreads the cross-block atomic adds)
+
     def __init__(self, module, p_drop=None):
         self.module = module
         self.full = _is_full_model(module)
@@ -98,21 +105,25 @@ class Engine:
 
     def _ensure_grads(self, tensors, device):
         params = [t for t in tensors if isinstance(t, nn.Parameter)]
-        n = sum(p.numel() for p in params)
+        n = sum((p.numel() + 3) // 4 * 4 for p in params)          # every tensor starts 16-byte aligned
         if self.flat_grads is None or self.flat_grads.numel() != n or self.flat_grads.device != device:
             self.flat_grads = torch.zeros(n, dtype=torch.float32, device=device)
+            self.grad_parts = torch.zeros(self.GRAD_REPLICAS * n, dtype=torch.float32, device=device)
+            self.grad_stride = n
             self.anchor = torch.zeros(1, dtype=torch.float32, device=device, requires_grad=True)
-        off, views, pviews, plist = 0, [], [], []
+        off, views, pviews, plist, parts = 0, [], [], [], []
         for t in tensors:
             if isinstance(t, nn.Parameter):
                 v = self.flat_grads[off:off + t.numel()].view_as(t)
-                off += t.numel()
+                parts.append(self.grad_parts[off:off + t.numel()])        # replica 0
+                off += (t.numel() + 3) // 4 * 4
                 views.append(v)
                 pviews.append(v)
                 plist.append(t)
             else:
                 views.append(None)
-        self.grad_views, self.param_grad_views, self.param_list = views, pviews, plist
+                parts.append(None)
+        self.grad_views, self.param_grad_views, self.param_list, self.part_views = views, pviews, plist, parts
 
     def publish_grads(self):
         for p, g in zip(self.param_list, self.param_grad_views):

@@ -27,6 +27,7 @@ STEM, PW, DW, KXK, FINALIZE, EW, MAXPOOL, AVGPOOL, CA_MLP, TABLE_FILL, MEMSET = 
 STEM_BWD, PW_BWD, DW_BWD, KXK_BWD, BN_BWD, EW_BWD, MAXPOOL_BWD, AVGPOOL_BWD, GATE_REDUCE, CA_MLP_BWD = range(101, 111)
 
 ALIGN = 256
+STAT_REPLICAS = 32     # LHN_STAT_REPLICAS in include/lhn.h
 
 
 def _al(n):
@@ -135,10 +136,10 @@ class PlanBuilder:
         rec = dict(op=kind, x=x, out=out, conv=conv, bn=bn, slope=float(slope), k=kh, stride=s, pad=p, dil=d,
                    nchw=nchw_out)
         if bn is not None:
-            rec["stats"] = self._ws("zf", 2 * cout * 8)
+            rec["stats"] = self._ws("zf", STAT_REPLICAS * 2 * cout * 8)
             rec["save"] = self._ws("misc", 2 * cout * 4)
             if self.with_backward:
-                rec["sums"] = self._ws("zb", 2 * cout * 8)
+                rec["sums"] = self._ws("zb", STAT_REPLICAS * 2 * cout * 8)
                 self.bufs[out.buf].coef = True
         self.recs.append(rec)
         return out
@@ -448,7 +449,7 @@ class CompiledPlan:
         for j, g in enumerate(grad_tensors):
             self._grads[j] = 0 if g is None else g.data_ptr()
 
-    def run(self, phase, io0, io1, training):
+    def run(self, phase, io0, io1, training, grad_replicas=1, grad_rep_stride=0):
         self._io[0] = 0 if io0 is None else io0.data_ptr()
         self._io[1] = 0 if io1 is None else io1.data_ptr()
         if phase == 0 and training and self.mask_view is not None:
@@ -456,7 +457,7 @@ class CompiledPlan:
             self.mask_view.bernoulli_(keep).mul_(1.0 / keep)
         L = _lib.lib()
         rc = L.lhn_plan_run(C.c_void_p(self.handle), phase, _lib.ptr(self.ws), self._params, self._grads, self._io,
-                            1 if training else 0, _lib.stream())
+                            1 if training else 0, int(grad_replicas), C.c_int64(int(grad_rep_stride)), _lib.stream())
         _lib.check(rc, "lhn_plan_run")
 
     def __del__(self):

@@ -35,15 +35,16 @@ class FlatParams:
 
     def __init__(self, model):
         self.params = [p for p in model.parameters()]
-        n = sum(p.numel() for p in self.params)
+        # same layout as Engine.flat_grads: every tensor padded to a multiple of 4 floats (16-byte aligned)
+        n = sum((p.numel() + 3) // 4 * 4 for p in self.params)
         dev = self.params[0].device
-        self.flat = torch.empty(n, dtype=torch.float32, device=dev)
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
         off = 0
         for p in self.params:
             k = p.numel()
             self.flat[off:off + k].copy_(p.data.reshape(-1))
             p.data = self.flat[off:off + k].view_as(p)
-            off += k
+            off += (k + 3) // 4 * 4
         self.leaf = nn.Parameter(self.flat, requires_grad=True)   # aliases the same storage
 
     def broadcast(self, src=0):
