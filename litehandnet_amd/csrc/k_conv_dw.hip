@@ -18,7 +18,7 @@ __global__ void __launch_bounds__(256) k_dw_fwd(lhn_view x, const float* __restr
   const int tid = threadIdx.x;
   for (int i = tid; i < KK * C; i += 256) {
     const int c = i / KK, t = i - c * KK;
-    Ws[t * C + c] = w[i];
+    Ws[t * C + c] = w ? w[i] : 1.f;
   }
   __syncthreads();
   const int c4 = tid % C4, pl = tid / C4, PL = 256 / C4;
@@ -167,7 +167,7 @@ static inline bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
 extern "C" int lhn_conv_dw_fwd(const lhn_view* x, const float* w, const lhn_view* y, double* stats, int k, int stride,
                                int pad, int dil, void* stream) {
-  LHN_CHECK_ARG(lhn_view_ok(x) && lhn_view_ok(y) && w, "lhn_conv_dw_fwd: bad view / null pointer");
+  LHN_CHECK_ARG(lhn_view_ok(x) && lhn_view_ok(y) && (w || k == 1), "lhn_conv_dw_fwd: bad view / null pointer (w may be NULL = ones only for k=1)");
   LHN_CHECK_ARG(x->C == y->C && pow2(x->C) && x->C <= 256, "lhn_conv_dw_fwd: channels %d -> %d (power of two <= 256)", x->C, y->C);
   LHN_CHECK_ARG((k == 1 || k == 3 || k == 5 || k == 7) && stride >= 1 && dil >= 1 && pad >= 0, "lhn_conv_dw_fwd: k=%d stride=%d dil=%d", k, stride, dil);
   const int Ho = (x->H + 2 * pad - dil * (k - 1) - 1) / stride + 1, Wo = (x->W + 2 * pad - dil * (k - 1) - 1) / stride + 1;
@@ -235,7 +235,7 @@ __global__ void __launch_bounds__(256) k_dw_bwd_data(lhn_view x, const float* __
   const int tid = threadIdx.x;
   for (int i = tid; i < KK * C; i += 256) {
     const int c = i / KK, t = i - c * KK;
-    Ws[t * C + c] = w[i];
+    Ws[t * C + c] = w ? w[i] : 1.f;
   }
   __syncthreads();
   const int c4 = tid % C4, pl = tid / C4, PL = 256 / C4;
@@ -397,20 +397,26 @@ extern "C" int lhn_conv_dw_bwd(const lhn_view* x, const float* w, const lhn_view
                                int dx_accumulate, float* dw, int k, int stride, int pad, int dil, int nrep, int64_t rep_stride,
                                void* stream) {
   if (nrep < 1) nrep = 1;
-  LHN_CHECK_ARG(lhn_view_ok(x) && lhn_view_ok(y) && w && gy && gy->dz && dw, "lhn_conv_dw_bwd: bad view / null pointer");
+  LHN_CHECK_ARG(lhn_view_ok(x) && lhn_view_ok(y) && gy && gy->dz && ((w && dw) || k == 1), "lhn_conv_dw_bwd: bad view / null pointer");
   LHN_CHECK_ARG(x->C == y->C && pow2(x->C) && x->C <= 256, "lhn_conv_dw_bwd: channels");
-  LHN_CHECK_ARG(k == 3 || k == 7, "lhn_conv_dw_bwd: k=%d (3 or 7)", k);
+  LHN_CHECK_ARG(k == 1 || k == 3 || k == 7, "lhn_conv_dw_bwd: k=%d (1, 3 or 7)", k);
   hipStream_t s = (hipStream_t)stream;
   if (dx) {
     const size_t lds = (size_t)(k * k * x->C) * 4;
     const int g = grid_for((int64_t)x->N * x->H, 1, 8);
     if (k == 3)
       hipLaunchKernelGGL((k_dw_bwd_data<3>), dim3(g), dim3(256), lds, s, *x, w, *y, *gy, dx, dx_accumulate, stride, pad, dil);
+    else if (k == 1)
+      hipLaunchKernelGGL((k_dw_bwd_data<1>), dim3(g), dim3(256), lds, s, *x, w, *y, *gy, dx, dx_accumulate, stride, pad, dil);
     else
       hipLaunchKernelGGL((k_dw_bwd_data<7>), dim3(g), dim3(256), lds, s, *x, w, *y, *gy, dx, dx_accumulate, stride, pad, dil);
   }
   const int gw = grid_for((int64_t)y->N * y->H, 1, 4);
-  if (k == 3) {
+  if (!dw) {
+    // identity depthwise (no weight to learn)
+  } else if (k == 1) {
+    hipLaunchKernelGGL((k_dw_bwd_weight<1, 1>), dim3(gw), dim3(256), 0, s, *x, *y, *gy, dw, stride, pad, dil, 0, nrep, rep_stride);
+  } else if (k == 3) {
     hipLaunchKernelGGL((k_dw_bwd_weight<3, 3>), dim3(gw), dim3(256), 0, s, *x, *y, *gy, dw, stride, pad, dil, 0, nrep, rep_stride);
   } else {
     for (int kh = 0; kh < 7; ++kh)

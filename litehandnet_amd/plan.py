@@ -65,6 +65,14 @@ class _Arena:
         return off
 
 
+class _IdentConv:
+    weight = None
+    bias = None
+
+
+_IDENT = _IdentConv()
+
+
 class PlanBuilder:
     def __init__(self, N, state_index, image_hw=None, with_backward=True, p_drop=0.0):
         self.N = N
@@ -141,6 +149,20 @@ class PlanBuilder:
             if self.with_backward:
                 rec["sums"] = self._ws("zb", STAT_REPLICAS * 2 * cout * 8)
                 self.bufs[out.buf].coef = True
+        self.recs.append(rec)
+        return out
+
+    def bn_only(self, x, bn, slope=1.0):
+        """BatchNorm applied straight to a tensor (RepBlock.rbr_identity, repblocks.py:113-114): lowered as an
+        identity depthwise 1x1 (weights = NULL = ones), which copies the consumed value, takes the batch
+        statistics in its epilogue and leaves the normalisation pending like any other conv+BN."""
+        out = self.new(x.H, x.W, x.C)
+        rec = dict(op=DW, x=x, out=out, conv=_IDENT, bn=bn, slope=float(slope), k=1, stride=1, pad=0, dil=1, nchw=False)
+        rec["stats"] = self._ws("zf", STAT_REPLICAS * 2 * x.C * 8)
+        rec["save"] = self._ws("misc", 2 * x.C * 4)
+        if self.with_backward:
+            rec["sums"] = self._ws("zb", STAT_REPLICAS * 2 * x.C * 8)
+            self.bufs[out.buf].coef = True
         self.recs.append(rec)
         return out
 

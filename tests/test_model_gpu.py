@@ -120,7 +120,7 @@ def test_stem_B(dev):
     _check_block(lh.Stem(128, p_drop=0.0), torch_ref._StemB(128, 0.0), _x(2, 3, 64, 64), dev, no_dx=True)
 
 
-def _model_case(dev, golden_dir, tag, **kw):
+def _model_case(dev, golden_dir, tag, variant="B", **kw):
     """Full variant-B model, forward + TopdownHeatmapLoss + backward.
 
     Arbiter = the oracle in float64.  Bar: the HIP fp32 result must be at least as close to exact arithmetic
@@ -130,7 +130,7 @@ def _model_case(dev, golden_dir, tag, **kw):
     oracle's wherever the reference's fp32 run also does."""
     from litehandnet_amd import get_loss, get_model, heatmap
     g = np.load(os.path.join(golden_dir, f"model_{tag}.npz"))
-    cfg = litehandnet_cfg("B", **kw)
+    cfg = litehandnet_cfg(variant, **kw)
     cfg.MODEL["ca_dropout"] = 0.0
     n, size, seed = int(g["n"]), int(g["size"]), int(g["seed"])
     hs = size // 4
@@ -189,6 +189,70 @@ def test_model_B_256_golden(dev, golden_dir):
 
 def test_model_Bca_64_golden(dev, golden_dir):
     _model_case(dev, golden_dir, "Bca_64", rbu_ca="ca")
+
+
+def test_model_A_64_golden(dev, golden_dir):
+    _model_case(dev, golden_dir, "A_64", variant="A")
+
+
+def test_model_A_256_golden(dev, golden_dir):
+    _model_case(dev, golden_dir, "A_256", variant="A")
+
+
+# ---- variant A blocks (liteHandNet.py)
+@pytest.mark.parametrize("c,stride", [(32, 1), (64, 1), (128, 1), (32, 2), (128, 2)])
+def test_repconv_dense3x3(dev, c, stride):
+    from litehandnet_amd import repblocks
+    _check_block(repblocks.RepConv(c, c, 3, stride, 1, activation=torch.nn.LeakyReLU, inplace=True),
+                 torch_ref.RepConv(c, c, 3, stride, 1, activation=torch.nn.LeakyReLU, inplace=True), _x(3, c, 12, 16), dev)
+
+
+def test_repconv_pointwise_stride2(dev):
+    from litehandnet_amd import repblocks
+    _check_block(repblocks.RepConv(64, 64, 1, 2, 0, activation=None), torch_ref.RepConv(64, 64, 1, 2, 0, activation=None),
+                 _x(3, 64, 12, 16), dev)
+
+
+def test_repblock_dw7_identity(dev):
+    from litehandnet_amd import repblocks
+    _check_block(repblocks.RepBlock(32, 32, 7, 1, 3, groups=32), torch_ref.RepBlock(32, 32, 7, 1, 3, groups=32),
+                 _x(2, 32, 20, 20), dev)
+
+
+def test_dwconv_A(dev):
+    from litehandnet_amd import liteHandNet as la
+    _check_block(la.DWConv(64, 32, padding=2, dilation=2), torch_ref.DWConv(64, 32, 2, 2), _x(2, 64, 16, 16), dev)
+
+
+@pytest.mark.parametrize("red", [2, 4])
+def test_bottleneck(dev, red):
+    from litehandnet_amd import liteHandNet as la
+    _check_block(la.BottleNeck(128, red), torch_ref.BottleNeck(128, red), _x(4, 128, 8, 8), dev)
+
+
+@pytest.mark.parametrize("stride", [1, 2])
+def test_basicblock(dev, stride):
+    from litehandnet_amd import liteHandNet as la
+    _check_block(la.BasicBlock(128, 128, stride), torch_ref.BasicBlock(128, 128, stride), _x(4, 128, 8, 8), dev)
+
+
+@pytest.mark.parametrize("ca", ["none", "ca"])
+def test_msab(dev, ca):
+    from litehandnet_amd import liteHandNet as la
+    _check_block(la.MSAB(128, 128, ca, p_drop=0.0), torch_ref.MSAB(128, 128, ca, p_drop=0.0), _x(4, 128, 16, 16), dev)
+
+
+def test_stem_A(dev):
+    from litehandnet_amd import liteHandNet as la
+    _check_block(la.Stem(128), torch_ref._StemA(128, torch.nn.LeakyReLU), _x(2, 3, 64, 64), dev, no_dx=True)
+
+
+def test_state_dict_contract_A(dev):
+    from litehandnet_amd import get_model
+    cfg = litehandnet_cfg("A")
+    ours, ref = get_model(cfg), torch_ref.get_model(cfg)
+    assert list(ours.state_dict()) == list(ref.state_dict())
+    assert sum(p.numel() for p in ours.parameters()) == 2272981      # test_models_performance.ipynb:247
 
 
 def test_model_B_eval_golden(dev, golden_dir):
