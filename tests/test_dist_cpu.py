@@ -1,0 +1,70 @@
+"""CPU, world_size 2, gloo: the data-parallel pieces of litehandnet_amd.train (flat parameter buffer broadcast +
+one all-reduce(SUM)/world of the flat gradient = DistributedDataParallel semantics, train/spawn_dist.py:49-52)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from litehandnet_amd.train import FlatParams, allreduce_mean_
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)                       # ranks start with DIFFERENT weights
+    model = torch.nn.Sequential(torch.nn.Conv2d(3, 5, 3, padding=1), torch.nn.Conv2d(5, 2, 1))
+    fp = FlatParams(model)
+    fp.broadcast(0)                                     # ... and agree after the broadcast of the flat buffer
+    flat0 = fp.flat.clone()
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(8, 3, 6, 6, generator=g)
+    y = torch.randn(8, 2, 6, 6, generator=g)
+    xs, ys = x[rank::world], y[rank::world]            # shard the batch
+    loss = ((model(xs) - ys) ** 2).mean()
+    loss.backward()
+    # flat gradient in the FlatParams layout (each tensor padded to a multiple of 4 floats)
+    flat_g = torch.zeros_like(fp.flat)
+    off = 0
+    for p in fp.params:
+        flat_g[off:off + p.numel()] = p.grad.reshape(-1)
+        off += (p.numel() + 3) // 4 * 4
+    allreduce_mean_(flat_g)
+    # reference: the full batch on one process
+    torch.manual_seed(100)
+    ref = torch.nn.Sequential(torch.nn.Conv2d(3, 5, 3, padding=1), torch.nn.Conv2d(5, 2, 1))
+    lref = ((ref(x) - y) ** 2).mean()
+    lref.backward()
+    gref = torch.cat([torch.nn.functional.pad(p.grad.reshape(-1), (0, (-p.numel()) % 4)) for p in ref.parameters()])
+    pref = torch.cat([torch.nn.functional.pad(p.data.reshape(-1), (0, (-p.numel()) % 4)) for p in ref.parameters()])
+    ok = torch.allclose(flat0, pref) and torch.allclose(flat_g, gref, rtol=1e-5, atol=1e-7)
+    # the parameters are views of the flat buffer: an update of the single leaf moves every tensor
+    fp.leaf.data.add_(1.0)
+    ok = ok and all(torch.allclose(p.data.reshape(-1), fp.flat[o:o + p.numel()]) for p, o in zip(fp.params, _offsets(fp.params)))
+    out[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def _offsets(params):
+    off, res = 0, []
+    for p in params:
+        res.append(off)
+        off += (p.numel() + 3) // 4 * 4
+    return res
+
+
+def test_flat_allreduce_world2():
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    assert out[0] and out[1]
