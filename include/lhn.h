@@ -73,7 +73,8 @@ int lhn_heatmap_nms(float* hm /*in place*/, float* scratch /*same size*/, int N,
 int lhn_pck_accuracy(const float* pred, const float* gt, const uint8_t* mask /*[N,K]*/,
                      const float* normalize /*[N,2]*/, float thr, float* acc /*[K]*/,
                      float* avg_cnt /*[2]: avg, cnt*/, int N, int K, void* stream);
-/* acc: double[4] = {S_pos, S_neg, n_pos (exact integer < 2^53), unused}; zeroed by the call */
+/* acc: double[68]: [0..3] = {S_pos, S_neg, n_pos (exact integer < 2^53), unused} after the call,
+ * [4..67] = 16 replicated partial-sum slots (spread the atomics); zeroed by the call */
 int lhn_loss_balanced_mse_fwd(const float* out, const float* target, const float* weight /*[N,K]*/,
                               double* acc, float* loss /*[1]*/, int64_t NK, int64_t HW, float loss_weight,
                               int balance, void* stream);

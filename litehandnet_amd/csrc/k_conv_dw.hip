@@ -166,9 +166,9 @@ static inline int grid_for(int64_t items_per_block_total, int per_block, int cap
 }
 static inline bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
-int lhn_dw3_fwd_lds(const lhn_view* x, const float* w, const lhn_view* y, double* stats, int dil, hipStream_t s);
-int lhn_dw3_bwd_lds(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx, int dx_acc,
-                    float* dw, int dil, int nrep, int64_t rep_stride, hipStream_t s);
+int lhn_dwk_fwd_lds(const lhn_view* x, const float* w, const lhn_view* y, double* stats, int k, int dil, hipStream_t s);
+int lhn_dwk_bwd_lds(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx, int dx_acc,
+                    float* dw, int k, int dil, int nrep, int64_t rep_stride, hipStream_t s);
 static bool lhn_dw_force_gather() {
   static int v = -1;
   if (v < 0) {
@@ -188,8 +188,8 @@ extern "C" int lhn_conv_dw_fwd(const lhn_view* x, const float* w, const lhn_view
   const size_t lds = (size_t)(k * k * x->C) * 4 + 256 * 2 * 16;
   const int grid = grid_for((int64_t)y->N * Ho, 1, 8);
   hipStream_t s = (hipStream_t)stream;
-  if (w && k == 3 && stride == 1 && pad == dil && (dil == 1 || dil == 2) && x->C % 32 == 0 && y->W >= 8 && !lhn_dw_force_gather()) {
-    lhn_dw3_fwd_lds(x, w, y, stats, dil, s);
+  if (w && stride == 1 && pad == dil * (k - 1) / 2 && x->C % 32 == 0 && y->W >= 8 && !lhn_dw_force_gather() &&
+      lhn_dwk_fwd_lds(x, w, y, stats, k, dil, s)) {
   } else if (k == 3)
     hipLaunchKernelGGL((k_dw_fwd<3>), dim3(grid), dim3(256), lds, s, *x, w, *y, stats, stride, pad, dil);
   else if (k == 7)
@@ -416,8 +416,8 @@ extern "C" int lhn_conv_dw_bwd(const lhn_view* x, const float* w, const lhn_view
   LHN_CHECK_ARG(x->C == y->C && pow2(x->C) && x->C <= 256, "lhn_conv_dw_bwd: channels");
   LHN_CHECK_ARG(k == 1 || k == 3 || k == 7, "lhn_conv_dw_bwd: k=%d (1, 3 or 7)", k);
   hipStream_t s = (hipStream_t)stream;
-  if (w && dw && k == 3 && stride == 1 && pad == dil && (dil == 1 || dil == 2) && x->C % 32 == 0 && x->W >= 8 && !lhn_dw_force_gather()) {
-    lhn_dw3_bwd_lds(x, w, y, gy, dx, dx_accumulate, dw, dil, nrep, rep_stride, s);
+  if (w && dw && stride == 1 && pad == dil * (k - 1) / 2 && x->C % 32 == 0 && x->W >= 8 && !lhn_dw_force_gather() &&
+      lhn_dwk_bwd_lds(x, w, y, gy, dx, dx_accumulate, dw, k, dil, nrep, rep_stride, s)) {
     LHN_CHECK_LAUNCH("lhn_conv_dw_bwd");
     return 0;
   }
@@ -462,49 +462,43 @@ extern "C" int lhn_conv_stem_bwd(const float* img, const lhn_view* y, const lhn_
 }
 
 // =====================================================================================================
-// LDS-staged 3x3 depthwise (stride 1, dilation DIL, pad DIL) over 32-channel groups.
+// LDS-staged K x K depthwise (stride 1, dilation DIL, pad DIL*(K-1)/2) over 32-channel groups.
 // Block tile = TH x TW output pixels x 32 channels; the (TH+2P) x (TW+2P) input halo tile is loaded ONCE,
 // transformed (pending BN / activation / gate) once, and parked in LDS; every thread (= 4 channels x one
-// output column) then slides down the tile rows with a 3x3 register window (3 ds_read_b128 per output).
-template <int DIL, int TH, int TW>
+// output column) walks down the tile rows (3x3/dil 1: sliding register window, 3 ds_read_b128 per output).
+template <int K, int DIL, int TH, int TW>
 struct DwTile {
-  static constexpr int P = DIL, HH = TH + 2 * P, WW = TW + 2 * P, PIX = HH * WW;
+  static constexpr int P = DIL * (K - 1) / 2, HH = TH + 2 * P, WW = TW + 2 * P, PIX = HH * WW;
 };
 
-template <int DIL>
-__global__ void __launch_bounds__(256) k_dw3_fwd_lds(lhn_view x, const float* __restrict__ w, lhn_view y,
+template <int K, int DIL>
+__global__ void __launch_bounds__(256) k_dwk_fwd_lds(lhn_view x, const float* __restrict__ w, lhn_view y,
                                                      double* __restrict__ stats, int tiles_h, int tiles_w, int cgroups) {
-  constexpr int TH = 8, TW = 32;
-  using T = DwTile<DIL, TH, TW>;
+  constexpr int TH = 8, TW = 32, KK = K * K;
+  using T = DwTile<K, DIL, TH, TW>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   f4* tile = reinterpret_cast<f4*>(smem);                  // [PIX][8] float4
   f4* red = tile + T::PIX * 8;                             // [256][2]
+  f4* wl = red + 512;                                      // [KK][8] weights of this block's channel group
   const int tid = threadIdx.x, c4 = tid & 7, pl = tid >> 3;   // pl = output column 0..31
   const int ntile = y.N * tiles_h * tiles_w * cgroups;
+  const int cg = blockIdx.x % cgroups;                     // grid % cgroups == 0 (host): fixed per block
+  const int cin = x.coff + cg * 32 + 4 * c4, cout = y.coff + cg * 32 + 4 * c4;
+  const Xf4 xf = lhn_load_xf(x, cin);
+  for (int i = tid; i < KK * 8; i += 256) {
+    const int k = i >> 3, cc = cg * 32 + 4 * (i & 7);
+    wl[i] = (f4){w[(cc + 0) * KK + k], w[(cc + 1) * KK + k], w[(cc + 2) * KK + k], w[(cc + 3) * KK + k]};
+  }
   f4 s = (f4){0.f, 0.f, 0.f, 0.f}, q = s;
-  int cg_prev = -1;
-  f4 wt[9];
-  Xf4 xf;
   for (int t = blockIdx.x; t < ntile; t += gridDim.x) {
-    const int cg = t % cgroups;
     int r = t / cgroups;
     const int tw = r % tiles_w;
     r /= tiles_w;
     const int th = r % tiles_h, n = r / tiles_h;
-    const int cin = x.coff + cg * 32 + 4 * c4, cout = y.coff + cg * 32 + 4 * c4;
-    if (cg != cg_prev) {   // grid-stride over tiles keeps cg fixed when gridDim % cgroups == 0 (host guarantees)
-      cg_prev = cg;
-      xf = lhn_load_xf(x, cin);
-#pragma unroll
-      for (int k = 0; k < 9; ++k) {
-        const int cb = cg * 32 + 4 * c4;
-        wt[k] = (f4){w[(cb + 0) * 9 + k], w[(cb + 1) * 9 + k], w[(cb + 2) * 9 + k], w[(cb + 3) * 9 + k]};
-      }
-    }
     const f4 gate = x.gate ? *reinterpret_cast<const f4*>(x.gate + (size_t)n * x.cstride + cin) : (f4){1.f, 1.f, 1.f, 1.f};
     const int h0 = th * TH - T::P, w0 = tw * TW - T::P;
     const float* xin = x.data + (size_t)n * x.H * x.W * x.cstride + cin;
-    __syncthreads();   // previous tile fully consumed
+    __syncthreads();   // previous tile fully consumed (and wl visible)
     for (int i = pl; i < T::PIX; i += 32) {
       const int ph = i / T::WW, pw = i - ph * T::WW;
       const int ih = h0 + ph, iw = w0 + pw;
@@ -516,35 +510,45 @@ __global__ void __launch_bounds__(256) k_dw3_fwd_lds(lhn_view x, const float* __
     __syncthreads();
     const int wo = tw * TW + pl;
     if (wo < y.W) {
-      // register window: rows (ho-P, ho, ho+P) x cols (wo-P, wo, wo+P) in tile coordinates
       const f4* col = tile + (pl + T::P) * 8 + c4;    // centre column of this thread, tile row 0
-      f4 win[3][3];
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 3; ++b) win[a + 1][b] = col[((a * DIL) * T::WW + (b - 1) * DIL) * 8];
       float* yout = y.data + ((size_t)(n * y.H + th * TH) * y.W + wo) * y.cstride + cout;
+      if (K == 3 && DIL == 1) {
+        f4 wt[9];
 #pragma unroll
-      for (int rr = 0; rr < TH; ++rr) {
-        if (DIL == 1) {
+        for (int k = 0; k < 9; ++k) wt[k] = wl[k * 8 + c4];
+        f4 win[3][3];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 3; ++b) win[a + 1][b] = col[(a * T::WW + (b - 1)) * 8];
+#pragma unroll
+        for (int rr = 0; rr < TH; ++rr) {
 #pragma unroll
           for (int b = 0; b < 3; ++b) {
             win[0][b] = win[1][b];
             win[1][b] = win[2][b];
             win[2][b] = col[((rr + 2) * T::WW + (b - 1)) * 8];
           }
-        } else {
+          if (th * TH + rr < y.H) {
+            f4 acc = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int a = 0; a < 3; ++a)
+            for (int a = 0; a < 3; ++a)
 #pragma unroll
-            for (int b = 0; b < 3; ++b) win[a][b] = col[((rr + a * DIL) * T::WW + (b - 1) * DIL) * 8];
+              for (int b = 0; b < 3; ++b) acc += win[a][b] * wt[a * 3 + b];
+            *reinterpret_cast<f4*>(yout + (size_t)rr * y.W * y.cstride) = acc;
+            s += acc;
+            q += acc * acc;
+          }
         }
-        if (th * TH + rr < y.H) {
+      } else {
+        for (int rr = 0; rr < TH; ++rr) {
+          if (th * TH + rr >= y.H) break;
           f4 acc = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int a = 0; a < 3; ++a)
+          for (int a = 0; a < K; ++a)
 #pragma unroll
-            for (int b = 0; b < 3; ++b) acc += win[a][b] * wt[a * 3 + b];
+            for (int b = 0; b < K; ++b)
+              acc += col[((rr + a * DIL) * T::WW + (b * DIL - T::P)) * 8] * wl[(a * K + b) * 8 + c4];
           *reinterpret_cast<f4*>(yout + (size_t)rr * y.W * y.cstride) = acc;
           s += acc;
           q += acc * acc;
@@ -558,8 +562,6 @@ __global__ void __launch_bounds__(256) k_dw3_fwd_lds(lhn_view x, const float* __
     red[tid * 2 + 1] = q;
     __syncthreads();
     if (tid < 8) {
-      // all tiles of this block share one channel group (host: gridDim % cgroups == 0)
-      const int cg = blockIdx.x % cgroups;
       double sd[4] = {0, 0, 0, 0}, qd[4] = {0, 0, 0, 0};
       for (int j = 0; j < 32; ++j) {
         const f4 a = red[(j * 8 + tid) * 2], b = red[(j * 8 + tid) * 2 + 1];
@@ -577,48 +579,44 @@ __global__ void __launch_bounds__(256) k_dw3_fwd_lds(lhn_view x, const float* __
   }
 }
 
-// Fused backward (dgrad + wgrad), same tiling with TH x TW = 8 x 16: the dy halo tile (formed once per element
-// from dz, raw y and the BN-backward coefficients) and the transformed x halo tile sit in LDS.
+// Fused backward (dgrad + wgrad), TH x TW = 8 x 16: the dy halo tile (formed once per element from dz, raw y and
+// the BN-backward coefficients) and the transformed x halo tile sit in LDS.
 //   dx[h,w]   = sum_taps dy[h+P-a*DIL, w+P-b*DIL] * wgt[a][b]
 //   dW[a][b] += sum_{h,w in tile} dy[h,w] * x[h-P+a*DIL, w-P+b*DIL]
-template <int DIL>
-__global__ void __launch_bounds__(256) k_dw3_bwd_lds(lhn_view x, const float* __restrict__ w, lhn_view y, lhn_gradview gy,
+// K = 3 keeps all 9 dW accumulators in registers; K = 7 keeps the per-tile partials in LDS (dws) instead.
+template <int K, int DIL>
+__global__ void __launch_bounds__(256) k_dwk_bwd_lds(lhn_view x, const float* __restrict__ w, lhn_view y, lhn_gradview gy,
                                                      float* __restrict__ dx, int dx_acc, float* __restrict__ dw, int tiles_h,
                                                      int tiles_w, int cgroups, int nrep, int64_t rep_stride) {
-  constexpr int TH = 8, TW = 16;
-  using T = DwTile<DIL, TH, TW>;
+  constexpr int TH = 8, TW = 16, KK = K * K;
+  constexpr bool REGACC = (K == 3);
+  using T = DwTile<K, DIL, TH, TW>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   f4* tdy = reinterpret_cast<f4*>(smem);        // [PIX][8]
   f4* tx = tdy + T::PIX * 8;                    // [PIX][8]
   f4* red = tx + T::PIX * 8;                    // [256]
-  const int tid = threadIdx.x, c4 = tid & 7, pl = tid >> 3;   // pl: column = pl & 15, row parity = pl >> 4
+  f4* wl = red + 256;                           // [KK][8]
+  f4* dws = wl + KK * 8;                        // [KK][8]  (K = 7 only) block-level dW partials
+  const int tid = threadIdx.x, c4 = tid & 7, pl = tid >> 3;
   const int colw = pl & 15, rpar = pl >> 4;
   const int ntile = y.N * tiles_h * tiles_w * cgroups;
-  f4 accw[9];
+  const int cg = blockIdx.x % cgroups;
+  const int cx = x.coff + cg * 32 + 4 * c4, cy = y.coff + cg * 32 + 4 * c4;
+  const Xf4 xxf = lhn_load_xf(x, cx), yxf = lhn_load_xf(y, cy);
+  const Gr4 ygr = lhn_load_coef(gy, y.cstride, cy);
+  for (int i = tid; i < KK * 8; i += 256) {
+    const int k = i >> 3, cc = cg * 32 + 4 * (i & 7);
+    wl[i] = (f4){w[(cc + 0) * KK + k], w[(cc + 1) * KK + k], w[(cc + 2) * KK + k], w[(cc + 3) * KK + k]};
+    if (!REGACC) dws[i] = (f4){0.f, 0.f, 0.f, 0.f};
+  }
+  f4 accw[REGACC ? KK : 1];
 #pragma unroll
-  for (int k = 0; k < 9; ++k) accw[k] = (f4){0.f, 0.f, 0.f, 0.f};
-  int cg_prev = -1;
-  f4 wt[9];
-  Xf4 xxf, yxf;
-  Gr4 ygr;
+  for (int k = 0; k < (REGACC ? KK : 1); ++k) accw[k] = (f4){0.f, 0.f, 0.f, 0.f};
   for (int t = blockIdx.x; t < ntile; t += gridDim.x) {
-    const int cg = t % cgroups;
     int r = t / cgroups;
     const int tw = r % tiles_w;
     r /= tiles_w;
     const int th = r % tiles_h, n = r / tiles_h;
-    const int cx = x.coff + cg * 32 + 4 * c4, cy = y.coff + cg * 32 + 4 * c4;
-    if (cg != cg_prev) {
-      cg_prev = cg;
-      xxf = lhn_load_xf(x, cx);
-      yxf = lhn_load_xf(y, cy);
-      ygr = lhn_load_coef(gy, y.cstride, cy);
-#pragma unroll
-      for (int k = 0; k < 9; ++k) {
-        const int cb = cg * 32 + 4 * c4;
-        wt[k] = (f4){w[(cb + 0) * 9 + k], w[(cb + 1) * 9 + k], w[(cb + 2) * 9 + k], w[(cb + 3) * 9 + k]};
-      }
-    }
     const f4 xgate = x.gate ? *reinterpret_cast<const f4*>(x.gate + (size_t)n * x.cstride + cx) : (f4){1.f, 1.f, 1.f, 1.f};
     const f4 ygate = y.gate ? *reinterpret_cast<const f4*>(y.gate + (size_t)n * y.cstride + cy) : (f4){1.f, 1.f, 1.f, 1.f};
     const int h0 = th * TH - T::P, w0 = tw * TW - T::P;
@@ -627,7 +625,7 @@ __global__ void __launch_bounds__(256) k_dw3_bwd_lds(lhn_view x, const float* __
       const int ph = i / T::WW, pw = i - ph * T::WW;
       const int ih = h0 + ph, iw = w0 + pw;
       f4 vx = (f4){0.f, 0.f, 0.f, 0.f}, vy = vx;
-      if (ih >= 0 && ih < x.H && iw >= 0 && iw < x.W) {     // stride 1, pad = DIL: x and y share their geometry
+      if (ih >= 0 && ih < x.H && iw >= 0 && iw < x.W) {     // stride 1, "same" padding: x and y share their geometry
         const size_t pix = (size_t)(n * x.H + ih) * x.W + iw;
         vx = lhn_apply_xf(*reinterpret_cast<const f4*>(x.data + pix * x.cstride + cx), xxf) * xgate;
         vy = dw_dy_at(y, gy, yxf, ygr, ygate, pix * y.cstride + cy, n, ih, iw, cy);
@@ -637,45 +635,109 @@ __global__ void __launch_bounds__(256) k_dw3_bwd_lds(lhn_view x, const float* __
     }
     __syncthreads();
     const int wcol = tw * TW + colw;
+    if (REGACC) {
 #pragma unroll
-    for (int j = 0; j < TH / 2; ++j) {
-      const int rr = 2 * j + rpar, hh = th * TH + rr;
-      if (wcol < x.W && hh < x.H) {
-        const int centre = ((rr + T::P) * T::WW + colw + T::P) * 8 + c4;
-        const f4 dyc = tdy[centre];
-        f4 accx = (f4){0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < TH / 2; ++j) {
+        const int rr = 2 * j + rpar, hh = th * TH + rr;
+        if (wcol < x.W && hh < x.H) {
+          const int centre = ((rr + T::P) * T::WW + colw + T::P) * 8 + c4;
+          const f4 dyc = tdy[centre];
+          f4 accx = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int a = 0; a < 3; ++a)
+          for (int a = 0; a < K; ++a)
 #pragma unroll
-          for (int b = 0; b < 3; ++b) {
-            const int off = ((a - 1) * DIL * T::WW + (b - 1) * DIL) * 8;
-            accx += tdy[centre - off] * wt[a * 3 + b];      // dy[h + P - a*DIL, w + P - b*DIL] (pad = DIL)
-            accw[a * 3 + b] += dyc * tx[centre + off];      // x[h - P + a*DIL, w - P + b*DIL]
+            for (int b = 0; b < K; ++b) {
+              const int off = ((a * DIL - T::P) * T::WW + (b * DIL - T::P)) * 8;
+              accx += tdy[centre - off] * wl[(a * K + b) * 8 + c4];
+              accw[REGACC ? a * K + b : 0] += dyc * tx[centre + off];
+            }
+          if (dx) {
+            float* o = dx + ((size_t)(n * x.H + hh) * x.W + wcol) * x.cstride + cx;
+            if (dx_acc) accx += *reinterpret_cast<const f4*>(o);
+            *reinterpret_cast<f4*>(o) = accx;
           }
-        if (dx) {
-          float* o = dx + ((size_t)(n * x.H + hh) * x.W + wcol) * x.cstride + cx;
-          if (dx_acc) accx += *reinterpret_cast<const f4*>(o);
-          *reinterpret_cast<f4*>(o) = accx;
         }
+      }
+    } else {
+      // dgrad
+      if (dx)
+        for (int j = 0; j < TH / 2; ++j) {
+          const int rr = 2 * j + rpar, hh = th * TH + rr;
+          if (wcol < x.W && hh < x.H) {
+            const int centre = ((rr + T::P) * T::WW + colw + T::P) * 8 + c4;
+            f4 accx = (f4){0.f, 0.f, 0.f, 0.f};
+            for (int a = 0; a < K; ++a)
+#pragma unroll
+              for (int b = 0; b < K; ++b)
+                accx += tdy[centre - ((a * DIL - T::P) * T::WW + (b * DIL - T::P)) * 8] * wl[(a * K + b) * 8 + c4];
+            float* o = dx + ((size_t)(n * x.H + hh) * x.W + wcol) * x.cstride + cx;
+            if (dx_acc) accx += *reinterpret_cast<const f4*>(o);
+            *reinterpret_cast<f4*>(o) = accx;
+          }
+        }
+      // wgrad: one kernel row at a time, K register accumulators, cross-lane sum through `red`
+      for (int a = 0; a < K; ++a) {
+        f4 ar[K];
+#pragma unroll
+        for (int b = 0; b < K; ++b) ar[b] = (f4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TH / 2; ++j) {
+          const int rr = 2 * j + rpar, hh = th * TH + rr;
+          if (wcol < x.W && hh < x.H) {
+            const int centre = ((rr + T::P) * T::WW + colw + T::P) * 8 + c4;
+            const f4 dyc = tdy[centre];
+#pragma unroll
+            for (int b = 0; b < K; ++b) ar[b] += dyc * tx[centre + ((a * DIL - T::P) * T::WW + (b * DIL - T::P)) * 8];
+          }
+        }
+#pragma unroll
+        for (int b = 0; b < K; ++b) {
+          // reduce over the 32 pixel lanes of each channel lane: xor-shuffle across lanes 8,16,32 then LDS for the 4 waves
+          f4 v = ar[b];
+#pragma unroll
+          for (int o = 8; o < 64; o <<= 1) {
+            v.x += __shfl_xor(v.x, o, 64);
+            v.y += __shfl_xor(v.y, o, 64);
+            v.z += __shfl_xor(v.z, o, 64);
+            v.w += __shfl_xor(v.w, o, 64);
+          }
+          if ((tid & 63) < 8) red[(tid >> 6) * 8 + c4 + 32 * b] = v;
+        }
+        __syncthreads();
+        if (tid < 8 * K) {
+          const int b = tid >> 3, cc = tid & 7;
+          dws[(a * K + b) * 8 + cc] += red[cc + 32 * b] + red[8 + cc + 32 * b] + red[16 + cc + 32 * b] + red[24 + cc + 32 * b];
+        }
+        __syncthreads();
       }
     }
   }
-  // ---- dW: reduce the 32 pixel lanes of each channel lane, then one atomic per (block, channel, tap)
-  const int cg = blockIdx.x % cgroups;
+  // ---- flush dW
   float* dwr = dw + (size_t)((blockIdx.x / cgroups) % nrep) * rep_stride;
+  if (REGACC) {
 #pragma unroll
-  for (int k = 0; k < 9; ++k) {
+    for (int k = 0; k < KK; ++k) {
+      __syncthreads();
+      red[tid] = accw[REGACC ? k : 0];
+      __syncthreads();
+      if (tid < 8) {
+        f4 sacc = (f4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 32; ++j) sacc += red[j * 8 + tid];
+        const int cb = cg * 32 + 4 * tid;
+        atomicAdd(dwr + (cb + 0) * KK + k, sacc.x);
+        atomicAdd(dwr + (cb + 1) * KK + k, sacc.y);
+        atomicAdd(dwr + (cb + 2) * KK + k, sacc.z);
+        atomicAdd(dwr + (cb + 3) * KK + k, sacc.w);
+      }
+    }
+  } else {
     __syncthreads();
-    red[tid] = accw[k];
-    __syncthreads();
-    if (tid < 8) {
-      f4 sacc = (f4){0.f, 0.f, 0.f, 0.f};
-      for (int j = 0; j < 32; ++j) sacc += red[j * 8 + tid];
-      const int cb = cg * 32 + 4 * tid;
-      atomicAdd(dwr + (cb + 0) * 9 + k, sacc.x);
-      atomicAdd(dwr + (cb + 1) * 9 + k, sacc.y);
-      atomicAdd(dwr + (cb + 2) * 9 + k, sacc.z);
-      atomicAdd(dwr + (cb + 3) * 9 + k, sacc.w);
+    for (int i = tid; i < KK * 8; i += 256) {
+      const int k = i >> 3, cb = cg * 32 + 4 * (i & 7);
+      const f4 v = dws[i];
+      atomicAdd(dwr + (cb + 0) * KK + k, v.x);
+      atomicAdd(dwr + (cb + 1) * KK + k, v.y);
+      atomicAdd(dwr + (cb + 2) * KK + k, v.z);
+      atomicAdd(dwr + (cb + 3) * KK + k, v.w);
     }
   }
 }
@@ -688,38 +750,49 @@ static int dw3_grid(int ntile, int cgroups, int per_cu) {
   return g;
 }
 
-int lhn_dw3_fwd_lds(const lhn_view* x, const float* w, const lhn_view* y, double* stats, int dil, hipStream_t s) {
-  const int TH = 8, TW = 32, cg = x->C / 32;
+template <int K, int DIL>
+static void launch_dwk_fwd(const lhn_view* x, const float* w, const lhn_view* y, double* stats, hipStream_t s) {
+  constexpr int TH = 8, TW = 32, P = DIL * (K - 1) / 2;
+  const int cg = x->C / 32;
   const int th = (y->H + TH - 1) / TH, tw = (y->W + TW - 1) / TW, ntile = y->N * th * tw * cg;
-  const size_t lds = (size_t)((TH + 2 * dil) * (TW + 2 * dil) * 8 + 512) * 16;
+  const size_t lds = (size_t)((TH + 2 * P) * (TW + 2 * P) * 8 + 512 + K * K * 8) * 16;
   const int per_cu = lds > 80 * 1024 ? 1 : (lds > 52 * 1024 ? 2 : 3);
-  const int grid = dw3_grid(ntile, cg, per_cu * 2);
-  if (dil == 1) {
-    static bool a1 = false;
-    if (!a1) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dw3_fwd_lds<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); a1 = true; }
-    hipLaunchKernelGGL((k_dw3_fwd_lds<1>), dim3(grid), dim3(256), lds, s, *x, w, *y, stats, th, tw, cg);
-  } else {
-    static bool a2 = false;
-    if (!a2) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dw3_fwd_lds<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); a2 = true; }
-    hipLaunchKernelGGL((k_dw3_fwd_lds<2>), dim3(grid), dim3(256), lds, s, *x, w, *y, stats, th, tw, cg);
+  static bool done = false;
+  if (!done) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwk_fwd_lds<K, DIL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    done = true;
   }
-  return 0;
+  hipLaunchKernelGGL((k_dwk_fwd_lds<K, DIL>), dim3(dw3_grid(ntile, cg, per_cu * 2)), dim3(256), lds, s, *x, w, *y, stats, th, tw, cg);
+}
+template <int K, int DIL>
+static void launch_dwk_bwd(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx, int dx_acc,
+                           float* dw, int nrep, int64_t rep_stride, hipStream_t s) {
+  constexpr int TH = 8, TW = 16, P = DIL * (K - 1) / 2;
+  const int cg = x->C / 32;
+  const int th = (x->H + TH - 1) / TH, tw = (x->W + TW - 1) / TW, ntile = x->N * th * tw * cg;
+  const size_t lds = (size_t)((TH + 2 * P) * (TW + 2 * P) * 16 + 256 + 2 * K * K * 8) * 16;
+  static bool done = false;
+  if (!done) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwk_bwd_lds<K, DIL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    done = true;
+  }
+  hipLaunchKernelGGL((k_dwk_bwd_lds<K, DIL>), dim3(dw3_grid(ntile, cg, 4)), dim3(256), lds, s, *x, w, *y, *gy, dx, dx_acc, dw, th, tw,
+                     cg, nrep, rep_stride);
 }
 
-int lhn_dw3_bwd_lds(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx, int dx_acc,
-                    float* dw, int dil, int nrep, int64_t rep_stride, hipStream_t s) {
-  const int TH = 8, TW = 16, cg = x->C / 32;
-  const int th = (x->H + TH - 1) / TH, tw = (x->W + TW - 1) / TW, ntile = x->N * th * tw * cg;
-  const size_t lds = (size_t)((TH + 2 * dil) * (TW + 2 * dil) * 16 + 256) * 16;
-  const int grid = dw3_grid(ntile, cg, 4);
-  if (dil == 1) {
-    static bool a1 = false;
-    if (!a1) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dw3_bwd_lds<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); a1 = true; }
-    hipLaunchKernelGGL((k_dw3_bwd_lds<1>), dim3(grid), dim3(256), lds, s, *x, w, *y, *gy, dx, dx_acc, dw, th, tw, cg, nrep, rep_stride);
-  } else {
-    static bool a2 = false;
-    if (!a2) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dw3_bwd_lds<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); a2 = true; }
-    hipLaunchKernelGGL((k_dw3_bwd_lds<2>), dim3(grid), dim3(256), lds, s, *x, w, *y, *gy, dx, dx_acc, dw, th, tw, cg, nrep, rep_stride);
-  }
-  return 0;
+// returns 1 if an LDS-tiled kernel was launched
+int lhn_dwk_fwd_lds(const lhn_view* x, const float* w, const lhn_view* y, double* stats, int k, int dil, hipStream_t s) {
+  if (k == 3 && dil == 1) launch_dwk_fwd<3, 1>(x, w, y, stats, s);
+  else if (k == 3 && dil == 2) launch_dwk_fwd<3, 2>(x, w, y, stats, s);
+  else if (k == 7 && dil == 1) launch_dwk_fwd<7, 1>(x, w, y, stats, s);
+  else return 0;
+  return 1;
+}
+int lhn_dwk_bwd_lds(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx, int dx_acc,
+                    float* dw, int k, int dil, int nrep, int64_t rep_stride, hipStream_t s) {
+  if (k == 3 && dil == 1) launch_dwk_bwd<3, 1>(x, w, y, gy, dx, dx_acc, dw, nrep, rep_stride, s);
+  else if (k == 3 && dil == 2) launch_dwk_bwd<3, 2>(x, w, y, gy, dx, dx_acc, dw, nrep, rep_stride, s);
+  else if (k == 7 && dil == 1) launch_dwk_bwd<7, 1>(x, w, y, gy, dx, dx_acc, dw, nrep, rep_stride, s);
+  else return 0;
+  return 1;
 }

@@ -286,13 +286,29 @@ __global__ void __launch_bounds__(256) k_loss_fwd(const float* __restrict__ o, c
   sp = lhn_wave_sum_d(sp);
   sn = lhn_wave_sum_d(sn);
   double npd = lhn_wave_sum_d((double)np);
+  __shared__ double red[4][3];
+  const int wv = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) {
-    atomicAdd(acc + 0, sp);
-    atomicAdd(acc + 1, sn);
-    atomicAdd(acc + 2, npd);
+    red[wv][0] = sp;
+    red[wv][1] = sn;
+    red[wv][2] = npd;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const double v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    atomicAdd(acc + 4 + (blockIdx.x & 15) * 4 + threadIdx.x, v);   // 16 replica slots after the 4 result doubles
   }
 }
-__global__ void k_loss_final(const double* __restrict__ acc, float* __restrict__ loss, double numel, float lw, int balance) {
+__global__ void k_loss_final(double* __restrict__ acc, float* __restrict__ loss, double numel, float lw, int balance) {
+  double t0 = 0, t1 = 0, t2 = 0;
+  for (int r = 0; r < 16; ++r) {
+    t0 += acc[4 + r * 4 + 0];
+    t1 += acc[4 + r * 4 + 1];
+    t2 += acc[4 + r * 4 + 2];
+  }
+  acc[0] = t0;
+  acc[1] = t1;
+  acc[2] = t2;
   const double npos = acc[2], nneg = numel - npos;
   // the reference multiplies float32 loss elements by float32 factors; factors rounded to f32 here too
   const float pf = balance ? mul_rn((float)numel / (float)(npos + 1.0), 0.1f) : 1.f;
@@ -399,7 +415,7 @@ int lhn_loss_balanced_mse_fwd(const float* out, const float* target, const float
   LHN_CHECK_ARG(out && target && weight && acc && loss, "lhn_loss_balanced_mse_fwd: null pointer");
   LHN_CHECK_ARG(NK > 0 && HW > 0 && HW % 4 == 0, "lhn_loss_balanced_mse_fwd: bad shape");
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(acc, 0, 4 * sizeof(double), s) != hipSuccess) {
+  if (hipMemsetAsync(acc, 0, 68 * sizeof(double), s) != hipSuccess) {
     lhn_set_error("lhn_loss_balanced_mse_fwd: memset failed");
     return 2;
   }

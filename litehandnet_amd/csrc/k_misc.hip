@@ -252,10 +252,12 @@ __global__ void __launch_bounds__(256) k_avgpool_bwd(lhn_view x, const float* __
     const int n = row / x.H, h = row - n * x.H;
     for (int w = pl; w < x.W; w += PL) {
       f4 g = (f4){0.f, 0.f, 0.f, 0.f};
-      for (int oh = 0; oh < OH; ++oh) {
+      // bin oh contains h iff floor(oh*H/OH) <= h < ceil((oh+1)*H/OH): candidates are floor(h*OH/H) and its neighbours
+      const int ohc = (h * OH) / x.H, owc = (w * OW) / x.W;
+      for (int oh = max(ohc - 1, 0); oh <= min(ohc + 1, OH - 1); ++oh) {
         const int h0 = (oh * x.H) / OH, h1 = ((oh + 1) * x.H + OH - 1) / OH;
         if (h < h0 || h >= h1) continue;
-        for (int ow = 0; ow < OW; ++ow) {
+        for (int ow = max(owc - 1, 0); ow <= min(owc + 1, OW - 1); ++ow) {
           const int w0 = (ow * x.W) / OW, w1 = ((ow + 1) * x.W + OW - 1) / OW;
           if (w < w0 || w >= w1) continue;
           const float inv = 1.f / (float)((h1 - h0) * (w1 - w0));
@@ -698,9 +700,9 @@ int lhn_gate_bwd_reduce(const lhn_view* y, const float* dz, float* dgate, void* 
     lhn_set_error("lhn_gate_bwd_reduce: memset failed");
     return 2;
   }
-  int split = (y->H * y->W + 1023) / 1024;
+  int split = (y->H * y->W + 127) / 128;
   if (split < 1) split = 1;
-  if (split > 16) split = 16;
+  if (split > 32) split = 32;
   hipLaunchKernelGGL(k_gate_bwd_reduce, dim3(y->N, split), dim3(256), 0, s, *y, dz, dgate);
   LHN_CHECK_LAUNCH("lhn_gate_bwd_reduce");
   return 0;

@@ -41,7 +41,7 @@ class _BalancedMSE(torch.autograd.Function):
             raise _lib.LhnError(f"target shape {tuple(t.shape)} != output shape {tuple(o.shape)}")
         N, K, H, W = o.shape
         w = _lib.f32c(weight).reshape(N, K)
-        acc = torch.empty(4, dtype=torch.float64, device=o.device)
+        acc = torch.empty(68, dtype=torch.float64, device=o.device)
         loss = torch.empty(1, dtype=torch.float32, device=o.device)
         L = _lib.lib()
         _lib.check(L.lhn_loss_balanced_mse_fwd(_lib.ptr(o), _lib.ptr(t), _lib.ptr(w), _lib.ptr(acc), _lib.ptr(loss),
