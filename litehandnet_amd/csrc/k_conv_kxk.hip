@@ -8,7 +8,7 @@
 // Tile geometry, LDS images (+4 float row pad) and fragment maps are those of k_conv_pw.hip.
 #include "lhn_common.h"
 
-template <int KD, int NT, int MODE>
+template <int KD, int NT, int MODE, int TAPS>
 __global__ void __launch_bounds__(256) k_kxk(lhn_view x, const float* __restrict__ w, lhn_view y, lhn_gradview gy,
                                              double* __restrict__ stats, float* __restrict__ dx, int dx_acc, int stride,
                                              int nout, int M, int ntiles) {
@@ -54,17 +54,27 @@ __global__ void __launch_bounds__(256) k_kxk(lhn_view x, const float* __restrict
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
 
-    for (int tap = 0; tap < 9; ++tap) {
-      const int kh = tap / 3, kw = tap - kh * 3;
-      // ---- weights of this tap -> LDS as [n][k]
-      for (int i = tid; i < 32 * NT * KD; i += 256) {
-        const int nn = i / KD, kk = i - nn * KD;
-        float v = 0.f;
-        if (nn < nout) {
-          if (MODE == 0) v = w[((size_t)nn * cin_total + kk) * 9 + tap];            // W[co=nn][ci=kk][tap]
-          else v = w[((size_t)kk * cin_total + nn) * 9 + tap];                      // W[co=kk][ci=nn][tap]
+    for (int tap = 0; tap < TAPS; ++tap) {
+      const int kh = TAPS == 1 ? 1 : tap / 3, kw = TAPS == 1 ? 1 : tap - (tap / 3) * 3;   // 1x1 = centre tap only
+      // ---- weights of this tap -> LDS as [n][k]   (1x1: once per block)
+      if (TAPS > 1 || tile == (int)blockIdx.x) {
+        if (MODE == 0 || TAPS > 1) {
+          for (int i = tid; i < 32 * NT * KD; i += 256) {
+            const int nn = i / KD, kk = i - nn * KD;
+            float v = 0.f;
+            if (nn < nout) {
+              if (MODE == 0) v = w[((size_t)nn * cin_total + kk) * TAPS + tap];        // W[co=nn][ci=kk][tap]
+              else v = w[((size_t)kk * cin_total + nn) * TAPS + tap];                  // W[co=kk][ci=nn][tap]
+            }
+            Ws[nn * LDA + kk] = v;
+          }
+        } else {
+          // 1x1 dgrad: W^T; read rows of W[co=kk][ci=nn] coalesced along ci, scatter into the [n][k] image
+          for (int i = tid; i < KD * 32 * NT; i += 256) {
+            const int kk = i / (32 * NT), nn = i - kk * (32 * NT);
+            Ws[nn * LDA + kk] = nn < nout ? w[(size_t)kk * cin_total + nn] : 0.f;
+          }
         }
-        Ws[nn * LDA + kk] = v;
       }
       // ---- A tile of this tap
 #pragma unroll
@@ -162,7 +172,7 @@ __global__ void __launch_bounds__(256) k_kxk(lhn_view x, const float* __restrict
 }
 
 // wgrad: blockIdx.y = tap.  64-pixel tiles; dYs[m][co], Xs[m][ci] (X shifted by the tap) -> dW_tap += dY^T X.
-template <int CIN, int NTO>
+template <int CIN, int NTO, int TAPS>
 __global__ void __launch_bounds__(256) k_kxk_wgrad(lhn_view x, lhn_view y, lhn_gradview gy, float* __restrict__ dw, int stride,
                                                    int cout, int M, int ntiles, int nrep, int64_t rep_stride) {
   constexpr int NTI = CIN / 32, COP = 32 * NTO, LDY = COP + 4, LDX = CIN + 4;
@@ -171,7 +181,7 @@ __global__ void __launch_bounds__(256) k_kxk_wgrad(lhn_view x, lhn_view y, lhn_g
   float* dYs = smem;               // [64][LDY]
   float* Xs = dYs + 64 * LDY;      // [64][LDX]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
-  const int tap = blockIdx.y, kh = tap / 3, kw = tap - kh * 3;
+  const int tap = blockIdx.y, kh = TAPS == 1 ? 1 : tap / 3, kw = TAPS == 1 ? 1 : tap - (tap / 3) * 3;
   constexpr int XC4 = CIN / 4, XRP = 256 / XC4, XPF = 64 / XRP;
   constexpr int YC4 = COP / 4, YRP = 256 / YC4, YPF = 64 / YRP;
   const int xc4 = tid % XC4, xr0 = tid / XC4, xabs = x.coff + 4 * xc4;
@@ -244,13 +254,13 @@ __global__ void __launch_bounds__(256) k_kxk_wgrad(lhn_view x, lhn_view y, lhn_g
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = 32 * it + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (co < cout) atomicAdd(dw + ((size_t)co * CIN + 32 * jt + l31) * 9 + tap, accw[t][r]);
+        if (co < cout) atomicAdd(dw + ((size_t)co * CIN + 32 * jt + l31) * TAPS + tap, accw[t][r]);
       }
     }
   }
 }
 
-template <int KD, int NT, int MODE>
+template <int KD, int NT, int MODE, int TAPS>
 static int launch_kxk(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, double* stats, float* dx,
                       int dx_acc, int stride, int nout, hipStream_t s) {
   const lhn_view* ov = MODE == 0 ? y : x;
@@ -258,7 +268,7 @@ static int launch_kxk(const lhn_view* x, const float* w, const lhn_view* y, cons
   const size_t lds = (size_t)((32 * NT + 128) * (KD + 4) + 4 * 32 * NT * 2) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kxk<KD, NT, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kxk<KD, NT, MODE, TAPS>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess) {
       lhn_set_error("lhn_conv_kxk: cannot reserve %zu B of LDS", lds);
       return 2;
@@ -272,11 +282,11 @@ static int launch_kxk(const lhn_view* x, const float* w, const lhn_view* y, cons
   if (grid > ntiles) grid = ntiles;
   lhn_gradview g;
   if (gy) g = *gy; else g.dz = g.dpool = g.coef = nullptr;
-  hipLaunchKernelGGL((k_kxk<KD, NT, MODE>), dim3(grid), dim3(256), lds, s, *x, w, *y, g, stats, dx, dx_acc, stride, nout, M, ntiles);
+  hipLaunchKernelGGL((k_kxk<KD, NT, MODE, TAPS>), dim3(grid), dim3(256), lds, s, *x, w, *y, g, stats, dx, dx_acc, stride, nout, M, ntiles);
   return 0;
 }
 
-template <int CIN, int NTO>
+template <int CIN, int NTO, int TAPS>
 static int launch_kxk_wgrad(const lhn_view* x, const lhn_view* y, const lhn_gradview* gy, float* dw, int stride, int nrep,
                             int64_t rep_stride, hipStream_t s) {
   const int M = y->N * y->H * y->W, ntiles = (M + 63) / 64;
@@ -284,17 +294,20 @@ static int launch_kxk_wgrad(const lhn_view* x, const lhn_view* y, const lhn_grad
   const size_t lds = (size_t)(64 * (COP + 4) + 64 * (CIN + 4)) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kxk_wgrad<CIN, NTO>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kxk_wgrad<CIN, NTO, TAPS>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess) {
       lhn_set_error("lhn_conv_kxk_bwd: cannot reserve %zu B of LDS", lds);
       return 2;
     }
     attr_done = true;
   }
-  int grid = lhn_num_cus() / 4;      // x 9 taps
+  int per_cu = (int)((160 * 1024) / lds);
+  if (per_cu > 3) per_cu = 3;
+  if (per_cu < 1) per_cu = 1;
+  int grid = TAPS == 1 ? lhn_num_cus() * per_cu : lhn_num_cus() / 4;      // x 9 taps
   if (grid < 1) grid = 1;
   if (grid > ntiles) grid = ntiles;
-  hipLaunchKernelGGL((k_kxk_wgrad<CIN, NTO>), dim3(grid, 9), dim3(256), lds, s, *x, *y, *gy, dw, stride, y->C, M, ntiles, nrep,
+  hipLaunchKernelGGL((k_kxk_wgrad<CIN, NTO, TAPS>), dim3(grid, TAPS), dim3(256), lds, s, *x, *y, *gy, dw, stride, y->C, M, ntiles, nrep,
                      rep_stride);
   return 0;
 }
@@ -310,7 +323,7 @@ extern "C" int lhn_conv_kxk_fwd(const lhn_view* x, const float* w, const lhn_vie
   const int nt = (y->C + 31) / 32;
   hipStream_t s = (hipStream_t)stream;
   int rc = -1;
-#define KF(CI, NTV) if (x->C == CI && nt == NTV) rc = launch_kxk<CI, NTV, 0>(x, w, y, nullptr, stats, nullptr, 0, stride, y->C, s);
+#define KF(CI, NTV) if (x->C == CI && nt == NTV) rc = launch_kxk<CI, NTV, 0, 9>(x, w, y, nullptr, stats, nullptr, 0, stride, y->C, s);
   KF(32, 1) KF(64, 2) KF(128, 4) KF(32, 2) KF(64, 1) KF(64, 4) KF(128, 2) KF(128, 1) KF(32, 4)
 #undef KF
   LHN_CHECK_ARG(rc != -1, "lhn_conv_kxk_fwd: unsupported channels Cin=%d Cout=%d", x->C, y->C);
@@ -328,7 +341,7 @@ extern "C" int lhn_conv_kxk_bwd(const lhn_view* x, const float* w, const lhn_vie
   int rc = -1;
   if (dx) {
     const int nt = (x->C + 31) / 32;   // GEMM N = Cin, K = Cout
-#define KB(CO, NTV) if (y->C == CO && nt == NTV) rc = launch_kxk<CO, NTV, 1>(x, w, y, gy, nullptr, dx, dx_accumulate, stride, x->C, s);
+#define KB(CO, NTV) if (y->C == CO && nt == NTV) rc = launch_kxk<CO, NTV, 1, 9>(x, w, y, gy, nullptr, dx, dx_accumulate, stride, x->C, s);
     KB(32, 1) KB(64, 2) KB(128, 4) KB(32, 2) KB(64, 1) KB(64, 4) KB(128, 2) KB(128, 1) KB(32, 4)
 #undef KB
     LHN_CHECK_ARG(rc != -1, "lhn_conv_kxk_bwd: unsupported channels Cin=%d Cout=%d", x->C, y->C);
@@ -336,11 +349,31 @@ extern "C" int lhn_conv_kxk_bwd(const lhn_view* x, const float* w, const lhn_vie
   }
   rc = -1;
   const int nto = (y->C + 31) / 32;
-#define KW(CI, NTV) if (x->C == CI && nto == NTV) rc = launch_kxk_wgrad<CI, NTV>(x, y, gy, dw, stride, nrep, rep_stride, s);
+#define KW(CI, NTV) if (x->C == CI && nto == NTV) rc = launch_kxk_wgrad<CI, NTV, 9>(x, y, gy, dw, stride, nrep, rep_stride, s);
   KW(32, 1) KW(64, 2) KW(128, 4) KW(32, 2) KW(64, 1) KW(64, 4) KW(128, 2) KW(128, 1) KW(32, 4)
 #undef KW
   LHN_CHECK_ARG(rc != -1, "lhn_conv_kxk_bwd: unsupported channels Cin=%d Cout=%d", x->C, y->C);
   if (rc) return rc;
   LHN_CHECK_LAUNCH("lhn_conv_kxk_bwd");
   return 0;
+}
+
+// 1x1 backward as two launches (dgrad = the implicit-GEMM kernel with one tap, wgrad = the per-tap kernel with one
+// tap): used by lhn_conv_pw_bwd for large Cin*Cout where the fused kernel is LDS-bound to one block per CU.
+int lhn_pw_bwd_split(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx, int dx_accumulate,
+                     float* dw, int nrep, int64_t rep_stride, hipStream_t s) {
+  int rc = -1;
+  if (dx) {
+    const int nt = (x->C + 31) / 32;
+#define PB(CO, NTV) if (y->C == CO && nt == NTV) rc = launch_kxk<CO, NTV, 1, 1>(x, w, y, gy, nullptr, dx, dx_accumulate, 1, x->C, s);
+    PB(64, 4) PB(128, 4) PB(128, 2) PB(64, 2) PB(128, 1) PB(32, 4)
+#undef PB
+    if (rc) return rc;
+  }
+  rc = -1;
+  const int nto = (y->C + 31) / 32;
+#define PW(CI, NTV) if (x->C == CI && nto == NTV) rc = launch_kxk_wgrad<CI, NTV, 1>(x, y, gy, dw, 1, nrep, rep_stride, s);
+  PW(64, 4) PW(128, 4) PW(128, 2) PW(64, 2) PW(128, 1) PW(32, 4)
+#undef PW
+  return rc;
 }

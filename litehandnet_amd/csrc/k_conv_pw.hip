@@ -452,6 +452,9 @@ static int launch_pw_bwd(const lhn_view* x, const float* w, const lhn_view* y, c
   return 0;
 }
 
+int lhn_pw_bwd_split(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx, int dx_accumulate,
+                     float* dw, int nrep, int64_t rep_stride, hipStream_t s);
+
 extern "C" int lhn_conv_pw_bwd(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx,
                                int dx_accumulate, float* dw, float* dbias, int stride, const float* dy_nchw, int nrep,
                                int64_t rep_stride, void* stream) {
@@ -463,6 +466,14 @@ extern "C" int lhn_conv_pw_bwd(const lhn_view* x, const float* w, const lhn_view
   const int cout = y->C, nto = (cout + 31) / 32;
   hipStream_t s = (hipStream_t)stream;
   int rc = -1;
+  if (stride == 1 && !dy_nchw && !dbias && x->C * cout >= 64 * 128 && cout % 32 == 0) {
+    rc = lhn_pw_bwd_split(x, w, y, gy, dx, dx_accumulate, dw, nrep, rep_stride, s);
+    if (rc == 0) {
+      LHN_CHECK_LAUNCH("lhn_conv_pw_bwd");
+      return 0;
+    }
+    if (rc > 0) return rc;
+  }
 #define PWB_CASE(CI, NTV) \
   if (x->C == CI && nto == NTV) rc = launch_pw_bwd<CI, NTV>(x, w, y, gy, dx, dx_accumulate, dw, dbias, stride, dy_nchw, cout, nrep, rep_stride, s);
   PWB_CASE(32, 1) PWB_CASE(32, 2) PWB_CASE(32, 4) PWB_CASE(64, 1) PWB_CASE(64, 2) PWB_CASE(64, 4) PWB_CASE(128, 1)
