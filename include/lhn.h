@@ -40,6 +40,33 @@ typedef struct lhn_gradview {
   const float* coef;     /* [3][cstride]  A | B | C :  dy = A*du + B*y + C   (NULL: dy = du)          */
 } lhn_gradview;
 
+/* Optional fused BatchNorm finalize: the last workgroup of the conv launch to finish folds the replicated
+ * statistics into the table (same arithmetic as lhn_bn_finalize) -- saves one launch per BatchNorm.
+ * `counter` must be zero before the launch.  NULL pointer to the struct = not fused. */
+typedef struct lhn_bnfin {
+  uint32_t*    counter;
+  const float* gamma;
+  const float* beta;
+  float*       running_mean;
+  float*       running_var;
+  int64_t*     num_batches_tracked;
+  float*       table;
+  float*       save_mean_invstd;
+  double       count;
+  int32_t      cstride, coff, C;
+  float        eps, momentum, slope;
+} lhn_bnfin;
+/* same idea for lhn_bn_bwd_reduce -> lhn_bn_bwd_finalize */
+typedef struct lhn_bnbwdfin {
+  uint32_t*    counter;
+  const float* gamma;
+  float*       coef;
+  float*       dgamma;
+  float*       dbeta;
+  double       count;
+  int32_t      cstride, coff, C;
+} lhn_bnbwdfin;
+
 int         lhn_version(void);
 const char* lhn_last_error(void);
 int         lhn_device_ok(void);              /* 0 if a gfx950 device is usable                       */
@@ -94,13 +121,13 @@ int lhn_loss_balanced_mse_bwd(const float* out, const float* target, const float
  */
 int lhn_conv_pw_fwd(const lhn_view* x, const float* w /*[Cout,Cin]*/, const float* bias /*or NULL*/,
                     const lhn_view* y, double* stats /*or NULL*/, int stride, float* y_nchw /*or NULL*/,
-                    void* stream);
+                    const lhn_bnfin* fin /*or NULL*/, void* stream);
 int lhn_conv_dw_fwd(const lhn_view* x, const float* w /*[C,1,k,k]*/, const lhn_view* y, double* stats,
-                    int k, int stride, int pad, int dil, void* stream);
+                    int k, int stride, int pad, int dil, const lhn_bnfin* fin, void* stream);
 int lhn_conv_stem_fwd(const float* img /*[N,3,Hi,Wi]*/, const float* w /*[Cout,3,k,k]*/, const lhn_view* y,
-                      double* stats, int Hi, int Wi, int k, int stride, int pad, void* stream);
+                      double* stats, int Hi, int Wi, int k, int stride, int pad, const lhn_bnfin* fin, void* stream);
 int lhn_conv_kxk_fwd(const lhn_view* x, const float* w /*[Cout,Cin,3,3]*/, const lhn_view* y, double* stats,
-                     int stride, void* stream);
+                     int stride, const lhn_bnfin* fin, void* stream);
 int lhn_bn_finalize(const double* stats, const float* gamma, const float* beta, float* running_mean,
                     float* running_var, int64_t* num_batches_tracked, float* table, int cstride, int coff,
                     int C, float* save_mean_invstd /*[2][C]*/, double count, float eps, float momentum,
@@ -120,7 +147,7 @@ int lhn_ca_mlp_fwd(const float* pooled /*[N,9,C]*/, const float* w3 /*[C,1,3,3]*
 
 /* backward building blocks */
 int lhn_bn_bwd_reduce(const lhn_view* y, const lhn_gradview* g, const float* save_mean_invstd,
-                      double* sums /*[2][C]: sum du, sum du*xhat*/, void* stream);
+                      double* sums /*[R][2][C]: sum du, sum du*xhat*/, const lhn_bnbwdfin* fin /*or NULL*/, void* stream);
 int lhn_bn_bwd_finalize(const double* sums, const float* gamma, const float* save_mean_invstd,
                         float* coef, int cstride, int coff, int C, double count, float* dgamma, float* dbeta,
                         void* stream);

@@ -10,7 +10,7 @@
 // row/tap validity is block-uniform; a wave reads 64/C4 neighbouring pixels x C*4 contiguous bytes per tap.
 template <int K>
 __global__ void __launch_bounds__(256) k_dw_fwd(lhn_view x, const float* __restrict__ w, lhn_view y,
-                                                double* __restrict__ stats, int stride, int pad, int dil) {
+                                                double* __restrict__ stats, int stride, int pad, int dil, lhn_bnfin fin) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int C = x.C, C4 = C >> 2;
   constexpr int KK = K * K;
@@ -82,13 +82,15 @@ __global__ void __launch_bounds__(256) k_dw_fwd(lhn_view x, const float* __restr
         atomicAdd(st + C + 4 * tid + j, qd[j]);
       }
     }
+    if (fin.counter && lhn_last_block(fin.counter)) lhn_bn_finalize_block(fin, stats);
   }
 }
 
 // ------------------------------------------------------------------ stem forward (NCHW 3-channel image -> NHWC)
 // thread = (output pixel, group of 8 output channels)
 __global__ void __launch_bounds__(256) k_stem_fwd(const float* __restrict__ img, const float* __restrict__ w, lhn_view y,
-                                                  double* __restrict__ stats, int Hi, int Wi, int K, int stride, int pad) {
+                                                  double* __restrict__ stats, int Hi, int Wi, int K, int stride, int pad,
+                                                  lhn_bnfin fin) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int CO = y.C, CG = CO >> 3, KK = K * K, T = 3 * KK;
   float* Ws = smem;                                  // [T][CO]
@@ -154,6 +156,7 @@ __global__ void __launch_bounds__(256) k_stem_fwd(const float* __restrict__ img,
       atomicAdd(st + tid, sd);
       atomicAdd(st + CO + tid, qd);
     }
+    if (fin.counter && lhn_last_block(fin.counter)) lhn_bn_finalize_block(fin, stats);
   }
 }
 
@@ -166,7 +169,8 @@ static inline int grid_for(int64_t items_per_block_total, int per_block, int cap
 }
 static inline bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
-int lhn_dwk_fwd_lds(const lhn_view* x, const float* w, const lhn_view* y, double* stats, int k, int dil, hipStream_t s);
+int lhn_dwk_fwd_lds(const lhn_view* x, const float* w, const lhn_view* y, double* stats, int k, int dil, lhn_bnfin fin,
+                    hipStream_t s);
 int lhn_dwk_bwd_lds(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx, int dx_acc,
                     float* dw, int k, int dil, int nrep, int64_t rep_stride, hipStream_t s);
 static bool lhn_dw_force_gather() {
@@ -179,7 +183,9 @@ static bool lhn_dw_force_gather() {
 }
 
 extern "C" int lhn_conv_dw_fwd(const lhn_view* x, const float* w, const lhn_view* y, double* stats, int k, int stride,
-                               int pad, int dil, void* stream) {
+                               int pad, int dil, const lhn_bnfin* finp, void* stream) {
+  lhn_bnfin fin;
+  if (finp && stats) fin = *finp; else fin.counter = nullptr;
   LHN_CHECK_ARG(lhn_view_ok(x) && lhn_view_ok(y) && (w || k == 1), "lhn_conv_dw_fwd: bad view / null pointer (w may be NULL = ones only for k=1)");
   LHN_CHECK_ARG(x->C == y->C && pow2(x->C) && x->C <= 256, "lhn_conv_dw_fwd: channels %d -> %d (power of two <= 256)", x->C, y->C);
   LHN_CHECK_ARG((k == 1 || k == 3 || k == 5 || k == 7) && stride >= 1 && dil >= 1 && pad >= 0, "lhn_conv_dw_fwd: k=%d stride=%d dil=%d", k, stride, dil);
@@ -189,21 +195,23 @@ extern "C" int lhn_conv_dw_fwd(const lhn_view* x, const float* w, const lhn_view
   const int grid = grid_for((int64_t)y->N * Ho, 1, 8);
   hipStream_t s = (hipStream_t)stream;
   if (w && stride == 1 && pad == dil * (k - 1) / 2 && x->C % 32 == 0 && y->W >= 8 && !lhn_dw_force_gather() &&
-      lhn_dwk_fwd_lds(x, w, y, stats, k, dil, s)) {
+      lhn_dwk_fwd_lds(x, w, y, stats, k, dil, fin, s)) {
   } else if (k == 3)
-    hipLaunchKernelGGL((k_dw_fwd<3>), dim3(grid), dim3(256), lds, s, *x, w, *y, stats, stride, pad, dil);
+    hipLaunchKernelGGL((k_dw_fwd<3>), dim3(grid), dim3(256), lds, s, *x, w, *y, stats, stride, pad, dil, fin);
   else if (k == 7)
-    hipLaunchKernelGGL((k_dw_fwd<7>), dim3(grid), dim3(256), lds, s, *x, w, *y, stats, stride, pad, dil);
+    hipLaunchKernelGGL((k_dw_fwd<7>), dim3(grid), dim3(256), lds, s, *x, w, *y, stats, stride, pad, dil, fin);
   else if (k == 1)
-    hipLaunchKernelGGL((k_dw_fwd<1>), dim3(grid), dim3(256), lds, s, *x, w, *y, stats, stride, pad, dil);
+    hipLaunchKernelGGL((k_dw_fwd<1>), dim3(grid), dim3(256), lds, s, *x, w, *y, stats, stride, pad, dil, fin);
   else if (k == 5)
-    hipLaunchKernelGGL((k_dw_fwd<5>), dim3(grid), dim3(256), lds, s, *x, w, *y, stats, stride, pad, dil);
+    hipLaunchKernelGGL((k_dw_fwd<5>), dim3(grid), dim3(256), lds, s, *x, w, *y, stats, stride, pad, dil, fin);
   LHN_CHECK_LAUNCH("lhn_conv_dw_fwd");
   return 0;
 }
 
 extern "C" int lhn_conv_stem_fwd(const float* img, const float* w, const lhn_view* y, double* stats, int Hi, int Wi, int k,
-                                 int stride, int pad, void* stream) {
+                                 int stride, int pad, const lhn_bnfin* finp, void* stream) {
+  lhn_bnfin fin;
+  if (finp && stats) fin = *finp; else fin.counter = nullptr;
   LHN_CHECK_ARG(img && w && lhn_view_ok(y), "lhn_conv_stem_fwd: bad view / null pointer");
   LHN_CHECK_ARG(y->C % 8 == 0 && pow2(y->C / 8) && y->C <= 256, "lhn_conv_stem_fwd: Cout=%d", y->C);
   LHN_CHECK_ARG((k == 1 || k == 3) && stride >= 1, "lhn_conv_stem_fwd: k=%d", k);
@@ -212,7 +220,7 @@ extern "C" int lhn_conv_stem_fwd(const float* img, const float* w, const lhn_vie
   const int PL = 256 / (y->C / 8);
   const size_t lds = (size_t)(3 * k * k * y->C) * 4 + 256 * 16 * 4;
   hipLaunchKernelGGL(k_stem_fwd, dim3(grid_for((int64_t)y->N * Ho * Wo, PL, 8)), dim3(256), lds, (hipStream_t)stream, img,
-                     w, *y, stats, Hi, Wi, k, stride, pad);
+                     w, *y, stats, Hi, Wi, k, stride, pad, fin);
   LHN_CHECK_LAUNCH("lhn_conv_stem_fwd");
   return 0;
 }
@@ -473,7 +481,8 @@ struct DwTile {
 
 template <int K, int DIL>
 __global__ void __launch_bounds__(256) k_dwk_fwd_lds(lhn_view x, const float* __restrict__ w, lhn_view y,
-                                                     double* __restrict__ stats, int tiles_h, int tiles_w, int cgroups) {
+                                                     double* __restrict__ stats, int tiles_h, int tiles_w, int cgroups,
+                                                     lhn_bnfin fin) {
   constexpr int TH = 8, TW = 32, KK = K * K;
   using T = DwTile<K, DIL, TH, TW>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -576,6 +585,7 @@ __global__ void __launch_bounds__(256) k_dwk_fwd_lds(lhn_view x, const float* __
         atomicAdd(st + C + 4 * tid + j, qd[j]);
       }
     }
+    if (fin.counter && lhn_last_block(fin.counter)) lhn_bn_finalize_block(fin, stats);
   }
 }
 
@@ -751,7 +761,7 @@ static int dw3_grid(int ntile, int cgroups, int per_cu) {
 }
 
 template <int K, int DIL>
-static void launch_dwk_fwd(const lhn_view* x, const float* w, const lhn_view* y, double* stats, hipStream_t s) {
+static void launch_dwk_fwd(const lhn_view* x, const float* w, const lhn_view* y, double* stats, lhn_bnfin fin, hipStream_t s) {
   constexpr int TH = 8, TW = 32, P = DIL * (K - 1) / 2;
   const int cg = x->C / 32;
   const int th = (y->H + TH - 1) / TH, tw = (y->W + TW - 1) / TW, ntile = y->N * th * tw * cg;
@@ -762,7 +772,7 @@ static void launch_dwk_fwd(const lhn_view* x, const float* w, const lhn_view* y,
     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwk_fwd_lds<K, DIL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     done = true;
   }
-  hipLaunchKernelGGL((k_dwk_fwd_lds<K, DIL>), dim3(dw3_grid(ntile, cg, per_cu * 2)), dim3(256), lds, s, *x, w, *y, stats, th, tw, cg);
+  hipLaunchKernelGGL((k_dwk_fwd_lds<K, DIL>), dim3(dw3_grid(ntile, cg, per_cu * 2)), dim3(256), lds, s, *x, w, *y, stats, th, tw, cg, fin);
 }
 template <int K, int DIL>
 static void launch_dwk_bwd(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx, int dx_acc,
@@ -781,10 +791,11 @@ static void launch_dwk_bwd(const lhn_view* x, const float* w, const lhn_view* y,
 }
 
 // returns 1 if an LDS-tiled kernel was launched
-int lhn_dwk_fwd_lds(const lhn_view* x, const float* w, const lhn_view* y, double* stats, int k, int dil, hipStream_t s) {
-  if (k == 3 && dil == 1) launch_dwk_fwd<3, 1>(x, w, y, stats, s);
-  else if (k == 3 && dil == 2) launch_dwk_fwd<3, 2>(x, w, y, stats, s);
-  else if (k == 7 && dil == 1) launch_dwk_fwd<7, 1>(x, w, y, stats, s);
+int lhn_dwk_fwd_lds(const lhn_view* x, const float* w, const lhn_view* y, double* stats, int k, int dil, lhn_bnfin fin,
+                    hipStream_t s) {
+  if (k == 3 && dil == 1) launch_dwk_fwd<3, 1>(x, w, y, stats, fin, s);
+  else if (k == 3 && dil == 2) launch_dwk_fwd<3, 2>(x, w, y, stats, fin, s);
+  else if (k == 7 && dil == 1) launch_dwk_fwd<7, 1>(x, w, y, stats, fin, s);
   else return 0;
   return 1;
 }

@@ -11,7 +11,7 @@
 template <int KD, int NT, int MODE, int TAPS>
 __global__ void __launch_bounds__(256) k_kxk(lhn_view x, const float* __restrict__ w, lhn_view y, lhn_gradview gy,
                                              double* __restrict__ stats, float* __restrict__ dx, int dx_acc, int stride,
-                                             int nout, int M, int ntiles) {
+                                             int nout, int M, int ntiles, lhn_bnfin fin) {
   // MODE 0: KD = Cin,  nout = Cout, rows = output pixels of y, A from x
   // MODE 1: KD = Cout, nout = Cin,  rows = input pixels of x,  A from (gy, y)
   constexpr int LDA = KD + 4, C4 = KD / 4, RP = 256 / C4, PF = KD / 8;
@@ -168,6 +168,7 @@ __global__ void __launch_bounds__(256) k_kxk(lhn_view x, const float* __restrict
       atomicAdd(st + tid, s);
       atomicAdd(st + nout + tid, q);
     }
+    if (fin.counter && lhn_last_block(fin.counter)) lhn_bn_finalize_block(fin, stats);
   }
 }
 
@@ -262,7 +263,9 @@ __global__ void __launch_bounds__(256) k_kxk_wgrad(lhn_view x, lhn_view y, lhn_g
 
 template <int KD, int NT, int MODE, int TAPS>
 static int launch_kxk(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, double* stats, float* dx,
-                      int dx_acc, int stride, int nout, hipStream_t s) {
+                      int dx_acc, int stride, int nout, hipStream_t s, const lhn_bnfin* finp = nullptr) {
+  lhn_bnfin fin;
+  if (finp && stats) fin = *finp; else fin.counter = nullptr;
   const lhn_view* ov = MODE == 0 ? y : x;
   const int M = ov->N * ov->H * ov->W, ntiles = (M + 127) / 128;
   const size_t lds = (size_t)((32 * NT + 128) * (KD + 4) + 4 * 32 * NT * 2) * sizeof(float);
@@ -282,7 +285,7 @@ static int launch_kxk(const lhn_view* x, const float* w, const lhn_view* y, cons
   if (grid > ntiles) grid = ntiles;
   lhn_gradview g;
   if (gy) g = *gy; else g.dz = g.dpool = g.coef = nullptr;
-  hipLaunchKernelGGL((k_kxk<KD, NT, MODE, TAPS>), dim3(grid), dim3(256), lds, s, *x, w, *y, g, stats, dx, dx_acc, stride, nout, M, ntiles);
+  hipLaunchKernelGGL((k_kxk<KD, NT, MODE, TAPS>), dim3(grid), dim3(256), lds, s, *x, w, *y, g, stats, dx, dx_acc, stride, nout, M, ntiles, fin);
   return 0;
 }
 
@@ -317,13 +320,13 @@ static int kxk_geometry_ok(const lhn_view* x, const lhn_view* y, int stride) {
 }
 
 extern "C" int lhn_conv_kxk_fwd(const lhn_view* x, const float* w, const lhn_view* y, double* stats, int stride,
-                                void* stream) {
+                                const lhn_bnfin* fin, void* stream) {
   LHN_CHECK_ARG(lhn_view_ok(x) && lhn_view_ok(y) && w, "lhn_conv_kxk_fwd: bad view / null pointer");
   LHN_CHECK_ARG((stride == 1 || stride == 2) && kxk_geometry_ok(x, y, stride), "lhn_conv_kxk_fwd: geometry / stride %d", stride);
   const int nt = (y->C + 31) / 32;
   hipStream_t s = (hipStream_t)stream;
   int rc = -1;
-#define KF(CI, NTV) if (x->C == CI && nt == NTV) rc = launch_kxk<CI, NTV, 0, 9>(x, w, y, nullptr, stats, nullptr, 0, stride, y->C, s);
+#define KF(CI, NTV) if (x->C == CI && nt == NTV) rc = launch_kxk<CI, NTV, 0, 9>(x, w, y, nullptr, stats, nullptr, 0, stride, y->C, s, fin);
   KF(32, 1) KF(64, 2) KF(128, 4) KF(32, 2) KF(64, 1) KF(64, 4) KF(128, 2) KF(128, 1) KF(32, 4)
 #undef KF
   LHN_CHECK_ARG(rc != -1, "lhn_conv_kxk_fwd: unsupported channels Cin=%d Cout=%d", x->C, y->C);

@@ -11,7 +11,7 @@
 template <int CIN, int NT>
 __global__ void __launch_bounds__(256) k_pw_fwd(lhn_view x, const float* __restrict__ w, const float* __restrict__ bias,
                                                 lhn_view y, double* __restrict__ stats, int stride,
-                                                float* __restrict__ y_nchw, int cout, int M, int ntiles) {
+                                                float* __restrict__ y_nchw, int cout, int M, int ntiles, lhn_bnfin fin) {
   constexpr int LDA = CIN + 4;
   constexpr int PF = CIN / 8;   // float4 loads per thread per 128-pixel tile
   constexpr int C4 = CIN / 4;   // float4 per pixel row
@@ -155,12 +155,15 @@ __global__ void __launch_bounds__(256) k_pw_fwd(lhn_view x, const float* __restr
       atomicAdd(st + tid, s);
       atomicAdd(st + cout + tid, q);
     }
+    if (fin.counter && lhn_last_block(fin.counter)) lhn_bn_finalize_block(fin, stats);
   }
 }
 
 template <int CIN, int NT>
 static int launch_pw_fwd(const lhn_view* x, const float* w, const float* bias, const lhn_view* y, double* stats,
-                         int stride, float* y_nchw, int cout, hipStream_t s) {
+                         int stride, float* y_nchw, int cout, const lhn_bnfin* fin, hipStream_t s) {
+  lhn_bnfin f;
+  if (fin && stats) f = *fin; else f.counter = nullptr;
   const int M = y->N * y->H * y->W;
   const int ntiles = (M + 127) / 128;
   const size_t lds = (size_t)((32 * NT + 128) * (CIN + 4) + 4 * 32 * NT * 2) * sizeof(float);
@@ -179,12 +182,12 @@ static int launch_pw_fwd(const lhn_view* x, const float* w, const float* bias, c
   int grid = lhn_num_cus() * per_cu;
   if (grid > ntiles) grid = ntiles;
   hipLaunchKernelGGL((k_pw_fwd<CIN, NT>), dim3(grid), dim3(256), lds, s, *x, w, bias, *y, stats, stride, y_nchw, cout, M,
-                     ntiles);
+                     ntiles, f);
   return 0;
 }
 
 extern "C" int lhn_conv_pw_fwd(const lhn_view* x, const float* w, const float* bias, const lhn_view* y, double* stats,
-                               int stride, float* y_nchw, void* stream) {
+                               int stride, float* y_nchw, const lhn_bnfin* fin, void* stream) {
   LHN_CHECK_ARG(lhn_view_ok(x) && w && y, "lhn_conv_pw_fwd: bad input view / null pointer");
   LHN_CHECK_ARG(stride == 1 || stride == 2, "lhn_conv_pw_fwd: stride %d", stride);
   LHN_CHECK_ARG(y->N == x->N && y->H == (x->H + stride - 1) / stride && y->W == (x->W + stride - 1) / stride,
@@ -202,13 +205,13 @@ extern "C" int lhn_conv_pw_fwd(const lhn_view* x, const float* w, const float* b
   hipStream_t s = (hipStream_t)stream;
   int rc = -1;
 #define PW_CASE(CI, NTV) \
-  if (x->C == CI && nt == NTV) rc = launch_pw_fwd<CI, NTV>(x, w, bias, y, stats, stride, y_nchw, cout, s);
+  if (x->C == CI && nt == NTV) rc = launch_pw_fwd<CI, NTV>(x, w, bias, y, stats, stride, y_nchw, cout, fin, s);
   PW_CASE(32, 1) PW_CASE(32, 2) PW_CASE(32, 4) PW_CASE(64, 1) PW_CASE(64, 2) PW_CASE(64, 4) PW_CASE(128, 1)
   PW_CASE(128, 2) PW_CASE(128, 4) PW_CASE(16, 1) PW_CASE(16, 2) PW_CASE(16, 4)
 #undef PW_CASE
   if (nt == 3) {  // 96 output channels: run as 128 with zero rows
 #define PW_CASE3(CI) \
-  if (x->C == CI) rc = launch_pw_fwd<CI, 4>(x, w, bias, y, stats, stride, y_nchw, cout, s);
+  if (x->C == CI) rc = launch_pw_fwd<CI, 4>(x, w, bias, y, stats, stride, y_nchw, cout, fin, s);
     PW_CASE3(16) PW_CASE3(32) PW_CASE3(64) PW_CASE3(128)
 #undef PW_CASE3
   }

@@ -505,7 +505,7 @@ __global__ void __launch_bounds__(256) k_ca_bwd1(const float* __restrict__ poole
 // ------------------------------------------------------------------ BatchNorm backward reductions
 // sums[0][c] = sum du, sums[1][c] = sum du * xhat   over all pixels (du: gradient at the BN output)
 __global__ void __launch_bounds__(256) k_bn_bwd_reduce(lhn_view y, lhn_gradview g, const float* __restrict__ save,
-                                                       double* __restrict__ sums) {
+                                                       double* __restrict__ sums, lhn_bnbwdfin fin) {
   __shared__ f4 red[512];
   const int C4 = y.C >> 2, PL = 256 / C4;
   const int c4 = threadIdx.x % C4, pl = threadIdx.x / C4;
@@ -547,6 +547,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_reduce(lhn_view y, lhn_gradview 
       atomicAdd(st + y.C + 4 * threadIdx.x + j, qd[j]);
     }
   }
+  if (fin.counter && lhn_last_block(fin.counter)) lhn_bn_bwd_finalize_block(fin, sums, save);
 }
 // dy = A*du + B*y + C with  A = s, B = -s*invstd*dgamma/n, C = -s*dbeta/n + s*invstd*mean*dgamma/n, s = gamma*invstd
 __global__ void k_bn_bwd_finalize(const double* __restrict__ sums, const float* __restrict__ gamma,
@@ -725,9 +726,12 @@ int lhn_ca_mlp_bwd(const float* pooled, const float* w3, const float* gamma, con
   return 0;
 }
 
-int lhn_bn_bwd_reduce(const lhn_view* y, const lhn_gradview* g, const float* save, double* sums, void* stream) {
+int lhn_bn_bwd_reduce(const lhn_view* y, const lhn_gradview* g, const float* save, double* sums, const lhn_bnbwdfin* finp,
+                      void* stream) {
+  lhn_bnbwdfin fin;
+  if (finp) fin = *finp; else fin.counter = nullptr;
   LHN_CHECK_ARG(lhn_view_ok(y) && g && g->dz && save && sums && pow2i(y->C / 4) && y->C <= 1024, "lhn_bn_bwd_reduce: bad args");
-  hipLaunchKernelGGL(k_bn_bwd_reduce, dim3(grid_cap((int64_t)y->N * y->H, 8)), dim3(256), 0, (hipStream_t)stream, *y, *g, save, sums);
+  hipLaunchKernelGGL(k_bn_bwd_reduce, dim3(grid_cap((int64_t)y->N * y->H, 8)), dim3(256), 0, (hipStream_t)stream, *y, *g, save, sums, fin);
   LHN_CHECK_LAUNCH("lhn_bn_bwd_reduce");
   return 0;
 }

@@ -1,6 +1,7 @@
 // Static plan executor: one call enqueues a whole forward or backward pass on a HIP stream.
 // The plan (buffers + op lists) is produced by the Python mirror of the reference's module tree;
 // this file only resolves offsets into the workspace arena / parameter array and calls the launchers.
+#include <stdlib.h>
 #include <vector>
 #include "lhn_common.h"
 
@@ -41,6 +42,42 @@ static lhn_gradview mkgrad(const Plan* P, void* ws, int buf, bool use_coef) {
 }
 template <typename T>
 static inline T* prm(void* const* arr, int idx) { return idx < 0 ? nullptr : static_cast<T*>(arr[idx]); }
+
+// conv op with a trailing BatchNorm: p[2..6] = gamma, beta, running_mean, running_var, num_batches_tracked,
+// ws[1] = save(mean,invstd), ws[2] = arrival counter, f[0..2] = eps, momentum, slope
+static bool conv_has_bn(const lhn_op& o) { return o.p[2] >= 0 || o.p[3] >= 0 || o.ws[1] >= 0; }
+static lhn_bnfin mkfin(const Plan* P, void* ws, const lhn_op& o, void* const* params) {
+  const lhn_buf& b = P->bufs[o.out_buf];
+  lhn_bnfin f;
+  f.counter = reinterpret_cast<uint32_t*>(at(ws, o.ws[2]));
+  f.gamma = prm<const float>(params, o.p[2]);
+  f.beta = prm<const float>(params, o.p[3]);
+  f.running_mean = prm<float>(params, o.p[4]);
+  f.running_var = prm<float>(params, o.p[5]);
+  f.num_batches_tracked = prm<int64_t>(params, o.p[6]);
+  f.table = reinterpret_cast<float*>(at(ws, b.table_off));
+  f.save_mean_invstd = reinterpret_cast<float*>(at(ws, o.ws[1]));
+  f.count = (double)b.N * b.H * b.W;
+  f.cstride = b.C; f.coff = o.out_coff; f.C = o.out_C;
+  f.eps = o.f[0]; f.momentum = o.f[1]; f.slope = o.f[2];
+  return f;
+}
+// The finalize runs as its own tiny launch unless LHN_FUSE_FINALIZE=1: measured on MI355X the in-kernel
+// last-block hand-off (one returning ticket atomic per workgroup on one word, ~88 tickets/us) costs MORE than
+// the ~5.5 us launch it replaces (variant B step 13.5 ms fused vs 12.9 ms separate), so separate is the default.
+static bool fuse_finalize() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("LHN_FUSE_FINALIZE");
+    v = (e && e[0] == '1') ? 1 : 0;
+  }
+  return v == 1;
+}
+static int sep_finalize(const lhn_bnfin& f, const double* stats, int training, void* stream) {
+  return lhn_bn_finalize(training ? stats : nullptr, f.gamma, f.beta, f.running_mean, f.running_var,
+                         training ? f.num_batches_tracked : nullptr, f.table, f.cstride, f.coff, f.C,
+                         training ? f.save_mean_invstd : nullptr, f.count, f.eps, f.momentum, f.slope, training, stream);
+}
 
 extern "C" {
 
@@ -95,9 +132,13 @@ int lhn_plan_run(void* plan, int phase, void* ws, void* const* params, void* con
       }
       case OP_STEM: {
         lhn_view y = mkview(P, ws, o.out_buf, o.out_coff, o.out_C);
+        const bool bn = conv_has_bn(o);
+        lhn_bnfin fin;
+        if (bn) fin = mkfin(P, ws, o, params);
         rc = lhn_conv_stem_fwd(static_cast<const float*>(io[0]), prm<const float>(params, o.p[0]), &y,
                                training ? reinterpret_cast<double*>(at(ws, o.ws[0])) : nullptr, o.i[3], o.i[4], o.i[0], o.i[1],
-                               o.i[2], stream);
+                               o.i[2], (bn && training && fuse_finalize()) ? &fin : nullptr, stream);
+        if (!rc && bn && !(training && fuse_finalize())) rc = sep_finalize(fin, reinterpret_cast<const double*>(at(ws, o.ws[0])), training, stream);
         break;
       }
       case OP_PW: {
@@ -112,24 +153,37 @@ int lhn_plan_run(void* plan, int phase, void* ws, void* const* params, void* con
         } else {
           y = mkview(P, ws, o.out_buf, o.out_coff, o.out_C);
         }
+        const bool bn = !o.i[1] && conv_has_bn(o);
+        lhn_bnfin fin;
+        if (bn) fin = mkfin(P, ws, o, params);
         rc = lhn_conv_pw_fwd(&x, prm<const float>(params, o.p[0]), prm<const float>(params, o.p[1]), &y,
                              (training && o.ws[0] >= 0) ? reinterpret_cast<double*>(at(ws, o.ws[0])) : nullptr, o.i[0], nchw,
-                             stream);
+                             (bn && training && fuse_finalize()) ? &fin : nullptr, stream);
+        if (!rc && bn && !(training && fuse_finalize())) rc = sep_finalize(fin, reinterpret_cast<const double*>(at(ws, o.ws[0])), training, stream);
         break;
       }
       case OP_DW: {
         lhn_view x = mkview(P, ws, o.in_buf[0], o.in_coff[0], o.in_C[0]);
         lhn_view y = mkview(P, ws, o.out_buf, o.out_coff, o.out_C);
+        const bool bn = conv_has_bn(o);
+        lhn_bnfin fin;
+        if (bn) fin = mkfin(P, ws, o, params);
         rc = lhn_conv_dw_fwd(&x, prm<const float>(params, o.p[0]), &y,
                              training ? reinterpret_cast<double*>(at(ws, o.ws[0])) : nullptr, o.i[0], o.i[1], o.i[2], o.i[3],
-                             stream);
+                             (bn && training && fuse_finalize()) ? &fin : nullptr, stream);
+        if (!rc && bn && !(training && fuse_finalize())) rc = sep_finalize(fin, reinterpret_cast<const double*>(at(ws, o.ws[0])), training, stream);
         break;
       }
       case OP_KXK: {
         lhn_view x = mkview(P, ws, o.in_buf[0], o.in_coff[0], o.in_C[0]);
         lhn_view y = mkview(P, ws, o.out_buf, o.out_coff, o.out_C);
+        const bool bn = conv_has_bn(o);
+        lhn_bnfin fin;
+        if (bn) fin = mkfin(P, ws, o, params);
         rc = lhn_conv_kxk_fwd(&x, prm<const float>(params, o.p[0]), &y,
-                              training ? reinterpret_cast<double*>(at(ws, o.ws[0])) : nullptr, o.i[0], stream);
+                              training ? reinterpret_cast<double*>(at(ws, o.ws[0])) : nullptr, o.i[0],
+                              (bn && training && fuse_finalize()) ? &fin : nullptr, stream);
+        if (!rc && bn && !(training && fuse_finalize())) rc = sep_finalize(fin, reinterpret_cast<const double*>(at(ws, o.ws[0])), training, stream);
         break;
       }
       case OP_FINALIZE: {
@@ -224,11 +278,22 @@ int lhn_plan_run(void* plan, int phase, void* ws, void* const* params, void* con
         lhn_gradview g = mkgrad(P, ws, o.out_buf, false);
         double* sums = reinterpret_cast<double*>(at(ws, o.ws[0]));
         const float* save = reinterpret_cast<const float*>(at(ws, o.ws[1]));
-        rc = lhn_bn_bwd_reduce(&y, &g, save, sums, stream);
-        if (!rc)
-          rc = lhn_bn_bwd_finalize(sums, prm<const float>(params, o.p[0]), save, reinterpret_cast<float*>(at(ws, b.coef_off)),
-                                   b.C, o.out_coff, o.out_C, (double)b.N * b.H * b.W, prm<float>(grads, o.p[1]),
-                                   prm<float>(grads, o.p[2]), stream);
+        lhn_bnbwdfin fin;
+        fin.counter = reinterpret_cast<uint32_t*>(at(ws, o.ws[2]));
+        fin.gamma = prm<const float>(params, o.p[0]);
+        fin.coef = reinterpret_cast<float*>(at(ws, b.coef_off));
+        fin.dgamma = prm<float>(grads, o.p[1]);
+        fin.dbeta = prm<float>(grads, o.p[2]);
+        fin.count = (double)b.N * b.H * b.W;
+        fin.cstride = b.C; fin.coff = o.out_coff; fin.C = o.out_C;
+        if (fin.counter && fuse_finalize()) {
+          rc = lhn_bn_bwd_reduce(&y, &g, save, sums, &fin, stream);
+        } else {
+          rc = lhn_bn_bwd_reduce(&y, &g, save, sums, nullptr, stream);
+          if (!rc)
+            rc = lhn_bn_bwd_finalize(sums, fin.gamma, save, fin.coef, b.C, o.out_coff, o.out_C, fin.count, fin.dgamma, fin.dbeta,
+                                     stream);
+        }
         break;
       }
       case OP_EW_BWD: {

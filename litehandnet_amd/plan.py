@@ -145,9 +145,11 @@ class PlanBuilder:
                    nchw=nchw_out)
         if bn is not None:
             rec["stats"] = self._ws("zf", STAT_REPLICAS * 2 * cout * 8)
+            rec["cnt"] = self._ws("zf", 4)
             rec["save"] = self._ws("misc", 2 * cout * 4)
             if self.with_backward:
                 rec["sums"] = self._ws("zb", STAT_REPLICAS * 2 * cout * 8)
+                rec["bcnt"] = self._ws("zb", 4)
                 self.bufs[out.buf].coef = True
         self.recs.append(rec)
         return out
@@ -159,9 +161,11 @@ class PlanBuilder:
         out = self.new(x.H, x.W, x.C)
         rec = dict(op=DW, x=x, out=out, conv=_IDENT, bn=bn, slope=float(slope), k=1, stride=1, pad=0, dil=1, nchw=False)
         rec["stats"] = self._ws("zf", STAT_REPLICAS * 2 * x.C * 8)
+        rec["cnt"] = self._ws("zf", 4)
         rec["save"] = self._ws("misc", 2 * x.C * 4)
         if self.with_backward:
             rec["sums"] = self._ws("zb", STAT_REPLICAS * 2 * x.C * 8)
+            rec["bcnt"] = self._ws("zb", 4)
             self.bufs[out.buf].coef = True
         self.recs.append(rec)
         return out
@@ -304,21 +308,24 @@ class PlanBuilder:
                 conv, bn, x, out = r["conv"], r["bn"], r["x"], r["out"]
                 stats = self._abs(r.get("stats"))
                 pw = self._p(conv.weight)
+                # a trailing BatchNorm rides on the conv op: the last workgroup of the conv finalizes the table
+                if bn is not None:
+                    pbn = (self._p(bn.weight), self._p(bn.bias), self._p(bn.running_mean), self._p(bn.running_var),
+                           self._p(bn.num_batches_tracked))
+                    wsl = (stats, self._abs(r["save"]), self._abs(r["cnt"]))
+                    fl = (bn.eps, bn.momentum, r["slope"])
+                else:
+                    pbn, wsl, fl = (-1, -1, -1, -1, -1), (stats,), ()
                 if k == STEM:
-                    fwd.append(mk(STEM, out=out, p=(pw,), ws=(stats,), i=(r["k"], r["stride"], r["pad"], x.H, x.W)))
+                    fwd.append(mk(STEM, out=out, p=(pw, -1) + pbn, ws=wsl, i=(r["k"], r["stride"], r["pad"], x.H, x.W), f=fl))
                 elif k == PW:
                     o = TRef(-1, 0, out.C, out.H, out.W) if r["nchw"] else out
-                    fwd.append(mk(PW, ins=(x,), out=o, p=(pw, self._p(conv.bias)), ws=(stats,),
-                                  i=(r["stride"], 1 if r["nchw"] else 0)))
+                    fwd.append(mk(PW, ins=(x,), out=o, p=(pw, self._p(conv.bias)) + pbn, ws=wsl,
+                                  i=(r["stride"], 1 if r["nchw"] else 0), f=fl))
                 elif k == DW:
-                    fwd.append(mk(DW, ins=(x,), out=out, p=(pw,), ws=(stats,), i=(r["k"], r["stride"], r["pad"], r["dil"])))
+                    fwd.append(mk(DW, ins=(x,), out=out, p=(pw, -1) + pbn, ws=wsl, i=(r["k"], r["stride"], r["pad"], r["dil"]), f=fl))
                 else:
-                    fwd.append(mk(KXK, ins=(x,), out=out, p=(pw,), ws=(stats,), i=(r["stride"],)))
-                if bn is not None:
-                    fwd.append(mk(FINALIZE, out=out,
-                                  p=(self._p(bn.weight), self._p(bn.bias), self._p(bn.running_mean),
-                                     self._p(bn.running_var), self._p(bn.num_batches_tracked)),
-                                  ws=(stats, self._abs(r["save"])), f=(bn.eps, bn.momentum, r["slope"])))
+                    fwd.append(mk(KXK, ins=(x,), out=out, p=(pw, -1) + pbn, ws=wsl, i=(r["stride"],), f=fl))
             elif k == EW:
                 fwd.append(mk(EW, ins=r["srcs"], out=r["out"], i=(len(r["srcs"]),), f=(r["slope"],)))
             elif k == MAXPOOL:
@@ -351,7 +358,7 @@ class PlanBuilder:
                     use_coef = 1 if bn is not None else 0
                     if bn is not None:
                         body.append(mk(BN_BWD, out=out, p=(self._p(bn.weight), self._p(bn.weight), self._p(bn.bias)),
-                                       ws=(self._abs(r["sums"]), self._abs(r["save"]))))
+                                       ws=(self._abs(r["sums"]), self._abs(r["save"]), self._abs(r["bcnt"]))))
                     if k == STEM:
                         body.append(mk(STEM_BWD, out=out, p=(pw, pw), i=(r["k"], r["stride"], r["pad"], x.H, x.W, use_coef)))
                         continue

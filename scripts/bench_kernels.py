@@ -36,12 +36,12 @@ for (N, H, Cc) in ([] if ONLY == "pw" else [(64, 128, 32), (64, 64, 64), (64, 32
     vx, vy = view(x, table=tb), view(y)
     byts = 2 * x.numel() * 4
     for name, sp in (("dw_fwd+stats", stats.data_ptr()), ("dw_fwd nostats", None)):
-        us = timeit(lambda: _lib.check(L.lhn_conv_dw_fwd(C.byref(vx), _lib.ptr(w), C.byref(vy), C.c_void_p(sp), 3, 1, 1, 1, st)))
+        us = timeit(lambda: _lib.check(L.lhn_conv_dw_fwd(C.byref(vx), _lib.ptr(w), C.byref(vy), C.c_void_p(sp), 3, 1, 1, 1, None, st)))
         print(f"{name}, {N}x{H}x{H}x{Cc}, {us:.1f}, {byts / us / 1e3:.0f}")
     # bn bwd reduce
     dz = torch.randn_like(x); save = torch.randn(2 * Cc, device=dev).abs() + 0.5; sums = torch.zeros(32 * 2 * Cc, dtype=torch.float64, device=dev)
     g = GradView(); g.dz = dz.data_ptr(); g.dpool = None; g.coef = None
-    us = timeit(lambda: _lib.check(L.lhn_bn_bwd_reduce(C.byref(vx), C.byref(g), _lib.ptr(save), _lib.ptr(sums), st)))
+    us = timeit(lambda: _lib.check(L.lhn_bn_bwd_reduce(C.byref(vx), C.byref(g), _lib.ptr(save), _lib.ptr(sums), None, st)))
     print(f"bn_bwd_reduce, {N}x{H}x{H}x{Cc}, {us:.1f}, {byts / us / 1e3:.0f}")
     coef = torch.randn(3, Cc, device=dev); g.coef = coef.data_ptr()
     dx = torch.empty_like(x); dw = torch.zeros(16, w.numel(), device=dev)
@@ -56,7 +56,7 @@ for (N, H, Ci, Co) in [(64, 64, 64, 64), (64, 64, 128, 128), (64, 128, 32, 32), 
     stats = torch.zeros(32 * 2 * Co, dtype=torch.float64, device=dev); tb = table(Ci)
     vx, vy = view(x, table=tb), view(y)
     byts = (x.numel() + y.numel()) * 4
-    us = timeit(lambda: _lib.check(L.lhn_conv_pw_fwd(C.byref(vx), _lib.ptr(w), None, C.byref(vy), _lib.ptr(stats), 1, None, st)))
+    us = timeit(lambda: _lib.check(L.lhn_conv_pw_fwd(C.byref(vx), _lib.ptr(w), None, C.byref(vy), _lib.ptr(stats), 1, None, None, st)))
     print(f"pw_fwd, {N}x{H}x{H} {Ci}->{Co}, {us:.1f}, {byts / us / 1e3:.0f} GB/s, {2 * N * H * H * Ci * Co / us / 1e6:.1f} TFLOP/s")
     dz = torch.randn_like(y); coef = torch.randn(3, Co, device=dev); tby = table(Co)
     g = GradView(); g.dz = dz.data_ptr(); g.dpool = None; g.coef = coef.data_ptr()
