@@ -8,36 +8,51 @@
 // Tile geometry, LDS images (+4 float row pad) and fragment maps are those of k_conv_pw.hip.
 #include "lhn_common.h"
 
-template <int KD, int NT, int MODE, int TAPS>
+// ---------------------------------------------------------------------------------------------------------
+// Core.  GEMM rows = 128 pixels per tile (wave w owns rows [32w, 32w+32)), N = 32*NT features, one PHASE =
+// one tap with the whole K = KD: 16*NT*KD/32... MFMAs per wave, long enough to cover memory latency with a single
+// 4-wave workgroup per CU.  While a phase multiplies out of LDS, the A rows of the NEXT phase are already in
+// flight into registers (raw loads; the pending BN/activation/gate or the dy formula is applied when they are
+// committed to LDS after the MFMA loop).  Weights of the next tap are fetched at the start of the commit; for
+// 1x1 (TAPS = 1) they are staged once per block.
+template <int KD, int NT, int MODE, int TAPS, bool DPOOL = false>
 __global__ void __launch_bounds__(256) k_kxk(lhn_view x, const float* __restrict__ w, lhn_view y, lhn_gradview gy,
                                              double* __restrict__ stats, float* __restrict__ dx, int dx_acc, int stride,
                                              int nout, int M, int ntiles, lhn_bnfin fin) {
-  // MODE 0: KD = Cin,  nout = Cout, rows = output pixels of y, A from x
-  // MODE 1: KD = Cout, nout = Cin,  rows = input pixels of x,  A from (gy, y)
-  constexpr int LDA = KD + 4, C4 = KD / 4, RP = 256 / C4, PF = KD / 8;
+  constexpr int BM = 128, LDA = KD + 4;
+  constexpr int C4 = KD / 4, RP = 256 / C4, PF = BM / RP;     // float4 per thread per phase
+  constexpr int NW = 32 * NT * KD / 256;                      // weight scalars per thread per tap
+  constexpr int WCH = NW > 16 ? 16 : NW;                      // staged in chunks of <= 16 registers
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Ws = smem;                   // [32*NT][LDA]  weights of the current tap
+  float* Ws = smem;                   // [32*NT][LDA]
   float* As = smem + 32 * NT * LDA;   // [128][LDA]
-  float* red = As + 128 * LDA;        // [4][32*NT][2]
+  float* red = As + BM * LDA;         // [4][32*NT][2]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
   const int c4 = tid % C4, row0 = tid / C4;
-  const lhn_view& av = MODE == 0 ? x : y;          // view the A operand is read from
-  const lhn_view& ov = MODE == 0 ? y : x;          // geometry of the GEMM rows
+  const lhn_view& av = MODE == 0 ? x : y;
+  const lhn_view& ov = MODE == 0 ? y : x;
+  const int OW = ov.W, OHW = ov.H * ov.W;
+  const int cin_total = MODE == 0 ? KD : nout;
   const int cabs = av.coff + 4 * c4;
   const Xf4 xf = lhn_load_xf(av, cabs);
   Gr4 gr;
   if (MODE == 1) gr = lhn_load_coef(gy, y.cstride, cabs);
-  const int OW = ov.W, OHW = ov.H * ov.W;
-  const int cin_total = MODE == 0 ? KD : nout;     // Cin of the OIHW weight
   float ssum[NT], ssq[NT];
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) ssum[nt] = ssq[nt] = 0.f;
+  for (int j = 0; j < NT; ++j) ssum[j] = ssq[j] = 0.f;
 
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    int rn[PF], rh[PF], rw[PF];
+  constexpr bool LIN = (TAPS == 1);        // 1x1: launched with stride 1 only -> rows are linear pixel indices
+  int rn[LIN ? 1 : PF], rh[LIN ? 1 : PF], rw[LIN ? 1 : PF];
+  f4 pa[PF], pb[MODE == 1 ? PF : 1];
+  bool pv[PF];
+  int cur_tile = 0;
+
+  auto geom = [&](int tile) {
+    cur_tile = tile;
+    if (LIN) return;
 #pragma unroll
     for (int p = 0; p < PF; ++p) {
-      const int m = tile * 128 + row0 + p * RP;
+      const int m = tile * BM + row0 + p * RP;
       if (m < M) {
         rn[p] = m / OHW;
         const int r = m - rn[p] * OHW;
@@ -48,96 +63,171 @@ __global__ void __launch_bounds__(256) k_kxk(lhn_view x, const float* __restrict
         rh[p] = rw[p] = 0;
       }
     }
-    f16v acc[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
-
-    for (int tap = 0; tap < TAPS; ++tap) {
-      const int kh = TAPS == 1 ? 1 : tap / 3, kw = TAPS == 1 ? 1 : tap - (tap / 3) * 3;   // 1x1 = centre tap only
-      // ---- weights of this tap -> LDS as [n][k]   (1x1: once per block)
-      if (TAPS > 1 || tile == (int)blockIdx.x) {
-        if (MODE == 0 || TAPS > 1) {
-          for (int i = tid; i < 32 * NT * KD; i += 256) {
-            const int nn = i / KD, kk = i - nn * KD;
-            float v = 0.f;
-            if (nn < nout) {
-              if (MODE == 0) v = w[((size_t)nn * cin_total + kk) * TAPS + tap];        // W[co=nn][ci=kk][tap]
-              else v = w[((size_t)kk * cin_total + nn) * TAPS + tap];                  // W[co=kk][ci=nn][tap]
-            }
-            Ws[nn * LDA + kk] = v;
-          }
-        } else {
-          // 1x1 dgrad: W^T; read rows of W[co=kk][ci=nn] coalesced along ci, scatter into the [n][k] image
-          for (int i = tid; i < KD * 32 * NT; i += 256) {
-            const int kk = i / (32 * NT), nn = i - kk * (32 * NT);
-            Ws[nn * LDA + kk] = nn < nout ? w[(size_t)kk * cin_total + nn] : 0.f;
-          }
-        }
-      }
-      // ---- A tile of this tap
+  };
+  auto issue = [&](int tap) {
+    const int kh = TAPS == 1 ? 1 : tap / 3, kw = TAPS == 1 ? 1 : tap - (tap / 3) * 3;
+    if (LIN) {
 #pragma unroll
       for (int p = 0; p < PF; ++p) {
-        const int row = row0 + p * RP;
-        f4 v = (f4){0.f, 0.f, 0.f, 0.f};
-        if (rn[p] >= 0) {
-          const int n = rn[p];
-          if (MODE == 0) {
-            const int ih = rh[p] * stride - 1 + kh, iw = rw[p] * stride - 1 + kw;
-            if (ih >= 0 && ih < x.H && iw >= 0 && iw < x.W) {
-              const size_t off = ((size_t)(n * x.H + ih) * x.W + iw) * x.cstride + cabs;
-              v = lhn_apply_xf(*reinterpret_cast<const f4*>(x.data + off), xf);
-              if (x.gate) v *= *reinterpret_cast<const f4*>(x.gate + (size_t)n * x.cstride + cabs);
-            }
-          } else {
-            const int hn = rh[p] + 1 - kh, wn = rw[p] + 1 - kw;
-            if (hn >= 0 && wn >= 0 && hn % stride == 0 && wn % stride == 0) {
-              const int ho = hn / stride, wo = wn / stride;
-              if (ho < y.H && wo < y.W) {
-                const size_t off = ((size_t)(n * y.H + ho) * y.W + wo) * y.cstride + cabs;
-                const f4 raw = *reinterpret_cast<const f4*>(y.data + off);
-                const f4 dz = *reinterpret_cast<const f4*>(gy.dz + off);
-                const f4 du = lhn_grad_du(y, gy, xf, raw, dz, n, ho, wo, cabs);
-                v = gr.A * du + gr.B * raw + gr.Cc;
-              }
-            }
-          }
-        }
-        *reinterpret_cast<f4*>(As + row * LDA + 4 * c4) = v;
+        const int m = cur_tile * BM + row0 + p * RP;
+        pv[p] = m < M;
+        const size_t off = (size_t)min(m, M - 1) * av.cstride + cabs;
+        pa[p] = *reinterpret_cast<const f4*>(av.data + off);
+        if (MODE == 1) pb[MODE == 1 ? p : 0] = *reinterpret_cast<const f4*>(gy.dz + off);
       }
-      __syncthreads();
+      return;
+    }
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {
+      // clamped, always-valid addresses: all loads of the phase issue back to back; validity is a select at commit
+      const int n = rn[p] < 0 ? 0 : rn[p];
+      if (MODE == 0) {
+        const int ih = rh[p] * stride - 1 + kh, iw = rw[p] * stride - 1 + kw;
+        const int ihc = min(max(ih, 0), x.H - 1), iwc = min(max(iw, 0), x.W - 1);
+        pv[p] = rn[p] >= 0 && ih == ihc && iw == iwc;
+        pa[p] = *reinterpret_cast<const f4*>(x.data + ((size_t)(n * x.H + ihc) * x.W + iwc) * x.cstride + cabs);
+      } else {
+        const int hn = rh[p] + 1 - kh, wn2 = rw[p] + 1 - kw;
+        const int ho = hn / stride, wo = wn2 / stride;     // hn, wn2 >= -1: trunc == floor where it matters (validity below)
+        const int hoc = min(max(ho, 0), y.H - 1), woc = min(max(wo, 0), y.W - 1);
+        pv[p] = rn[p] >= 0 && hn >= 0 && wn2 >= 0 && ho * stride == hn && wo * stride == wn2 && ho == hoc && wo == woc;
+        const size_t off = ((size_t)(n * y.H + hoc) * y.W + woc) * y.cstride + cabs;
+        pa[p] = *reinterpret_cast<const f4*>(y.data + off);
+        pb[MODE == 1 ? p : 0] = *reinterpret_cast<const f4*>(gy.dz + off);
+      }
+    }
+  };
+  auto stage_w = [&](int tap) {
+#pragma unroll 1
+    for (int j0 = 0; j0 < NW; j0 += WCH) {
+      float t[WCH];
+#pragma unroll
+      for (int j = 0; j < WCH; ++j) {
+        const int i = tid + 256 * (j0 + j);
+        float v = 0.f;
+        if (MODE == 0 || TAPS > 1) {
+          const int nn = i / KD, kk = i - nn * KD;
+          if (nn < nout) v = MODE == 0 ? w[((size_t)nn * cin_total + kk) * TAPS + tap] : w[((size_t)kk * cin_total + nn) * TAPS + tap];
+        } else {   // 1x1 dgrad: W[co = k][ci = n], coalesced along n
+          const int kk = i / (32 * NT), nn = i - kk * (32 * NT);
+          if (nn < nout) v = w[(size_t)kk * cin_total + nn];
+        }
+        t[j] = v;
+      }
+#pragma unroll
+      for (int j = 0; j < WCH; ++j) {
+        const int i = tid + 256 * (j0 + j);
+        if (MODE == 0 || TAPS > 1) {
+          const int nn = i / KD, kk = i - nn * KD;
+          Ws[nn * LDA + kk] = t[j];
+        } else {
+          const int kk = i / (32 * NT), nn = i - kk * (32 * NT);
+          Ws[nn * LDA + kk] = t[j];
+        }
+      }
+    }
+  };
+  auto commit = [&](int tap) {
+    const int kh = TAPS == 1 ? 1 : tap / 3, kw = TAPS == 1 ? 1 : tap - (tap / 3) * 3;
+    const f4 one = (f4){1.f, 1.f, 1.f, 1.f}, zero = (f4){0.f, 0.f, 0.f, 0.f};
+    if (MODE == 1 && DPOOL) {
+      // rare instantiation: the output carries a channel-attention pooled gradient (fully unrolled: a runtime
+      // index into pa/pb would push the prefetch registers to scratch)
+#pragma unroll
+      for (int p = 0; p < PF; ++p) {
+        f4 v = zero;
+        if (pv[p]) {
+          int n, ho, wo;
+          if (LIN) {
+            const int m = cur_tile * BM + row0 + p * RP;
+            n = m / OHW;
+            const int r = m - n * OHW;
+            ho = r / OW;
+            wo = r - ho * OW;
+          } else {
+            n = rn[p];
+            ho = (rh[p] + 1 - kh) / stride;
+            wo = (rw[p] + 1 - kw) / stride;
+          }
+          const f4 du = lhn_grad_du(y, gy, xf, pa[p], pb[MODE == 1 ? p : 0], n, ho, wo, cabs);
+          v = gr.A * du + gr.B * pa[p] + gr.Cc;
+        }
+        *reinterpret_cast<f4*>(As + (row0 + p * RP) * LDA + 4 * c4) = v;
+      }
+      return;
+    }
+    const float* gptr = av.gate;
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {
+      int n = 0;
+      if (gptr) n = LIN ? min(cur_tile * BM + row0 + p * RP, M - 1) / OHW : (rn[p] < 0 ? 0 : rn[p]);
+      const f4 gate = gptr ? *reinterpret_cast<const f4*>(gptr + (size_t)n * av.cstride + cabs) : one;
+      f4 v;
+      if (MODE == 0) v = lhn_apply_xf(pa[p], xf) * gate;
+      else v = lhn_dy_fast(xf, gr, pa[p], pb[MODE == 1 ? p : 0], gate);
+      *reinterpret_cast<f4*>(As + (row0 + p * RP) * LDA + 4 * c4) = pv[p] ? v : zero;
+    }
+  };
+
+  int tile = blockIdx.x;
+  if (tile < ntiles) {
+    geom(tile);
+    issue(0);
+    stage_w(0);
+    commit(0);
+  }
+  __syncthreads();
+  for (; tile < ntiles; tile += gridDim.x) {
+    f16v acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    const int next_tile = tile + gridDim.x;
+    for (int tap = 0; tap < TAPS; ++tap) {
+      const bool more = (tap + 1 < TAPS) || (next_tile < ntiles);
+      const int ntap = tap + 1 < TAPS ? tap + 1 : 0;
+      if (tap + 1 < TAPS) issue(tap + 1);
+      else if (next_tile < ntiles) {
+        geom(next_tile);
+        issue(0);
+      }
       const float* arow = As + (wave * 32 + l31) * LDA + 4 * lh;
       const float* brow = Ws + l31 * LDA + 4 * lh;
 #pragma unroll 4
       for (int kc = 0; kc < KD / 8; ++kc) {
         const f4 a = *reinterpret_cast<const f4*>(arow + kc * 8);
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          const f4 b = *reinterpret_cast<const f4*>(brow + nt * 32 * LDA + kc * 8);
-          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[nt], 0, 0, 0);
-          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[nt], 0, 0, 0);
-          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[nt], 0, 0, 0);
-          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[nt], 0, 0, 0);
+        for (int j = 0; j < NT; ++j) {
+          const f4 b = *reinterpret_cast<const f4*>(brow + j * 32 * LDA + kc * 8);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[j], 0, 0, 0);
         }
       }
-      __syncthreads();
+      if (more) {
+        __syncthreads();                 // every wave is done reading this phase's LDS images
+        if (TAPS > 1) stage_w(ntap);
+        commit(ntap);
+        __syncthreads();
+      }
     }
-    // ---- epilogue
-    const int mbase = tile * 128 + wave * 32 + 4 * lh;
+    // ---- epilogue (C/D layout: col = lane&31 -> feature, row = (r&3) + 8*(r>>2) + 4*(lane>>5) -> pixel)
+    const int mbase = tile * BM + wave * 32 + 4 * lh;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int ch = nt * 32 + l31;
+    for (int j = 0; j < NT; ++j) {
+      const int ch = j * 32 + l31;
       if (ch >= nout) continue;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = mbase + (r & 3) + 8 * (r >> 2);
         if (m < M) {
-          const float v = acc[nt][r];
+          const float v = acc[j][r];
           if (MODE == 0) {
             y.data[(size_t)m * y.cstride + y.coff + ch] = v;
-            ssum[nt] += v;
-            ssq[nt] += v * v;
+            ssum[j] += v;
+            ssq[j] += v * v;
           } else {
             float* o = dx + (size_t)m * x.cstride + x.coff + ch;
             *o = dx_acc ? *o + v : v;
@@ -147,22 +237,23 @@ __global__ void __launch_bounds__(256) k_kxk(lhn_view x, const float* __restrict
     }
   }
   if (MODE == 0 && stats) {
+    __syncthreads();
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const float s = ssum[nt] + __shfl_xor(ssum[nt], 32, 64);
-      const float q = ssq[nt] + __shfl_xor(ssq[nt], 32, 64);
+    for (int j = 0; j < NT; ++j) {
+      const float s = ssum[j] + __shfl_xor(ssum[j], 32, 64);
+      const float q = ssq[j] + __shfl_xor(ssq[j], 32, 64);
       if (lh == 0) {
-        red[(wave * 32 * NT + nt * 32 + l31) * 2 + 0] = s;
-        red[(wave * 32 * NT + nt * 32 + l31) * 2 + 1] = q;
+        red[(wave * 32 * NT + j * 32 + l31) * 2 + 0] = s;
+        red[(wave * 32 * NT + j * 32 + l31) * 2 + 1] = q;
       }
     }
     __syncthreads();
     if (tid < 32 * NT && tid < nout) {
       double s = 0, q = 0;
 #pragma unroll
-      for (int wv = 0; wv < 4; ++wv) {
-        s += (double)red[(wv * 32 * NT + tid) * 2 + 0];
-        q += (double)red[(wv * 32 * NT + tid) * 2 + 1];
+      for (int k = 0; k < 4; ++k) {
+        s += (double)red[(k * 32 * NT + tid) * 2 + 0];
+        q += (double)red[(k * 32 * NT + tid) * 2 + 1];
       }
       double* st = stats + (size_t)(blockIdx.x % LHN_STAT_REPLICAS) * 2 * nout;
       atomicAdd(st + tid, s);
@@ -173,7 +264,7 @@ __global__ void __launch_bounds__(256) k_kxk(lhn_view x, const float* __restrict
 }
 
 // wgrad: blockIdx.y = tap.  64-pixel tiles; dYs[m][co], Xs[m][ci] (X shifted by the tap) -> dW_tap += dY^T X.
-template <int CIN, int NTO, int TAPS>
+template <int CIN, int NTO, int TAPS, bool DPOOL = false>
 __global__ void __launch_bounds__(256) k_kxk_wgrad(lhn_view x, lhn_view y, lhn_gradview gy, float* __restrict__ dw, int stride,
                                                    int cout, int M, int ntiles, int nrep, int64_t rep_stride) {
   constexpr int NTI = CIN / 32, COP = 32 * NTO, LDY = COP + 4, LDX = CIN + 4;
@@ -189,12 +280,8 @@ __global__ void __launch_bounds__(256) k_kxk_wgrad(lhn_view x, lhn_view y, lhn_g
   const int yc4 = tid % YC4, yr0 = tid / YC4, yabs = y.coff + 4 * yc4;
   const Xf4 xxf = lhn_load_xf(x, xabs);
   const bool ych_ok = 4 * yc4 < cout;
-  Xf4 yxf;
-  Gr4 ygr;
-  if (ych_ok) {
-    yxf = lhn_load_xf(y, yabs);
-    ygr = lhn_load_coef(gy, y.cstride, yabs);
-  }
+  const Xf4 yxf = lhn_load_xf(y, ych_ok ? yabs : y.coff);
+  const Gr4 ygr = lhn_load_coef(gy, y.cstride, ych_ok ? yabs : y.coff);
   const int HoWo = y.H * y.W;
   f16v accw[NDW];
 #pragma unroll
@@ -203,32 +290,54 @@ __global__ void __launch_bounds__(256) k_kxk_wgrad(lhn_view x, lhn_view y, lhn_g
     for (int r = 0; r < 16; ++r) accw[t][r] = 0.f;
 
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const f4 one = (f4){1.f, 1.f, 1.f, 1.f}, zero = (f4){0.f, 0.f, 0.f, 0.f};
+    f4 xraw[XPF], yraw[YPF], ydz[YPF];
+    bool xok[XPF], yok[YPF];
+    int xn[XPF], yn[YPF];
 #pragma unroll
     for (int p = 0; p < XPF; ++p) {
-      const int row = xr0 + p * XRP, m = tile * 64 + row;
-      f4 v = (f4){0.f, 0.f, 0.f, 0.f};
-      if (m < M) {
-        const int n = m / HoWo, r = m - n * HoWo, ho = r / y.W, wo = r - ho * y.W;
-        const int ih = ho * stride - 1 + kh, iw = wo * stride - 1 + kw;
-        if (ih >= 0 && ih < x.H && iw >= 0 && iw < x.W) {
-          v = lhn_apply_xf(*reinterpret_cast<const f4*>(x.data + ((size_t)(n * x.H + ih) * x.W + iw) * x.cstride + xabs), xxf);
-          if (x.gate) v *= *reinterpret_cast<const f4*>(x.gate + (size_t)n * x.cstride + xabs);
-        }
-      }
-      *reinterpret_cast<f4*>(Xs + row * LDX + 4 * xc4) = v;
+      const int m = min(tile * 64 + xr0 + p * XRP, M - 1);
+      const int n = m / HoWo, r = m - n * HoWo, ho = r / y.W, wo = r - ho * y.W;
+      const int ih = ho * stride - 1 + kh, iw = wo * stride - 1 + kw;
+      const int ihc = min(max(ih, 0), x.H - 1), iwc = min(max(iw, 0), x.W - 1);
+      xok[p] = (tile * 64 + xr0 + p * XRP < M) && ih == ihc && iw == iwc;
+      xn[p] = n;
+      xraw[p] = *reinterpret_cast<const f4*>(x.data + ((size_t)(n * x.H + ihc) * x.W + iwc) * x.cstride + xabs);
     }
 #pragma unroll
     for (int p = 0; p < YPF; ++p) {
-      const int row = yr0 + p * YRP, m = tile * 64 + row;
-      f4 v = (f4){0.f, 0.f, 0.f, 0.f};
-      if (m < M && ych_ok) {
-        const int n = m / HoWo, r = m - n * HoWo, h = r / y.W, ww = r - h * y.W;
-        const f4 raw = *reinterpret_cast<const f4*>(y.data + (size_t)m * y.cstride + yabs);
-        const f4 dz = *reinterpret_cast<const f4*>(gy.dz + (size_t)m * y.cstride + yabs);
-        const f4 du = lhn_grad_du(y, gy, yxf, raw, dz, n, h, ww, yabs);
-        v = ygr.A * du + ygr.B * raw + ygr.Cc;
+      const int m = min(tile * 64 + yr0 + p * YRP, M - 1);
+      yok[p] = (tile * 64 + yr0 + p * YRP < M) && ych_ok;
+      yn[p] = m / HoWo;
+      const size_t off = (size_t)m * y.cstride + (ych_ok ? yabs : y.coff);
+      yraw[p] = *reinterpret_cast<const f4*>(y.data + off);
+      ydz[p] = *reinterpret_cast<const f4*>(gy.dz + off);
+    }
+#pragma unroll
+    for (int p = 0; p < XPF; ++p) {
+      const f4 gate = x.gate ? *reinterpret_cast<const f4*>(x.gate + (size_t)xn[p] * x.cstride + xabs) : one;
+      const f4 v = lhn_apply_xf(xraw[p], xxf) * gate;
+      *reinterpret_cast<f4*>(Xs + (xr0 + p * XRP) * LDX + 4 * xc4) = xok[p] ? v : zero;
+    }
+    if (DPOOL) {
+#pragma unroll
+      for (int p = 0; p < YPF; ++p) {
+        f4 v = zero;
+        if (yok[p]) {
+          const int m = tile * 64 + yr0 + p * YRP;
+          const int n = m / HoWo, r = m - n * HoWo, h = r / y.W, ww = r - h * y.W;
+          const f4 du = lhn_grad_du(y, gy, yxf, yraw[p], ydz[p], n, h, ww, yabs);
+          v = ygr.A * du + ygr.B * yraw[p] + ygr.Cc;
+        }
+        *reinterpret_cast<f4*>(dYs + (yr0 + p * YRP) * LDY + 4 * yc4) = v;
       }
-      *reinterpret_cast<f4*>(dYs + row * LDY + 4 * yc4) = v;
+    } else {
+#pragma unroll
+      for (int p = 0; p < YPF; ++p) {
+        const f4 gate = (y.gate && ych_ok) ? *reinterpret_cast<const f4*>(y.gate + (size_t)yn[p] * y.cstride + yabs) : one;
+        const f4 v = lhn_dy_fast(yxf, ygr, yraw[p], ydz[p], gate);
+        *reinterpret_cast<f4*>(dYs + (yr0 + p * YRP) * LDY + 4 * yc4) = yok[p] ? v : zero;
+      }
     }
     __syncthreads();
 #pragma unroll 4
@@ -261,7 +370,7 @@ __global__ void __launch_bounds__(256) k_kxk_wgrad(lhn_view x, lhn_view y, lhn_g
   }
 }
 
-template <int KD, int NT, int MODE, int TAPS>
+template <int KD, int NT, int MODE, int TAPS, bool DPOOL = false>
 static int launch_kxk(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, double* stats, float* dx,
                       int dx_acc, int stride, int nout, hipStream_t s, const lhn_bnfin* finp = nullptr) {
   lhn_bnfin fin;
@@ -271,7 +380,7 @@ static int launch_kxk(const lhn_view* x, const float* w, const lhn_view* y, cons
   const size_t lds = (size_t)((32 * NT + 128) * (KD + 4) + 4 * 32 * NT * 2) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kxk<KD, NT, MODE, TAPS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kxk<KD, NT, MODE, TAPS, DPOOL>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess) {
       lhn_set_error("lhn_conv_kxk: cannot reserve %zu B of LDS", lds);
       return 2;
@@ -285,11 +394,11 @@ static int launch_kxk(const lhn_view* x, const float* w, const lhn_view* y, cons
   if (grid > ntiles) grid = ntiles;
   lhn_gradview g;
   if (gy) g = *gy; else g.dz = g.dpool = g.coef = nullptr;
-  hipLaunchKernelGGL((k_kxk<KD, NT, MODE, TAPS>), dim3(grid), dim3(256), lds, s, *x, w, *y, g, stats, dx, dx_acc, stride, nout, M, ntiles, fin);
+  hipLaunchKernelGGL((k_kxk<KD, NT, MODE, TAPS, DPOOL>), dim3(grid), dim3(256), lds, s, *x, w, *y, g, stats, dx, dx_acc, stride, nout, M, ntiles, fin);
   return 0;
 }
 
-template <int CIN, int NTO, int TAPS>
+template <int CIN, int NTO, int TAPS, bool DPOOL = false>
 static int launch_kxk_wgrad(const lhn_view* x, const lhn_view* y, const lhn_gradview* gy, float* dw, int stride, int nrep,
                             int64_t rep_stride, hipStream_t s) {
   const int M = y->N * y->H * y->W, ntiles = (M + 63) / 64;
@@ -297,7 +406,7 @@ static int launch_kxk_wgrad(const lhn_view* x, const lhn_view* y, const lhn_grad
   const size_t lds = (size_t)(64 * (COP + 4) + 64 * (CIN + 4)) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kxk_wgrad<CIN, NTO, TAPS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kxk_wgrad<CIN, NTO, TAPS, DPOOL>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess) {
       lhn_set_error("lhn_conv_kxk_bwd: cannot reserve %zu B of LDS", lds);
       return 2;
@@ -310,7 +419,7 @@ static int launch_kxk_wgrad(const lhn_view* x, const lhn_view* y, const lhn_grad
   int grid = TAPS == 1 ? lhn_num_cus() * per_cu : lhn_num_cus() / 4;      // x 9 taps
   if (grid < 1) grid = 1;
   if (grid > ntiles) grid = ntiles;
-  hipLaunchKernelGGL((k_kxk_wgrad<CIN, NTO, TAPS>), dim3(grid, TAPS), dim3(256), lds, s, *x, *y, *gy, dw, stride, y->C, M, ntiles, nrep,
+  hipLaunchKernelGGL((k_kxk_wgrad<CIN, NTO, TAPS, DPOOL>), dim3(grid, TAPS), dim3(256), lds, s, *x, *y, *gy, dw, stride, y->C, M, ntiles, nrep,
                      rep_stride);
   return 0;
 }
@@ -344,7 +453,7 @@ extern "C" int lhn_conv_kxk_bwd(const lhn_view* x, const float* w, const lhn_vie
   int rc = -1;
   if (dx) {
     const int nt = (x->C + 31) / 32;   // GEMM N = Cin, K = Cout
-#define KB(CO, NTV) if (y->C == CO && nt == NTV) rc = launch_kxk<CO, NTV, 1, 9>(x, w, y, gy, nullptr, dx, dx_accumulate, stride, x->C, s);
+#define KB(CO, NTV) if (y->C == CO && nt == NTV) rc = gy->dpool ? launch_kxk<CO, NTV, 1, 9, true>(x, w, y, gy, nullptr, dx, dx_accumulate, stride, x->C, s) : launch_kxk<CO, NTV, 1, 9, false>(x, w, y, gy, nullptr, dx, dx_accumulate, stride, x->C, s);
     KB(32, 1) KB(64, 2) KB(128, 4) KB(32, 2) KB(64, 1) KB(64, 4) KB(128, 2) KB(128, 1) KB(32, 4)
 #undef KB
     LHN_CHECK_ARG(rc != -1, "lhn_conv_kxk_bwd: unsupported channels Cin=%d Cout=%d", x->C, y->C);
@@ -352,7 +461,7 @@ extern "C" int lhn_conv_kxk_bwd(const lhn_view* x, const float* w, const lhn_vie
   }
   rc = -1;
   const int nto = (y->C + 31) / 32;
-#define KW(CI, NTV) if (x->C == CI && nto == NTV) rc = launch_kxk_wgrad<CI, NTV, 9>(x, y, gy, dw, stride, nrep, rep_stride, s);
+#define KW(CI, NTV) if (x->C == CI && nto == NTV) rc = gy->dpool ? launch_kxk_wgrad<CI, NTV, 9, true>(x, y, gy, dw, stride, nrep, rep_stride, s) : launch_kxk_wgrad<CI, NTV, 9, false>(x, y, gy, dw, stride, nrep, rep_stride, s);
   KW(32, 1) KW(64, 2) KW(128, 4) KW(32, 2) KW(64, 1) KW(64, 4) KW(128, 2) KW(128, 1) KW(32, 4)
 #undef KW
   LHN_CHECK_ARG(rc != -1, "lhn_conv_kxk_bwd: unsupported channels Cin=%d Cout=%d", x->C, y->C);
@@ -368,14 +477,14 @@ int lhn_pw_bwd_split(const lhn_view* x, const float* w, const lhn_view* y, const
   int rc = -1;
   if (dx) {
     const int nt = (x->C + 31) / 32;
-#define PB(CO, NTV) if (y->C == CO && nt == NTV) rc = launch_kxk<CO, NTV, 1, 1>(x, w, y, gy, nullptr, dx, dx_accumulate, 1, x->C, s);
+#define PB(CO, NTV) if (y->C == CO && nt == NTV) rc = gy->dpool ? launch_kxk<CO, NTV, 1, 1, true>(x, w, y, gy, nullptr, dx, dx_accumulate, 1, x->C, s) : launch_kxk<CO, NTV, 1, 1, false>(x, w, y, gy, nullptr, dx, dx_accumulate, 1, x->C, s);
     PB(64, 4) PB(128, 4) PB(128, 2) PB(64, 2) PB(128, 1) PB(32, 4)
 #undef PB
     if (rc) return rc;
   }
   rc = -1;
   const int nto = (y->C + 31) / 32;
-#define PW(CI, NTV) if (x->C == CI && nto == NTV) rc = launch_kxk_wgrad<CI, NTV, 1>(x, y, gy, dw, 1, nrep, rep_stride, s);
+#define PW(CI, NTV) if (x->C == CI && nto == NTV) rc = gy->dpool ? launch_kxk_wgrad<CI, NTV, 1, true>(x, y, gy, dw, 1, nrep, rep_stride, s) : launch_kxk_wgrad<CI, NTV, 1, false>(x, y, gy, dw, 1, nrep, rep_stride, s);
   PW(64, 4) PW(128, 4) PW(128, 2) PW(64, 2) PW(128, 1) PW(32, 4)
 #undef PW
   return rc;
