@@ -159,6 +159,8 @@ int lhn_conv_dw_bwd(const lhn_view* x, const float* w, const lhn_view* y, const 
                     void* stream);
 int lhn_conv_stem_bwd(const float* img, const lhn_view* y, const lhn_gradview* gy, float* dw, int Hi, int Wi,
                       int k, int stride, int pad, int nrep, int64_t rep_stride, void* stream);
+/* NOTE: lhn_conv_kxk_bwd and the large-channel path of lhn_conv_pw_bwd CONSUME gy->dz (it is overwritten in place
+ * with dy before the MFMA kernels stream it). */
 int lhn_conv_kxk_bwd(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx,
                      int dx_accumulate, float* dw, int stride, int nrep, int64_t rep_stride, void* stream);
 /* out[i] = sum_r part[r*rep_stride + i]  (folds the replicated weight-gradient partials into the flat gradient) */

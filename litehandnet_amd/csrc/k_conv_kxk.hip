@@ -6,7 +6,34 @@
 //                  taps mirrored, epilogue = dx store / accumulate
 // wgrad          : one tap per blockIdx.y, dW_tap[co][ci] += dY^T X_shifted in registers across the block's tiles.
 // Tile geometry, LDS images (+4 float row pad) and fragment maps are those of k_conv_pw.hip.
+#include <stdlib.h>
 #include "lhn_common.h"
+
+// dz := dy in place (dy = A*du + B*y + C with du from gate / pooled gradient / leaky derivative).  Used ahead of the
+// MFMA-heavy backward kernels: they then stream ONE plain tensor instead of (dz, raw y) + the formula per element,
+// which halves their prefetch registers (no spills) -- worth one extra elementwise pass when Cin*Cout is large.
+__global__ void __launch_bounds__(256) k_dy_inplace(lhn_view y, lhn_gradview g, float* __restrict__ dz) {
+  const int C4 = y.C >> 2, c4 = threadIdx.x % C4, pl = threadIdx.x / C4, PL = 256 / C4;
+  const int ca = y.coff + 4 * c4;
+  const Xf4 xf = lhn_load_xf(y, ca);
+  const Gr4 gr = lhn_load_coef(g, y.cstride, ca);
+  const int rows = y.N * y.H;
+  for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+    const int n = row / y.H, h = row - n * y.H;
+    for (int w = pl; w < y.W; w += PL) {
+      const size_t off = ((size_t)row * y.W + w) * y.cstride + ca;
+      const f4 raw = *reinterpret_cast<const f4*>(y.data + off);
+      const f4 du = lhn_grad_du(y, g, xf, raw, *reinterpret_cast<const f4*>(dz + off), n, h, w, ca);
+      *reinterpret_cast<f4*>(dz + off) = gr.A * du + gr.B * raw + gr.Cc;
+    }
+  }
+}
+static void launch_dy_inplace(const lhn_view* y, const lhn_gradview* gy, hipStream_t s) {
+  int64_t g = (int64_t)y->N * y->H;
+  const int64_t cap = (int64_t)lhn_num_cus() * 8;
+  if (g > cap) g = cap;
+  hipLaunchKernelGGL(k_dy_inplace, dim3((int)g), dim3(256), 0, s, *y, *gy, const_cast<float*>(gy->dz));
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // Core.  GEMM rows = 128 pixels per tile (wave w owns rows [32w, 32w+32)), N = 32*NT features, one PHASE =
@@ -15,7 +42,7 @@
 // flight into registers (raw loads; the pending BN/activation/gate or the dy formula is applied when they are
 // committed to LDS after the MFMA loop).  Weights of the next tap are fetched at the start of the commit; for
 // 1x1 (TAPS = 1) they are staged once per block.
-template <int KD, int NT, int MODE, int TAPS, bool DPOOL = false>
+template <int KD, int NT, int MODE, int TAPS, bool PLAIN = false>
 __global__ void __launch_bounds__(256) k_kxk(lhn_view x, const float* __restrict__ w, lhn_view y, lhn_gradview gy,
                                              double* __restrict__ stats, float* __restrict__ dx, int dx_acc, int stride,
                                              int nout, int M, int ntiles, lhn_bnfin fin) {
@@ -43,7 +70,7 @@ __global__ void __launch_bounds__(256) k_kxk(lhn_view x, const float* __restrict
 
   constexpr bool LIN = (TAPS == 1);        // 1x1: launched with stride 1 only -> rows are linear pixel indices
   int rn[LIN ? 1 : PF], rh[LIN ? 1 : PF], rw[LIN ? 1 : PF];
-  f4 pa[PF], pb[MODE == 1 ? PF : 1];
+  f4 pa[PF], pb[(MODE == 1 && !PLAIN) ? PF : 1];
   bool pv[PF];
   int cur_tile = 0;
 
@@ -72,8 +99,9 @@ __global__ void __launch_bounds__(256) k_kxk(lhn_view x, const float* __restrict
         const int m = cur_tile * BM + row0 + p * RP;
         pv[p] = m < M;
         const size_t off = (size_t)min(m, M - 1) * av.cstride + cabs;
-        pa[p] = *reinterpret_cast<const f4*>(av.data + off);
-        if (MODE == 1) pb[MODE == 1 ? p : 0] = *reinterpret_cast<const f4*>(gy.dz + off);
+        if (MODE == 1 && PLAIN) pa[p] = *reinterpret_cast<const f4*>(gy.dz + off);
+        else pa[p] = *reinterpret_cast<const f4*>(av.data + off);
+        if (MODE == 1 && !PLAIN) pb[(MODE == 1 && !PLAIN) ? p : 0] = *reinterpret_cast<const f4*>(gy.dz + off);
       }
       return;
     }
@@ -92,8 +120,11 @@ __global__ void __launch_bounds__(256) k_kxk(lhn_view x, const float* __restrict
         const int hoc = min(max(ho, 0), y.H - 1), woc = min(max(wo, 0), y.W - 1);
         pv[p] = rn[p] >= 0 && hn >= 0 && wn2 >= 0 && ho * stride == hn && wo * stride == wn2 && ho == hoc && wo == woc;
         const size_t off = ((size_t)(n * y.H + hoc) * y.W + woc) * y.cstride + cabs;
-        pa[p] = *reinterpret_cast<const f4*>(y.data + off);
-        pb[MODE == 1 ? p : 0] = *reinterpret_cast<const f4*>(gy.dz + off);
+        if (PLAIN) pa[p] = *reinterpret_cast<const f4*>(gy.dz + off);
+        else {
+          pa[p] = *reinterpret_cast<const f4*>(y.data + off);
+          pb[(MODE == 1 && !PLAIN) ? p : 0] = *reinterpret_cast<const f4*>(gy.dz + off);
+        }
       }
     }
   };
@@ -130,30 +161,9 @@ __global__ void __launch_bounds__(256) k_kxk(lhn_view x, const float* __restrict
   auto commit = [&](int tap) {
     const int kh = TAPS == 1 ? 1 : tap / 3, kw = TAPS == 1 ? 1 : tap - (tap / 3) * 3;
     const f4 one = (f4){1.f, 1.f, 1.f, 1.f}, zero = (f4){0.f, 0.f, 0.f, 0.f};
-    if (MODE == 1 && DPOOL) {
-      // rare instantiation: the output carries a channel-attention pooled gradient (fully unrolled: a runtime
-      // index into pa/pb would push the prefetch registers to scratch)
+    if (MODE == 1 && PLAIN) {
 #pragma unroll
-      for (int p = 0; p < PF; ++p) {
-        f4 v = zero;
-        if (pv[p]) {
-          int n, ho, wo;
-          if (LIN) {
-            const int m = cur_tile * BM + row0 + p * RP;
-            n = m / OHW;
-            const int r = m - n * OHW;
-            ho = r / OW;
-            wo = r - ho * OW;
-          } else {
-            n = rn[p];
-            ho = (rh[p] + 1 - kh) / stride;
-            wo = (rw[p] + 1 - kw) / stride;
-          }
-          const f4 du = lhn_grad_du(y, gy, xf, pa[p], pb[MODE == 1 ? p : 0], n, ho, wo, cabs);
-          v = gr.A * du + gr.B * pa[p] + gr.Cc;
-        }
-        *reinterpret_cast<f4*>(As + (row0 + p * RP) * LDA + 4 * c4) = v;
-      }
+      for (int p = 0; p < PF; ++p) *reinterpret_cast<f4*>(As + (row0 + p * RP) * LDA + 4 * c4) = pv[p] ? pa[p] : zero;
       return;
     }
     const float* gptr = av.gate;
@@ -164,7 +174,7 @@ __global__ void __launch_bounds__(256) k_kxk(lhn_view x, const float* __restrict
       const f4 gate = gptr ? *reinterpret_cast<const f4*>(gptr + (size_t)n * av.cstride + cabs) : one;
       f4 v;
       if (MODE == 0) v = lhn_apply_xf(pa[p], xf) * gate;
-      else v = lhn_dy_fast(xf, gr, pa[p], pb[MODE == 1 ? p : 0], gate);
+      else v = lhn_dy_fast(xf, gr, pa[p], pb[(MODE == 1 && !PLAIN) ? p : 0], gate);
       *reinterpret_cast<f4*>(As + (row0 + p * RP) * LDA + 4 * c4) = pv[p] ? v : zero;
     }
   };
@@ -264,7 +274,7 @@ __global__ void __launch_bounds__(256) k_kxk(lhn_view x, const float* __restrict
 }
 
 // wgrad: blockIdx.y = tap.  64-pixel tiles; dYs[m][co], Xs[m][ci] (X shifted by the tap) -> dW_tap += dY^T X.
-template <int CIN, int NTO, int TAPS, bool DPOOL = false>
+template <int CIN, int NTO, int TAPS, bool PLAIN = false>
 __global__ void __launch_bounds__(256) k_kxk_wgrad(lhn_view x, lhn_view y, lhn_gradview gy, float* __restrict__ dw, int stride,
                                                    int cout, int M, int ntiles, int nrep, int64_t rep_stride) {
   constexpr int NTI = CIN / 32, COP = 32 * NTO, LDY = COP + 4, LDX = CIN + 4;
@@ -289,11 +299,12 @@ __global__ void __launch_bounds__(256) k_kxk_wgrad(lhn_view x, lhn_view y, lhn_g
 #pragma unroll
     for (int r = 0; r < 16; ++r) accw[t][r] = 0.f;
 
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const f4 one = (f4){1.f, 1.f, 1.f, 1.f}, zero = (f4){0.f, 0.f, 0.f, 0.f};
-    f4 xraw[XPF], yraw[YPF], ydz[YPF];
-    bool xok[XPF], yok[YPF];
-    int xn[XPF], yn[YPF];
+  const f4 one = (f4){1.f, 1.f, 1.f, 1.f}, zero = (f4){0.f, 0.f, 0.f, 0.f};
+  f4 xraw[XPF], yraw[PLAIN ? 1 : YPF], ydz[YPF];
+  bool xok[XPF], yok[YPF];
+  int xn[XPF], yn[YPF];
+  // raw global loads of one 64-pixel tile into registers (clamped addresses, validity kept as predicates)
+  auto issue = [&](int tile) {
 #pragma unroll
     for (int p = 0; p < XPF; ++p) {
       const int m = min(tile * 64 + xr0 + p * XRP, M - 1);
@@ -310,35 +321,34 @@ __global__ void __launch_bounds__(256) k_kxk_wgrad(lhn_view x, lhn_view y, lhn_g
       yok[p] = (tile * 64 + yr0 + p * YRP < M) && ych_ok;
       yn[p] = m / HoWo;
       const size_t off = (size_t)m * y.cstride + (ych_ok ? yabs : y.coff);
-      yraw[p] = *reinterpret_cast<const f4*>(y.data + off);
+      if (!PLAIN) yraw[PLAIN ? 0 : p] = *reinterpret_cast<const f4*>(y.data + off);
       ydz[p] = *reinterpret_cast<const f4*>(gy.dz + off);
     }
+  };
+  // transform and park them in LDS
+  auto commit = [&]() {
 #pragma unroll
     for (int p = 0; p < XPF; ++p) {
       const f4 gate = x.gate ? *reinterpret_cast<const f4*>(x.gate + (size_t)xn[p] * x.cstride + xabs) : one;
       const f4 v = lhn_apply_xf(xraw[p], xxf) * gate;
       *reinterpret_cast<f4*>(Xs + (xr0 + p * XRP) * LDX + 4 * xc4) = xok[p] ? v : zero;
     }
-    if (DPOOL) {
+    if (PLAIN) {
 #pragma unroll
-      for (int p = 0; p < YPF; ++p) {
-        f4 v = zero;
-        if (yok[p]) {
-          const int m = tile * 64 + yr0 + p * YRP;
-          const int n = m / HoWo, r = m - n * HoWo, h = r / y.W, ww = r - h * y.W;
-          const f4 du = lhn_grad_du(y, gy, yxf, yraw[p], ydz[p], n, h, ww, yabs);
-          v = ygr.A * du + ygr.B * yraw[p] + ygr.Cc;
-        }
-        *reinterpret_cast<f4*>(dYs + (yr0 + p * YRP) * LDY + 4 * yc4) = v;
-      }
+      for (int p = 0; p < YPF; ++p) *reinterpret_cast<f4*>(dYs + (yr0 + p * YRP) * LDY + 4 * yc4) = yok[p] ? ydz[p] : zero;
     } else {
 #pragma unroll
       for (int p = 0; p < YPF; ++p) {
         const f4 gate = (y.gate && ych_ok) ? *reinterpret_cast<const f4*>(y.gate + (size_t)yn[p] * y.cstride + yabs) : one;
-        const f4 v = lhn_dy_fast(yxf, ygr, yraw[p], ydz[p], gate);
+        const f4 v = lhn_dy_fast(yxf, ygr, yraw[PLAIN ? 0 : p], ydz[p], gate);
         *reinterpret_cast<f4*>(dYs + (yr0 + p * YRP) * LDY + 4 * yc4) = yok[p] ? v : zero;
       }
     }
+  };
+  // (a register-prefetch variant of this loop produced wrong dW for NTO*NTI == 1 on hipcc 7.2 -- kept simple)
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    issue(tile);
+    commit();
     __syncthreads();
 #pragma unroll 4
     for (int ks = 0; ks < 32; ++ks) {
@@ -370,7 +380,7 @@ __global__ void __launch_bounds__(256) k_kxk_wgrad(lhn_view x, lhn_view y, lhn_g
   }
 }
 
-template <int KD, int NT, int MODE, int TAPS, bool DPOOL = false>
+template <int KD, int NT, int MODE, int TAPS, bool PLAIN = false>
 static int launch_kxk(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, double* stats, float* dx,
                       int dx_acc, int stride, int nout, hipStream_t s, const lhn_bnfin* finp = nullptr) {
   lhn_bnfin fin;
@@ -380,7 +390,7 @@ static int launch_kxk(const lhn_view* x, const float* w, const lhn_view* y, cons
   const size_t lds = (size_t)((32 * NT + 128) * (KD + 4) + 4 * 32 * NT * 2) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kxk<KD, NT, MODE, TAPS, DPOOL>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kxk<KD, NT, MODE, TAPS, PLAIN>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess) {
       lhn_set_error("lhn_conv_kxk: cannot reserve %zu B of LDS", lds);
       return 2;
@@ -394,11 +404,11 @@ static int launch_kxk(const lhn_view* x, const float* w, const lhn_view* y, cons
   if (grid > ntiles) grid = ntiles;
   lhn_gradview g;
   if (gy) g = *gy; else g.dz = g.dpool = g.coef = nullptr;
-  hipLaunchKernelGGL((k_kxk<KD, NT, MODE, TAPS, DPOOL>), dim3(grid), dim3(256), lds, s, *x, w, *y, g, stats, dx, dx_acc, stride, nout, M, ntiles, fin);
+  hipLaunchKernelGGL((k_kxk<KD, NT, MODE, TAPS, PLAIN>), dim3(grid), dim3(256), lds, s, *x, w, *y, g, stats, dx, dx_acc, stride, nout, M, ntiles, fin);
   return 0;
 }
 
-template <int CIN, int NTO, int TAPS, bool DPOOL = false>
+template <int CIN, int NTO, int TAPS, bool PLAIN = false>
 static int launch_kxk_wgrad(const lhn_view* x, const lhn_view* y, const lhn_gradview* gy, float* dw, int stride, int nrep,
                             int64_t rep_stride, hipStream_t s) {
   const int M = y->N * y->H * y->W, ntiles = (M + 63) / 64;
@@ -406,7 +416,7 @@ static int launch_kxk_wgrad(const lhn_view* x, const lhn_view* y, const lhn_grad
   const size_t lds = (size_t)(64 * (COP + 4) + 64 * (CIN + 4)) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kxk_wgrad<CIN, NTO, TAPS, DPOOL>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kxk_wgrad<CIN, NTO, TAPS, PLAIN>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess) {
       lhn_set_error("lhn_conv_kxk_bwd: cannot reserve %zu B of LDS", lds);
       return 2;
@@ -419,7 +429,7 @@ static int launch_kxk_wgrad(const lhn_view* x, const lhn_view* y, const lhn_grad
   int grid = TAPS == 1 ? lhn_num_cus() * per_cu : lhn_num_cus() / 4;      // x 9 taps
   if (grid < 1) grid = 1;
   if (grid > ntiles) grid = ntiles;
-  hipLaunchKernelGGL((k_kxk_wgrad<CIN, NTO, TAPS, DPOOL>), dim3(grid, TAPS), dim3(256), lds, s, *x, *y, *gy, dw, stride, y->C, M, ntiles, nrep,
+  hipLaunchKernelGGL((k_kxk_wgrad<CIN, NTO, TAPS, PLAIN>), dim3(grid, TAPS), dim3(256), lds, s, *x, *y, *gy, dw, stride, y->C, M, ntiles, nrep,
                      rep_stride);
   return 0;
 }
@@ -451,9 +461,13 @@ extern "C" int lhn_conv_kxk_bwd(const lhn_view* x, const float* w, const lhn_vie
   if (nrep < 1) nrep = 1;
   hipStream_t s = (hipStream_t)stream;
   int rc = -1;
+  // large channel counts (or a channel-attention pooled gradient): turn dz into dy in place, then stream it plain
+  const char* pe = getenv("LHN_PLAIN");
+  const bool plain = pe ? (pe[0] == '1') : ((x->C * y->C >= 64 * 64) || gy->dpool);
+  if (plain) launch_dy_inplace(y, gy, s);
   if (dx) {
     const int nt = (x->C + 31) / 32;   // GEMM N = Cin, K = Cout
-#define KB(CO, NTV) if (y->C == CO && nt == NTV) rc = gy->dpool ? launch_kxk<CO, NTV, 1, 9, true>(x, w, y, gy, nullptr, dx, dx_accumulate, stride, x->C, s) : launch_kxk<CO, NTV, 1, 9, false>(x, w, y, gy, nullptr, dx, dx_accumulate, stride, x->C, s);
+#define KB(CO, NTV) if (y->C == CO && nt == NTV) rc = plain ? launch_kxk<CO, NTV, 1, 9, true>(x, w, y, gy, nullptr, dx, dx_accumulate, stride, x->C, s) : launch_kxk<CO, NTV, 1, 9, false>(x, w, y, gy, nullptr, dx, dx_accumulate, stride, x->C, s);
     KB(32, 1) KB(64, 2) KB(128, 4) KB(32, 2) KB(64, 1) KB(64, 4) KB(128, 2) KB(128, 1) KB(32, 4)
 #undef KB
     LHN_CHECK_ARG(rc != -1, "lhn_conv_kxk_bwd: unsupported channels Cin=%d Cout=%d", x->C, y->C);
@@ -461,7 +475,7 @@ extern "C" int lhn_conv_kxk_bwd(const lhn_view* x, const float* w, const lhn_vie
   }
   rc = -1;
   const int nto = (y->C + 31) / 32;
-#define KW(CI, NTV) if (x->C == CI && nto == NTV) rc = gy->dpool ? launch_kxk_wgrad<CI, NTV, 9, true>(x, y, gy, dw, stride, nrep, rep_stride, s) : launch_kxk_wgrad<CI, NTV, 9, false>(x, y, gy, dw, stride, nrep, rep_stride, s);
+#define KW(CI, NTV) if (x->C == CI && nto == NTV) rc = plain ? launch_kxk_wgrad<CI, NTV, 9, true>(x, y, gy, dw, stride, nrep, rep_stride, s) : launch_kxk_wgrad<CI, NTV, 9, false>(x, y, gy, dw, stride, nrep, rep_stride, s);
   KW(32, 1) KW(64, 2) KW(128, 4) KW(32, 2) KW(64, 1) KW(64, 4) KW(128, 2) KW(128, 1) KW(32, 4)
 #undef KW
   LHN_CHECK_ARG(rc != -1, "lhn_conv_kxk_bwd: unsupported channels Cin=%d Cout=%d", x->C, y->C);
@@ -475,16 +489,17 @@ extern "C" int lhn_conv_kxk_bwd(const lhn_view* x, const float* w, const lhn_vie
 int lhn_pw_bwd_split(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx, int dx_accumulate,
                      float* dw, int nrep, int64_t rep_stride, hipStream_t s) {
   int rc = -1;
+  launch_dy_inplace(y, gy, s);
   if (dx) {
     const int nt = (x->C + 31) / 32;
-#define PB(CO, NTV) if (y->C == CO && nt == NTV) rc = gy->dpool ? launch_kxk<CO, NTV, 1, 1, true>(x, w, y, gy, nullptr, dx, dx_accumulate, 1, x->C, s) : launch_kxk<CO, NTV, 1, 1, false>(x, w, y, gy, nullptr, dx, dx_accumulate, 1, x->C, s);
+#define PB(CO, NTV) if (y->C == CO && nt == NTV) rc = launch_kxk<CO, NTV, 1, 1, true>(x, w, y, gy, nullptr, dx, dx_accumulate, 1, x->C, s);
     PB(64, 4) PB(128, 4) PB(128, 2) PB(64, 2) PB(128, 1) PB(32, 4)
 #undef PB
     if (rc) return rc;
   }
   rc = -1;
   const int nto = (y->C + 31) / 32;
-#define PW(CI, NTV) if (x->C == CI && nto == NTV) rc = gy->dpool ? launch_kxk_wgrad<CI, NTV, 1, true>(x, y, gy, dw, 1, nrep, rep_stride, s) : launch_kxk_wgrad<CI, NTV, 1, false>(x, y, gy, dw, 1, nrep, rep_stride, s);
+#define PW(CI, NTV) if (x->C == CI && nto == NTV) rc = launch_kxk_wgrad<CI, NTV, 1, true>(x, y, gy, dw, 1, nrep, rep_stride, s);
   PW(64, 4) PW(128, 4) PW(128, 2) PW(64, 2) PW(128, 1) PW(32, 4)
 #undef PW
   return rc;
