@@ -95,6 +95,10 @@ int lhn_transform_preds(const float* coords /*[N,K,2]*/, const float* center /*[
 int lhn_heatmap_decode(const float* hm, const float* center, const float* scale, float* hm_preds,
                        float* preds, float* maxvals, int N, int K, int H, int W, int post_process,
                        void* stream);
+/* DARK 'unbiased' decode: k x k Gaussian modulation + log + Taylor step (top_down_eval.py:233-272,338-372,433-439;
+ * twin utils/heatmap_post_processing.py:35-91), fused with argmax and transform_preds */
+int lhn_heatmap_decode_dark(const float* hm, const float* center, const float* scale, float* hm_preds,
+                            float* preds, float* maxvals, int N, int K, int H, int W, int kernel, void* stream);
 int lhn_heatmap_nms(float* hm /*in place*/, float* scratch /*same size*/, int N, int K, int H, int W,
                     int kernel, void* stream);
 int lhn_pck_accuracy(const float* pred, const float* gt, const uint8_t* mask /*[N,K]*/,

@@ -440,3 +440,106 @@ int lhn_loss_balanced_mse_bwd(const float* out, const float* target, const float
   return 0;
 }
 }  // extern "C"
+
+// ------------------------------------------------------------------ DARK ("unbiased") decode
+// top_down_eval.py:233-272 (_gaussian_blur: k x k Gaussian on the zero-padded map, re-normalised to the original
+// max), :433-439 (log(max(., 1e-10))), :338-372 (_taylor), then transform_preds.  One workgroup per (n, k) map,
+// the whole map in LDS.  cv2.GaussianBlur is absent from the build container: the kernel follows OpenCV's
+// documented rule sigma = 0.3*((k-1)*0.5-1)+0.8, normalised taps, separable, float32 -- "parity unpinned" at bit
+// level, tolerance-tested against the numpy oracle.
+__global__ void __launch_bounds__(256) k_dark(const float* __restrict__ hm, const float* __restrict__ center,
+                                              const float* __restrict__ scale, float* __restrict__ hm_preds,
+                                              float* __restrict__ preds, float* __restrict__ maxvals, int K, int H, int W,
+                                              int ksize) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int HW = H * W, nk = blockIdx.x, b = (ksize - 1) / 2;
+  float* A = smem;            // original map, later the blurred map
+  float* B = smem + HW;       // row-blurred
+  __shared__ float taps[32];
+  __shared__ float sred[4];
+  const float* m = hm + (int64_t)nk * HW;
+  if (threadIdx.x < ksize) {
+    const double sigma = 0.3 * ((ksize - 1) * 0.5 - 1) + 0.8;
+    double sum = 0;
+    for (int t = 0; t < ksize; ++t) {
+      const double xx = t - (ksize - 1) * 0.5;
+      sum += exp(-(xx * xx) / (2 * sigma * sigma));
+    }
+    const double xx = threadIdx.x - (ksize - 1) * 0.5;
+    taps[threadIdx.x] = (float)(exp(-(xx * xx) / (2 * sigma * sigma)) / sum);
+  }
+  for (int i = threadIdx.x; i < HW; i += blockDim.x) A[i] = m[i];
+  const MaxI r = block_argmax(m, HW);          // contains a barrier
+  __syncthreads();
+  for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+    const int x = i % W, y = i / W;
+    float s = 0.f;
+    for (int t = 0; t < ksize; ++t) {
+      const int xx = x + t - b;
+      if (xx >= 0 && xx < W) s += taps[t] * A[y * W + xx];
+    }
+    B[i] = s;
+  }
+  __syncthreads();
+  float mx = -INFINITY;
+  for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+    const int x = i % W, y = i / W;
+    float s = 0.f;
+    for (int t = 0; t < ksize; ++t) {
+      const int yy = y + t - b;
+      if (yy >= 0 && yy < H) s += taps[t] * B[yy * W + x];
+    }
+    A[i] = s;
+    mx = fmaxf(mx, s);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float bmax = fmaxf(fmaxf(sred[0], sred[1]), fmaxf(sred[2], sred[3]));
+    const float sc = r.v / bmax;               // heatmaps[i, j] *= origin_max / np.max(heatmaps[i, j])
+    float x = (float)(r.i % W), y = (float)(r.i / W);
+    if (!(r.v > 0.f)) x = y = -1.f;
+    const int px = (int)x, py = (int)y;
+    if (1 < px && px < W - 2 && 1 < py && py < H - 2) {
+      auto L = [&](int yy, int xx) { return logf(fmaxf(A[yy * W + xx] * sc, 1e-10f)); };
+      const float dx = 0.5f * (L(py, px + 1) - L(py, px - 1));
+      const float dy = 0.5f * (L(py + 1, px) - L(py - 1, px));
+      const float dxx = 0.25f * (L(py, px + 2) - 2.f * L(py, px) + L(py, px - 2));
+      const float dxy = 0.25f * (L(py + 1, px + 1) - L(py - 1, px + 1) - L(py + 1, px - 1) + L(py - 1, px - 1));
+      const float dyy = 0.25f * (L(py + 2, px) - 2.f * L(py, px) + L(py - 2, px));
+      const float det = dxx * dyy - dxy * dxy;
+      if (det != 0.f) {
+        // offset = -H^-1 g
+        x += -(dyy * dx - dxy * dy) / det;
+        y += -(-dxy * dx + dxx * dy) / det;
+      }
+    }
+    maxvals[nk] = r.v;
+    hm_preds[nk * 2 + 0] = x;
+    hm_preds[nk * 2 + 1] = y;
+    const int n = nk / K;
+    float ox, oy;
+    xform_xy(x, y, center + n * 2, scale + n * 2, W, H, 0, ox, oy);
+    preds[nk * 2 + 0] = ox;
+    preds[nk * 2 + 1] = oy;
+  }
+}
+
+extern "C" int lhn_heatmap_decode_dark(const float* hm, const float* center, const float* scale, float* hm_preds, float* preds,
+                                       float* maxvals, int N, int K, int H, int W, int kernel, void* stream) {
+  LHN_CHECK_ARG(hm && center && scale && hm_preds && preds && maxvals, "lhn_heatmap_decode_dark: null pointer");
+  LHN_CHECK_ARG(kernel % 2 == 1 && kernel >= 3 && kernel <= 31, "lhn_heatmap_decode_dark: kernel %d (odd, 3..31)", kernel);
+  LHN_CHECK_ARG((H * W) % 4 == 0 && H * W <= 16384, "lhn_heatmap_decode_dark: H*W must be a multiple of 4 and <= 16384");
+  const size_t lds = (size_t)2 * H * W * sizeof(float);
+  static bool done = false;
+  if (!done) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dark), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 16384 * 4);
+    done = true;
+  }
+  hipLaunchKernelGGL(k_dark, dim3(N * K), dim3(256), lds, (hipStream_t)stream, hm, center, scale, hm_preds, preds, maxvals, K, H,
+                     W, kernel);
+  LHN_CHECK_LAUNCH("lhn_heatmap_decode_dark");
+  return 0;
+}

