@@ -140,9 +140,21 @@ int lhn_table_fill(float* table, int cstride, int coff, int C, float scale, floa
                    void* stream);
 
 /* elementwise / pooling (liteHandNet.py:88-113, litehourglass.py:136-163, common.py:40-66) */
+/* pending transform of a deployed (biased, BN-free) convolution: table slice = (1, bias[c] or 0, slope)
+ * -- RepConv.forward with rep_conv, repblocks.py:41-43 */
+int lhn_table_bias(float* table, int cstride, int coff, int C, const float* bias /*or NULL*/, float slope,
+                   void* stream);
+/* deploy-time re-parameterisation (repblocks.py:46-73,169-236; common.py:68-90): one branch of the fused kernel.
+ * out_w[Cout][cin_g][k][k] (store | +=) branch * gamma/sqrt(rvar+eps), branch = w (kb x kb centred in k x k) or the
+ * identity kernel when w == NULL; out_b[Cout] (store | +=) beta - rmean*gamma/sqrt(rvar+eps).  Equals the IEEE float32
+ * evaluation of the reference's formula bit for bit when the branches are added in the order 1x1, identity, k x k. */
+int lhn_fold_bn(const float* w, int kb, const float* gamma, const float* beta, const float* rmean,
+                const float* rvar, float eps, float* out_w, float* out_b, int Cout, int cin_g, int k,
+                int accumulate, void* stream);
 int lhn_ew_fwd(const lhn_view* srcs, int nsrc, const lhn_view* dst, float out_slope, void* stream);
 int lhn_maxpool2_fwd(const lhn_view* x, const lhn_view* y, void* stream);
 int lhn_avgpool_fwd(const lhn_view* x, float* out /*[N,OH,OW,x.C]*/, int OH, int OW, void* stream);
+/* gamma == NULL: deployed attention, `beta` is the bias of the fused depthwise conv, no BatchNorm (eval only) */
 int lhn_ca_mlp_fwd(const float* pooled /*[N,9,C]*/, const float* w3 /*[C,1,3,3]*/, const float* gamma,
                    const float* beta, float* rmean, float* rvar, int64_t* nbt, const float* w1 /*[C/2,C]*/,
                    const float* b1, const float* w2 /*[C,C/2]*/, const float* b2, const float* dropmask,

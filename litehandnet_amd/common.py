@@ -9,13 +9,25 @@ class ChannelAttension(PlanModule):
 
     def __init__(self, channel, deploy=False, p_drop=0.3):
         super().__init__()
-        assert not deploy
-        self.conv3x3 = nn.Sequential()
-        self.conv3x3.add_module("conv", nn.Conv2d(channel, channel, 3, 1, 0, groups=channel, bias=False))
-        self.conv3x3.add_module("bn", nn.BatchNorm2d(channel))
+        self.deploy = deploy
+        if deploy:
+            self.rbr_reparam = nn.Conv2d(channel, channel, 3, 1, 0, groups=channel)
+        else:
+            self.conv3x3 = nn.Sequential()
+            self.conv3x3.add_module("conv", nn.Conv2d(channel, channel, 3, 1, 0, groups=channel, bias=False))
+            self.conv3x3.add_module("bn", nn.BatchNorm2d(channel))
         self.conv1x1 = nn.Sequential(nn.Dropout2d(p=p_drop), nn.Conv2d(channel, channel // 2, 1, 1, 0),
                                      nn.LeakyReLU(inplace=True), nn.Conv2d(channel // 2, channel, 1, 1, 0),
                                      nn.Sigmoid())
+
+    def switch_to_deploy(self):
+        """common.py:68-90: fold the BatchNorm of the 3x3 depthwise conv into a biased conv."""
+        if hasattr(self, "rbr_reparam"):
+            return
+        from .repblocks import fused_conv
+        self.rbr_reparam = fused_conv(self.conv3x3.conv, [(self.conv3x3.conv.weight, self.conv3x3.bn)])
+        del self.conv3x3
+        self.deploy = True
 
     def emit(self, pb, x, out=None):
         # the gate attaches to the buffer behind x; a view that does not own its buffer is materialised first

@@ -769,7 +769,7 @@ static void launch_dwk_fwd(const lhn_view* x, const float* w, const lhn_view* y,
   const int per_cu = lds > 80 * 1024 ? 1 : (lds > 52 * 1024 ? 2 : 3);
   static bool done = false;
   if (!done) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwk_fwd_lds<K, DIL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwk_fwd_lds<K, DIL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     done = true;
   }
   hipLaunchKernelGGL((k_dwk_fwd_lds<K, DIL>), dim3(dw3_grid(ntile, cg, per_cu * 2)), dim3(256), lds, s, *x, w, *y, stats, th, tw, cg, fin);
@@ -783,7 +783,7 @@ static void launch_dwk_bwd(const lhn_view* x, const float* w, const lhn_view* y,
   const size_t lds = (size_t)((TH + 2 * P) * (TW + 2 * P) * 16 + 256 + 2 * K * K * 8) * 16;
   static bool done = false;
   if (!done) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwk_bwd_lds<K, DIL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwk_bwd_lds<K, DIL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     done = true;
   }
   hipLaunchKernelGGL((k_dwk_bwd_lds<K, DIL>), dim3(dw3_grid(ntile, cg, 4)), dim3(256), lds, s, *x, w, *y, *gy, dx, dx_acc, dw, th, tw,

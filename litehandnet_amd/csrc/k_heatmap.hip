@@ -535,7 +535,7 @@ extern "C" int lhn_heatmap_decode_dark(const float* hm, const float* center, con
   const size_t lds = (size_t)2 * H * W * sizeof(float);
   static bool done = false;
   if (!done) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dark), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 16384 * 4);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dark), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 16384 * 4);
     done = true;
   }
   hipLaunchKernelGGL(k_dark, dim3(N * K), dim3(256), lds, (hipStream_t)stream, hm, center, scale, hm_preds, preds, maxvals, K, H,

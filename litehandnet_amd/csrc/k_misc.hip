@@ -59,6 +59,15 @@ __global__ void k_table_fill(float* __restrict__ table, int cs, int coff, int C,
   }
 }
 
+// pending transform of a biased, BN-free (deployed) convolution: v = lrelu_slope(raw + bias)
+__global__ void k_table_bias(float* __restrict__ table, int cs, int coff, int C, const float* __restrict__ bias, float sl) {
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    table[coff + c] = 1.f;
+    table[cs + coff + c] = bias ? bias[c] : 0.f;
+    table[2 * cs + coff + c] = sl;
+  }
+}
+
 // ------------------------------------------------------------------ elementwise combine
 // dst = lrelu_{out_slope}( sum_i value_i(nearest-resampled to dst geometry) ), dst stored plain.
 struct EwSrcs {
@@ -309,6 +318,12 @@ __global__ void __launch_bounds__(256) k_ca1(const float* __restrict__ pooled, c
       q += rq[j][cl];
     }
     double mean, var;
+    if (!gamma) {          // deployed attention (common.py:68-90): the BatchNorm is folded, `beta` is the conv bias
+      smean[c] = 0.f;
+      sinv[c] = 1.f;
+      s_sc[cl] = 1.f;
+      s_sh[cl] = beta ? beta[c] : 0.f;
+    } else {
     if (training) {
       mean = s / N;
       var = q / N - mean * mean;
@@ -324,6 +339,7 @@ __global__ void __launch_bounds__(256) k_ca1(const float* __restrict__ pooled, c
     sinv[c] = invstd;
     s_sc[cl] = gamma[c] * invstd;
     s_sh[cl] = beta[c] - (float)mean * (gamma[c] * invstd);
+    }
   }
   __syncthreads();
   if (ok) {
@@ -608,6 +624,13 @@ int lhn_table_fill(float* table, int cstride, int coff, int C, float scale, floa
   return 0;
 }
 
+int lhn_table_bias(float* table, int cstride, int coff, int C, const float* bias, float slope, void* stream) {
+  LHN_CHECK_ARG(table && C > 0 && coff >= 0 && coff + C <= cstride, "lhn_table_bias: bad slice");
+  hipLaunchKernelGGL(k_table_bias, dim3(1), dim3(128), 0, (hipStream_t)stream, table, cstride, coff, C, bias, slope);
+  LHN_CHECK_LAUNCH("lhn_table_bias");
+  return 0;
+}
+
 int lhn_ew_fwd(const lhn_view* srcs, int nsrc, const lhn_view* dst, float out_slope, void* stream) {
   LHN_CHECK_ARG(srcs && nsrc >= 1 && nsrc <= 3 && lhn_view_ok(dst), "lhn_ew_fwd: 1..3 sources, valid dst");
   EwSrcs S;
@@ -685,7 +708,8 @@ int lhn_ca_mlp_fwd(const float* pooled, const float* w3, const float* gamma, con
                    int64_t* nbt, const float* w1, const float* b1, const float* w2, const float* b2, const float* dropmask,
                    float* gate, int gate_stride, int gate_coff, float* save, int N, int C, float eps, float momentum,
                    int training, void* stream) {
-  LHN_CHECK_ARG(pooled && w3 && gamma && beta && rmean && rvar && w1 && b1 && w2 && b2 && gate && save, "lhn_ca_mlp_fwd: null pointer");
+  LHN_CHECK_ARG(pooled && w3 && w1 && b1 && w2 && b2 && gate && save, "lhn_ca_mlp_fwd: null pointer");
+  LHN_CHECK_ARG(gamma ? (beta && rmean && rvar) : !training, "lhn_ca_mlp_fwd: BatchNorm tensors missing (gamma NULL = deployed form, eval only)");
   LHN_CHECK_ARG(C > 0 && C <= 256 && C % 2 == 0 && N > 0, "lhn_ca_mlp_fwd: C=%d (<=256)", C);
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(k_ca1, dim3((C + 31) / 32), dim3(256), 0, s, pooled, w3, gamma, beta, rmean, rvar, nbt, dropmask, save, N, C, eps, momentum, training);

@@ -127,7 +127,10 @@ int lhn_plan_run(void* plan, int phase, void* ws, void* const* params, void* con
       }
       case OP_TABLE_FILL: {
         const lhn_buf& b = P->bufs[o.out_buf];
-        rc = lhn_table_fill(reinterpret_cast<float*>(at(ws, b.table_off)), b.C, o.out_coff, o.out_C, o.f[0], o.f[1], o.f[2], stream);
+        if (o.i[0])  // deployed conv: (1, bias, slope)
+          rc = lhn_table_bias(reinterpret_cast<float*>(at(ws, b.table_off)), b.C, o.out_coff, o.out_C, prm<const float>(params, o.p[0]), o.f[2], stream);
+        else
+          rc = lhn_table_fill(reinterpret_cast<float*>(at(ws, b.table_off)), b.C, o.out_coff, o.out_C, o.f[0], o.f[1], o.f[2], stream);
         break;
       }
       case OP_STEM: {
@@ -136,7 +139,7 @@ int lhn_plan_run(void* plan, int phase, void* ws, void* const* params, void* con
         lhn_bnfin fin;
         if (bn) fin = mkfin(P, ws, o, params);
         rc = lhn_conv_stem_fwd(static_cast<const float*>(io[0]), prm<const float>(params, o.p[0]), &y,
-                               training ? reinterpret_cast<double*>(at(ws, o.ws[0])) : nullptr, o.i[3], o.i[4], o.i[0], o.i[1],
+                               (training && o.ws[0] >= 0) ? reinterpret_cast<double*>(at(ws, o.ws[0])) : nullptr, o.i[3], o.i[4], o.i[0], o.i[1],
                                o.i[2], (bn && training && fuse_finalize()) ? &fin : nullptr, stream);
         if (!rc && bn && !(training && fuse_finalize())) rc = sep_finalize(fin, reinterpret_cast<const double*>(at(ws, o.ws[0])), training, stream);
         break;
@@ -169,7 +172,7 @@ int lhn_plan_run(void* plan, int phase, void* ws, void* const* params, void* con
         lhn_bnfin fin;
         if (bn) fin = mkfin(P, ws, o, params);
         rc = lhn_conv_dw_fwd(&x, prm<const float>(params, o.p[0]), &y,
-                             training ? reinterpret_cast<double*>(at(ws, o.ws[0])) : nullptr, o.i[0], o.i[1], o.i[2], o.i[3],
+                             (training && o.ws[0] >= 0) ? reinterpret_cast<double*>(at(ws, o.ws[0])) : nullptr, o.i[0], o.i[1], o.i[2], o.i[3],
                              (bn && training && fuse_finalize()) ? &fin : nullptr, stream);
         if (!rc && bn && !(training && fuse_finalize())) rc = sep_finalize(fin, reinterpret_cast<const double*>(at(ws, o.ws[0])), training, stream);
         break;
@@ -181,7 +184,7 @@ int lhn_plan_run(void* plan, int phase, void* ws, void* const* params, void* con
         lhn_bnfin fin;
         if (bn) fin = mkfin(P, ws, o, params);
         rc = lhn_conv_kxk_fwd(&x, prm<const float>(params, o.p[0]), &y,
-                              training ? reinterpret_cast<double*>(at(ws, o.ws[0])) : nullptr, o.i[0],
+                              (training && o.ws[0] >= 0) ? reinterpret_cast<double*>(at(ws, o.ws[0])) : nullptr, o.i[0],
                               (bn && training && fuse_finalize()) ? &fin : nullptr, stream);
         if (!rc && bn && !(training && fuse_finalize())) rc = sep_finalize(fin, reinterpret_cast<const double*>(at(ws, o.ws[0])), training, stream);
         break;

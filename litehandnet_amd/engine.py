@@ -140,6 +140,8 @@ class Engine:
         if x.dim() != 4 or x.dtype != torch.float32:
             raise _lib.LhnError(f"expected a float32 NCHW tensor, got {tuple(x.shape)} {x.dtype}")
         p_drop = self.p_drop if self.p_drop is not None else getattr(self.module, "p_drop", 0.0)
+        if any(getattr(m, "deploy", False) for m in self.module.modules()):
+            with_backward = False           # re-parameterised (deploy) form is inference-only
         key = (tuple(x.shape), bool(with_backward), float(p_drop), x.device.index)
         plan = self.plans.get(key)
         tensors = self._state(x.device)

@@ -152,6 +152,14 @@ class PlanBuilder:
                 rec["bcnt"] = self._ws("zb", 4)
                 self.bufs[out.buf].coef = True
         self.recs.append(rec)
+        if bn is None and not nchw_out:
+            # BN-free conv (deployed RepConv/RepBlock, repblocks.py:41-43,118-119): bias and activation stay pending
+            # in the output's table.  The 1x1 kernel already adds its bias while storing.
+            tb = conv.bias if kind != PW else None
+            if tb is not None or float(slope) != 1.0:
+                if self.with_backward:
+                    raise _lib.LhnError("BN-free convolutions with a pending bias/activation are inference-only (deploy form)")
+                self.recs.append(dict(op=TABLE_FILL, out=out, bias=tb, slope=float(slope)))
         return out
 
     def bn_only(self, x, bn, slope=1.0):
@@ -332,6 +340,19 @@ class PlanBuilder:
                 fwd.append(mk(MAXPOOL, ins=(r["x"],), out=r["out"]))
             elif k == AVGPOOL:
                 fwd.append(mk(AVGPOOL, ins=(r["x"],), ws=(self.bufs[r["out"].buf].off["data"],), i=(r["OH"], r["OW"], 0)))
+            elif k == TABLE_FILL:
+                fwd.append(mk(TABLE_FILL, out=r["out"], p=(self._p(r["bias"]),), i=(1,), f=(1.0, 0.0, r["slope"])))
+            elif k == CA_MLP and hasattr(r["ca"], "rbr_reparam"):
+                y, ca = r["y"], r["ca"]
+                if self.with_backward:
+                    raise _lib.LhnError("deployed ChannelAttension is inference-only")
+                fwd.append(mk(AVGPOOL, ins=(y,), ws=(self._abs(r["pooled"]),), i=(3, 3, 1)))
+                fwd.append(mk(CA_MLP, out=y,
+                              p=(self._p(ca.rbr_reparam.weight), -1, self._p(ca.rbr_reparam.bias), -1, -1, -1,
+                                 self._p(ca.conv1x1[1].weight), self._p(ca.conv1x1[1].bias),
+                                 self._p(ca.conv1x1[3].weight), self._p(ca.conv1x1[3].bias)),
+                              ws=(self._abs(r["pooled"]), self._abs(r["save"]), self._abs(r["mask"])),
+                              f=(1e-5, 0.1)))
             elif k == CA_MLP:
                 y, ca = r["y"], r["ca"]
                 fwd.append(mk(AVGPOOL, ins=(y,), ws=(self._abs(r["pooled"]),), i=(3, 3, 1)))

@@ -16,6 +16,7 @@ Reference behaviour followed (paths relative to the reference tree):
   * channel attention              models/pose_estimation/liteHandNet/common.py:40-66
   * variant A (registered name)    models/pose_estimation/liteHandNet/liteHandNet.py:8-238
   * variant B (MSRB hourglass)     models/pose_estimation/liteHandNet/litehourglass.py:13-237
+  * deploy-time re-parameterisation repblocks.py:46-73,169-236, common.py:68-90, liteHandNet.py:240-244
   * init                           models/weight_init.py:21-32
   * loss                           loss/loss.py:69-114, loss/heatmapLoss.py:228-265
 """
@@ -56,8 +57,51 @@ def _conv_bn(cin, cout, k, stride, pad, dil=1, groups=1):
     return seq
 
 
+def _fold_bn(kernel, bn):
+    """BN(conv_k(x)) in eval mode == conv_{k*t}(x) + (beta - mean*gamma/std), t = gamma/std per output channel
+    (repblocks.py:49-58, 197-221).  Same operation order as the reference (sqrt, divide, multiply)."""
+    std = (bn.running_var + bn.eps).sqrt()
+    t = (bn.weight / std).reshape(-1, 1, 1, 1)
+    return kernel * t, bn.bias - bn.running_mean * bn.weight / std
+
+
+def fold_bn_np(kernel, gamma, beta, mean, var, eps):
+    """_fold_bn in numpy float32: every operation correctly rounded (IEEE-754).  torch's CPU `sqrt` (MKL VML) is off by
+    one ulp on a few inputs, so the HIP kernel -- whose sqrt/divide are correctly rounded -- is pinned bit-for-bit against
+    THIS function and within 2 ulp against the reference-generated fixture."""
+    import numpy as np
+    f = np.float32
+    std = np.sqrt(var.astype(f) + f(eps))
+    t = gamma.astype(f) / std
+    return kernel.astype(f) * t.reshape(-1, 1, 1, 1), beta.astype(f) - mean.astype(f) * gamma.astype(f) / std
+
+
+def _swap_in(mod, name, like, kernel, bias, drop):
+    """Install `name` = biased conv shaped like `like` holding (kernel, bias); remove the train-time branches."""
+    conv = nn.Conv2d(like.in_channels, kernel.shape[0], like.kernel_size, like.stride, like.padding, like.dilation,
+                     like.groups, bias=True)
+    conv.weight.data = kernel.detach()
+    conv.bias.data = bias.detach()
+    setattr(mod, name, conv)
+    for p in mod.parameters():
+        p.detach_()
+    for d in drop:
+        if hasattr(mod, d):
+            delattr(mod, d)
+    mod.deploy = True
+
+
+def deploy_model(model):
+    """liteHandNet.py:240-244 / litehourglass.py:233-237: every module that can re-parameterise does."""
+    for m in model.modules():
+        if hasattr(m, "switch_to_deploy"):
+            m.switch_to_deploy()
+    model.deploy = True
+    return model
+
+
 class RepConv(nn.Module):
-    """act(BN(conv(x))); keys `conv.conv.weight`, `conv.bn.*`."""
+    """act(BN(conv(x))); keys `conv.conv.weight`, `conv.bn.*`; after deploy `rep_conv.{weight,bias}`."""
 
     def __init__(self, cin, cout, kernel=1, stride=1, padding=0, dilation=1, groups=1,
                  activation=nn.LeakyReLU, inplace=False):
@@ -66,7 +110,15 @@ class RepConv(nn.Module):
         self.nonlinearity = _repconv_act(activation, inplace)
 
     def forward(self, x):
+        if hasattr(self, "rep_conv"):
+            return self.nonlinearity(self.rep_conv(x))
         return self.nonlinearity(self.conv(x))
+
+    def switch_to_deploy(self):  # repblocks.py:46-73
+        if hasattr(self, "rep_conv"):
+            return
+        k, b = _fold_bn(self.conv.conv.weight, self.conv.bn)
+        _swap_in(self, "rep_conv", self.conv.conv, k, b, ("conv",))
 
 
 class RepBlock(nn.Module):
@@ -80,10 +132,30 @@ class RepBlock(nn.Module):
         self.nonlinearity = _act(activation)
 
     def forward(self, x):
+        if hasattr(self, "rbr_reparam"):
+            return self.nonlinearity(self.rbr_reparam(x))
         y = self.rbr_dense(x) + self.rbr_1x1(x)
         if self.rbr_identity is not None:
             y = y + self.rbr_identity(x)
         return self.nonlinearity(y)
+
+    def switch_to_deploy(self):  # repblocks.py:169-236: k x k  +  centre-padded 1x1  +  identity-as-conv
+        if hasattr(self, "rbr_reparam"):
+            return
+        dense = self.rbr_dense.conv
+        kk, bk = _fold_bn(dense.weight, self.rbr_dense.bn)
+        k1, b1 = _fold_bn(self.rbr_1x1.conv.weight, self.rbr_1x1.bn)
+        pad = dense.kernel_size[0] // 2
+        rest_k, rest_b = F.pad(k1, [pad] * 4), b1
+        if self.rbr_identity is not None:
+            cin, cin_g = dense.in_channels, dense.in_channels // dense.groups
+            eye = torch.zeros(cin, cin_g, *dense.kernel_size)
+            eye[torch.arange(cin), torch.arange(cin) % cin_g, pad, pad] = 1
+            ki, bi = _fold_bn(eye.to(dense.weight.device), self.rbr_identity)
+            rest_k, rest_b = rest_k + ki, rest_b + bi
+        else:                                   # the reference adds the integer 0 for a missing branch
+            rest_k, rest_b = rest_k + 0, rest_b + 0
+        _swap_in(self, "rbr_reparam", dense, kk + rest_k, bk + rest_b, ("rbr_dense", "rbr_1x1", "rbr_identity"))
 
 
 class ChannelAttension(nn.Module):
@@ -103,7 +175,14 @@ class ChannelAttension(nn.Module):
 
     def forward(self, x):
         pooled = F.adaptive_avg_pool2d(x, (3, 3))
-        return x * self.conv1x1(self.conv3x3(pooled))
+        att = self.rbr_reparam(pooled) if hasattr(self, "rbr_reparam") else self.conv3x3(pooled)
+        return x * self.conv1x1(att)
+
+    def switch_to_deploy(self):  # common.py:68-90
+        if hasattr(self, "rbr_reparam"):
+            return
+        k, b = _fold_bn(self.conv3x3.conv.weight, self.conv3x3.bn)
+        _swap_in(self, "rbr_reparam", self.conv3x3.conv, k, b, ("conv3x3",))
 
 
 def _make_ca(kind, c, p_drop):

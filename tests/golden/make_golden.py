@@ -148,6 +148,21 @@ def main():
         assert np.abs(yr - yo).max() <= 1e-5 * np.abs(yr).max()
         np.savez_compressed(os.path.join(HERE, f"model_{tag}_64_eval.npz"), seed=11, heatmap=yr,
                             weights_seed={"B": 5, "A": 6}[tag])
+        # deploy-time re-parameterisation (test.py:106-107 -> deploy_model): fused tensors must match bit for bit
+        rm.deploy_model(); torch_ref.deploy_model(om)
+        sr, so = rm.state_dict(), om.state_dict()
+        assert list(sr) == list(so), "deploy state_dict keys differ"
+        for k in sr:
+            assert sr[k].shape == so[k].shape and torch.equal(sr[k], so[k]), k
+        with torch.no_grad():
+            yd, yod = rm(x).numpy(), om(x).numpy()
+        assert np.array_equal(yd, yod)
+        fused = [k for k in sr if "rep_conv" in k or "rbr_reparam" in k]
+        pick = fused[:: max(1, len(fused) // 12)]
+        np.savez_compressed(os.path.join(HERE, f"model_{tag}_64_deploy.npz"), seed=11, heatmap=yd,
+                            weights_seed={"B": 5, "A": 6}[tag], n_params=sum(p.numel() for p in rm.parameters()),
+                            n_keys=len(sr), keys=np.array(list(sr)), abs_sums=np.array([float(v.double().abs().sum()) for v in sr.values()]),
+                            **{"t_" + k: sr[k].numpy() for k in pick})
 
     # ---- loss alone (reference loss/heatmapLoss.py:242-265 through loss/loss.py:93-114)
     r = np.random.Generator(np.random.PCG64(21))

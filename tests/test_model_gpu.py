@@ -273,3 +273,88 @@ def test_state_dict_contract(dev):
     assert list(ours.state_dict()) == list(ref.state_dict())
     for (k, a), (_, b) in zip(ours.state_dict().items(), ref.state_dict().items()):
         assert a.shape == b.shape, k
+
+
+# ---------------------------------------------------------------- deploy-time re-parameterisation (section 8f rank 2)
+@pytest.mark.parametrize("variant", ["A", "B"])
+def test_deploy_model_golden(dev, golden_dir, variant):
+    """deploy_model(): the fused tensors match the reference's (fixture written by make_golden.py from the real reference
+    on the CPU) to 2 ulp -- torch's CPU sqrt is not correctly rounded, see oracle.torch_ref.fold_bn_np, against which the
+    kernel is bit-exact below --, the parameter count is the notebook's known answer, and the deployed forward matches."""
+    from litehandnet_amd import get_model
+    g = np.load(os.path.join(golden_dir, f"model_{variant}_64_deploy.npz"))
+    m = get_model(litehandnet_cfg(variant))
+    m.load_state_dict(synth.synth_state_dict(m, int(g["weights_seed"])))
+    m.to(dev).eval()
+    x = synth.synth_images(2, 64, int(g["seed"])).to(dev)
+    with torch.no_grad():
+        y_eval = m(x)
+    m.deploy_model()
+    sd = m.state_dict()
+    assert list(sd) == [str(k) for k in g["keys"]]
+    assert sum(p.numel() for p in m.parameters()) == int(g["n_params"])
+    if variant == "A":
+        assert int(g["n_params"]) == 2265621                         # test_models_performance.ipynb:252-254
+    for k in g.files:
+        if k.startswith("t_"):
+            a = sd[k[2:]].cpu().numpy()
+            assert np.all(np.abs(a - g[k]) <= 2.4e-7 * np.abs(g[k]) + 3e-7 * np.abs(g[k]).max()), k   # ~2 ulp (stated above)
+    sums = np.array([float(v.double().abs().sum()) for v in sd.values()])
+    assert np.allclose(sums, g["abs_sums"], rtol=2e-7, atol=0)       # every tensor, via its |.| checksum
+    with torch.no_grad():
+        y = m(x)                                                     # grad mode on or off: deploy form is inference-only
+    ref = g["heatmap"]
+    assert np.abs(y.cpu().numpy() - ref).max() <= FWD_TOL * np.abs(ref).max()
+    assert _rel(y, y_eval) < 1e-4                                    # same function as the eval-mode train form
+    m.deploy_model()                                                 # idempotent
+    assert list(m.state_dict()) == [str(k) for k in g["keys"]]
+
+
+def test_deploy_units_vs_oracle(dev):
+    """RepConv / RepBlock (dense, depthwise 7x7, stride 2 without identity) / ChannelAttension one by one."""
+    from litehandnet_amd.common import ChannelAttension
+    from litehandnet_amd.repblocks import RepBlock, RepConv
+    cases = [
+        (RepConv(32, 64, 1), torch_ref.RepConv(32, 64, 1), 32),
+        (RepConv(32, 32, 3, 1, 2, 2, groups=32, activation=None), torch_ref.RepConv(32, 32, 3, 1, 2, 2, groups=32, activation=None), 32),
+        (RepBlock(32, 32, 3, 1, 1), torch_ref.RepBlock(32, 32, 3, 1, 1), 32),
+        (RepBlock(32, 32, 7, 1, 3, groups=32), torch_ref.RepBlock(32, 32, 7, 1, 3, groups=32), 32),
+        (RepBlock(32, 64, 3, 2, 1), torch_ref.RepBlock(32, 64, 3, 2, 1), 32),
+        (ChannelAttension(64, p_drop=0.0), torch_ref.ChannelAttension(64, 0.0), 64),
+    ]
+    for j, (ours, ref, cin) in enumerate(cases):
+        sd = synth.synth_state_dict(ref, 40 + j)
+        ref.load_state_dict(sd); ours.load_state_dict(sd)
+        ours.to(dev).eval(); ref.eval()
+        ours.switch_to_deploy(); ref.switch_to_deploy()
+        so, sr = ours.state_dict(), ref.state_dict()
+        assert list(so) == list(sr)
+        for k in sr:
+            assert torch.allclose(so[k].cpu(), sr[k], rtol=2.4e-7, atol=3e-7 * float(sr[k].abs().max())), (j, k)   # sums of 3 branches cancel
+        # bit-exact against the IEEE float32 (numpy) evaluation of the reference's formula, branches in its order
+        n = lambda t: sd[t].numpy()
+        bnp = lambda pre: (n(pre + ".weight"), n(pre + ".bias"), n(pre + ".running_mean"), n(pre + ".running_var"), 1e-5)
+        if "rep_conv.weight" in so:
+            kw, kb = torch_ref.fold_bn_np(n("conv.conv.weight"), *bnp("conv.bn"))
+            name = "rep_conv"
+        elif "conv3x3.conv.weight" in sd:
+            kw, kb = torch_ref.fold_bn_np(n("conv3x3.conv.weight"), *bnp("conv3x3.bn"))
+            name = "rbr_reparam"
+        else:
+            k3, b3 = torch_ref.fold_bn_np(n("rbr_dense.conv.weight"), *bnp("rbr_dense.bn"))
+            k1, b1 = torch_ref.fold_bn_np(n("rbr_1x1.conv.weight"), *bnp("rbr_1x1.bn"))
+            pad = k3.shape[-1] // 2
+            rest, restb = np.pad(k1, [(0, 0), (0, 0), (pad, pad), (pad, pad)]), b1
+            if "rbr_identity.weight" in sd:
+                eye = np.zeros_like(k3)
+                eye[np.arange(k3.shape[0]), np.arange(k3.shape[0]) % k3.shape[1], pad, pad] = 1
+                ki, bi = torch_ref.fold_bn_np(eye, *bnp("rbr_identity"))
+                rest, restb = rest + ki, restb + bi
+            kw, kb, name = k3 + rest, b3 + restb, "rbr_reparam"
+        assert np.array_equal(so[name + ".weight"].cpu().numpy(), kw), (j, "weight vs IEEE fold")
+        assert np.array_equal(so[name + ".bias"].cpu().numpy(), kb), (j, "bias vs IEEE fold")
+        x = synth.synth_images(2, 16, 50 + j)[:, :1].repeat(1, cin, 1, 1) * torch.linspace(0.5, 1.5, cin).view(1, -1, 1, 1)
+        with torch.no_grad():
+            yr = ref.double()(x.double())
+            yo = ours(x.to(dev))
+        assert _rel(yo, yr) < FWD_TOL, (j, _rel(yo, yr))
