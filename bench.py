@@ -139,6 +139,12 @@ def main():
         return
     value = world * B * args.steps / el
     alg = ALG_FWD_BYTES[args.variant] * B
+    traffic = None          # measured HBM bytes per forward launch (rocprofv3 PMC passes, committed under profiles/)
+    try:
+        pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")))
+        traffic = pmc.get(f"{args.variant}_bs{B}_256", {}).get("traffic_bytes_per_fwd")
+    except (OSError, ValueError):
+        pass
     ach = alg / (fwd_ms * 1e-3) / 1e9
     step_ms = el / args.steps * 1e3
     train_alg = (3 * ALG_FWD_BYTES[args.variant] + LOSS_BYTES) * B
@@ -150,7 +156,7 @@ def main():
                                f"C=128, 256x256x3 -> 21x64x64, per-GPU batch {B}, train-mode BN, fwd + TopdownHeatmapLoss + bwd + fused Adam",
                    "global_batch": world * B, "parallelism": f"dp{world}", "ca_dropout": args.dropout},
         "roofline": {"bound": "hbm", "kernel": "forward plan (one lhn_plan_run launch sequence)", "achieved": round(ach, 1),
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "algorithmic_bytes": alg, "launch_ms": round(fwd_ms, 4)},
         "roofline_train_step": {"bound": "hbm", "achieved": round(train_alg / (step_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
                                 "unit": "GB/s", "frac": round(train_alg / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},

@@ -75,6 +75,27 @@ def test_eval_mode(golden_dir):
         assert np.abs(y - g["heatmap"]).max() <= 1e-5 * np.abs(g["heatmap"]).max()
 
 
+def test_deploy_reparam(golden_dir):
+    """Oracle deploy_model() vs the fixture the real reference produced (keys, parameter count, fused tensors, output).
+    2-ulp tolerance on the tensors: torch's CPU sqrt differs between hosts (MKL VML)."""
+    for variant in ("B", "A"):
+        g = np.load(os.path.join(golden_dir, f"model_{variant}_64_deploy.npz"))
+        m = torch_ref.get_model(litehandnet_cfg(variant))
+        m.load_state_dict(synth.synth_state_dict(m, int(g["weights_seed"])))
+        m.eval()
+        torch_ref.deploy_model(m)
+        sd = m.state_dict()
+        assert list(sd) == [str(k) for k in g["keys"]]
+        assert sum(p.numel() for p in m.parameters()) == int(g["n_params"])
+        for k in g.files:
+            if k.startswith("t_"):
+                assert np.all(np.abs(sd[k[2:]].numpy() - g[k]) <= 2.4e-7 * np.abs(g[k]) + 3e-7 * np.abs(g[k]).max()), k
+        with torch.no_grad():
+            y = m(synth.synth_images(2, 64, int(g["seed"]))).numpy()
+        assert np.abs(y - g["heatmap"]).max() <= 1e-5 * np.abs(g["heatmap"]).max()
+    assert int(np.load(os.path.join(golden_dir, "model_A_64_deploy.npz"))["n_params"]) == 2265621   # notebook known answer
+
+
 def test_encode(golden_dir):
     g = np.load(os.path.join(golden_dir, "encode.npz"))
     for unb, tag in ((True, "unbiased"), (False, "biased")):
