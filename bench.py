@@ -21,7 +21,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # algorithmic HBM bytes per image, fp32: 4 B x sum over convs of (in + out) elements
-ALG_FWD_BYTES = {"B": 76.42e6, "A": 98.07e6}
+ALG_FWD_BYTES = {"B": 76.42e6, "A": 98.07e6, "M": 82.59e6}   # M = `mynet` (pose_hg_ms_att.py), scripts/dump_plan.py M
 LOSS_BYTES = (8 + 4) * 21 * 64 * 64          # loss fwd reads o,t; bwd writes g (per image)
 HBM_PEAK_GBS = 8000.0                        # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable copy rate)
 
@@ -72,7 +72,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--variant", default="B", choices=["A", "B"])
+    ap.add_argument("--variant", default="B", choices=["A", "B", "M"])
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dropout", type=float, default=0.3, help="Dropout2d p inside channel attention (reference: 0.3)")
@@ -152,7 +152,7 @@ def main():
         "metric": "images/sec fwd+bwd @256x256 bs64 litehandnet", "value": round(value, 1), "unit": "images/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(step_ms, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"litehandnet variant {args.variant} ({'MSRB hourglass litehourglass.py' if args.variant == 'B' else 'registered liteHandNet.py, reduction 4'}) "
+        "config": {"workload": f"litehandnet variant {args.variant} ({ {'B': 'MSRB hourglass litehourglass.py', 'A': 'registered liteHandNet.py, reduction 4', 'M': 'mynet pose_hg_ms_att.py'}[args.variant] }) "
                                f"C=128, 256x256x3 -> 21x64x64, per-GPU batch {B}, train-mode BN, fwd + TopdownHeatmapLoss + bwd + fused Adam",
                    "global_batch": world * B, "parallelism": f"dp{world}", "ca_dropout": args.dropout},
         "roofline": {"bound": "hbm", "kernel": "forward plan (one lhn_plan_run launch sequence)", "achieved": round(ach, 1),

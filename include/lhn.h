@@ -55,6 +55,7 @@ typedef struct lhn_bnfin {
   double       count;
   int32_t      cstride, coff, C;
   float        eps, momentum, slope;
+  const float* conv_bias;   /* bias of the convolution in front of the BatchNorm, or NULL (see lhn_bn_finalize) */
 } lhn_bnfin;
 /* same idea for lhn_bn_bwd_reduce -> lhn_bn_bwd_finalize */
 typedef struct lhn_bnbwdfin {
@@ -132,10 +133,13 @@ int lhn_conv_stem_fwd(const float* img /*[N,3,Hi,Wi]*/, const float* w /*[Cout,3
                       double* stats, int Hi, int Wi, int k, int stride, int pad, const lhn_bnfin* fin, void* stream);
 int lhn_conv_kxk_fwd(const lhn_view* x, const float* w /*[Cout,Cin,3,3]*/, const lhn_view* y, double* stats,
                      int stride, const lhn_bnfin* fin, void* stream);
+/* conv_bias: a biased convolution followed by BatchNorm (models/pose_hg_ms_att.py:27-35,46-56) stores its output
+ * WITHOUT the bias -- BatchNorm cancels it -- and the bias only enters the running mean (training) or the shift
+ * (eval: beta - (running_mean - bias) * scale).  d(bias) is identically zero in training mode. */
 int lhn_bn_finalize(const double* stats, const float* gamma, const float* beta, float* running_mean,
                     float* running_var, int64_t* num_batches_tracked, float* table, int cstride, int coff,
                     int C, float* save_mean_invstd /*[2][C]*/, double count, float eps, float momentum,
-                    float slope, int training, void* stream);
+                    float slope, int training, const float* conv_bias /*or NULL*/, void* stream);
 int lhn_table_fill(float* table, int cstride, int coff, int C, float scale, float shift, float slope,
                    void* stream);
 
@@ -151,6 +155,9 @@ int lhn_table_bias(float* table, int cstride, int coff, int C, const float* bias
 int lhn_fold_bn(const float* w, int kb, const float* gamma, const float* beta, const float* rmean,
                 const float* rvar, float eps, float* out_w, float* out_b, int Cout, int cin_g, int k,
                 int accumulate, void* stream);
+/* out_slope == LHN_SLOPE_SILU selects SiLU instead of a leaky ReLU as the combine's output activation (the
+ * BN -> SiLU -> conv pre-activation unit of models/pose_hg_ms_att.py:76-90; single same-size source in backward) */
+#define LHN_SLOPE_SILU 2.0f
 int lhn_ew_fwd(const lhn_view* srcs, int nsrc, const lhn_view* dst, float out_slope, void* stream);
 int lhn_maxpool2_fwd(const lhn_view* x, const lhn_view* y, void* stream);
 int lhn_avgpool_fwd(const lhn_view* x, float* out /*[N,OH,OW,x.C]*/, int OH, int OW, void* stream);
@@ -160,6 +167,17 @@ int lhn_ca_mlp_fwd(const float* pooled /*[N,9,C]*/, const float* w3 /*[C,1,3,3]*
                    const float* b1, const float* w2 /*[C,C/2]*/, const float* b2, const float* dropmask,
                    float* gate, int gate_stride, int gate_coff, float* save /*see DESIGN*/, int N, int C,
                    float eps, float momentum, int training, void* stream);
+
+/* attention of `mynet` (models/pose_hg_ms_att.py:165-174,191-192) on the pooled [N,9,C] tensor:
+ * gate = sigmoid(Linear(dropout(dw3x3(relu(BN(pooled))) + b3))); save = floats[3*N*C + 2*C] */
+int lhn_att_mlp_fwd(const float* pooled, const float* gamma, const float* beta, float* rmean, float* rvar,
+                    int64_t* nbt, const float* w3 /*[C,1,3,3]*/, const float* b3, const float* wl /*[C,C]*/,
+                    const float* bl, const float* dropmask /*[N,C] or NULL*/, float* gate, int gate_stride,
+                    int gate_coff, float* save, int N, int C, float eps, float momentum, int training, void* stream);
+int lhn_att_mlp_bwd(const float* pooled, const float* gamma, const float* beta, const float* w3, const float* wl,
+                    const float* dropmask, float* save, const float* dgate /*[N,C]*/, float* dpool, int cstride,
+                    int coff, int H, int W, float* dgamma, float* dbeta, float* dw3, float* db3, float* dwl,
+                    float* dbl, int N, int C, void* stream);
 
 /* backward building blocks */
 int lhn_bn_bwd_reduce(const lhn_view* y, const lhn_gradview* g, const float* save_mean_invstd,

@@ -39,6 +39,8 @@ def litehandnet_cfg(variant="A", channels=128, num_joints=21, image_size=256, **
     elif variant == "B":
         model = dict(name="litehourglass", num_stage=4, msrb_ca="ca", rbu_ca="none",
                      input_channel=channels, output_channel=num_joints)
+    elif variant == "M":            # `mynet`, config/mynet/_2_rhd2d_256x256_dark.py:4-11
+        model = dict(name="mynet", num_stage=4, num_block=[2, 2, 2], input_channel=channels, output_channel=num_joints)
     else:
         raise ValueError(variant)
     model.update(model_kw)

@@ -1,0 +1,228 @@
+// Attention of `mynet` (reference models/pose_hg_ms_att.py:165-174, 191-192):
+//   gate = sigmoid( Linear( dropout( dw3x3_valid( relu( BN( adaptive_avg_pool(y, 3x3) ) ) ) + b3 ) ) ),   y *= gate
+// The 3x3 pooling itself is lhn_avgpool_fwd; these kernels run on the pooled [N][9][C] tensor (a few hundred KB).
+// BatchNorm statistics are over the N*9 pooled values of a channel.
+// save layout (floats): ad[N*C] (dropout output = Linear input) | g[N*C] | mean[C] | invstd[C] | dad[N*C] (backward scratch)
+#include "lhn_common.h"
+
+// grid = ceil(C/32) blocks; thread = (channel lane 0..31, sample lane 0..7)
+__global__ void __launch_bounds__(256) k_att1(const float* __restrict__ pooled, const float* __restrict__ gamma,
+                                              const float* __restrict__ beta, float* __restrict__ rmean,
+                                              float* __restrict__ rvar, int64_t* __restrict__ nbt,
+                                              const float* __restrict__ w3, const float* __restrict__ b3,
+                                              const float* __restrict__ mask, float* __restrict__ save, int N, int C, float eps,
+                                              float momentum, int training) {
+  __shared__ double rs[8][32], rq[8][32];
+  __shared__ float s_mean[32], s_inv[32];
+  float* ad = save;
+  float* smean = save + (int64_t)N * C * 2;
+  float* sinv = smean + C;
+  const int cl = threadIdx.x & 31, nl = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
+  const bool ok = c < C;
+  double s = 0, q = 0;
+  if (ok && training)
+    for (int n = nl; n < N; n += 8)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const float p = pooled[((int64_t)n * 9 + t) * C + c];
+        s += p;
+        q += (double)p * p;
+      }
+  rs[nl][cl] = s;
+  rq[nl][cl] = q;
+  __syncthreads();
+  if (nl == 0 && ok) {
+    double mean, var;
+    if (training) {
+      for (int j = 1; j < 8; ++j) {
+        s += rs[j][cl];
+        q += rq[j][cl];
+      }
+      const double cnt = 9.0 * N;
+      mean = s / cnt;
+      var = q / cnt - mean * mean;
+      if (var < 0) var = 0;
+      rmean[c] = (float)((1.0 - (double)momentum) * rmean[c] + (double)momentum * mean);
+      rvar[c] = (float)((1.0 - (double)momentum) * rvar[c] + (double)momentum * (cnt > 1 ? var * cnt / (cnt - 1.0) : var));
+    } else {
+      mean = rmean[c];
+      var = rvar[c];
+    }
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    smean[c] = s_mean[cl] = (float)mean;
+    sinv[c] = s_inv[cl] = invstd;
+  }
+  __syncthreads();
+  if (ok) {
+    const float mean = s_mean[cl], sc = gamma[c] * s_inv[cl], sh = beta[c];
+    float wt[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wt[t] = w3[c * 9 + t];
+    const float bb = b3 ? b3[c] : 0.f;
+    for (int n = nl; n < N; n += 8) {
+      float a = bb;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const float u = (pooled[((int64_t)n * 9 + t) * C + c] - mean) * sc + sh;
+        a += wt[t] * fmaxf(u, 0.f);
+      }
+      if (mask) a *= mask[(int64_t)n * C + c];
+      ad[(int64_t)n * C + c] = a;
+    }
+  }
+  if (training && nbt && blockIdx.x == 0 && threadIdx.x == 0) nbt[0] += 1;
+}
+
+// one block per sample: gate[n][co] = sigmoid(bl[co] + sum_c wl[co][c] * ad[n][c])
+__global__ void __launch_bounds__(256) k_att2(const float* __restrict__ wl, const float* __restrict__ bl,
+                                              float* __restrict__ save, float* __restrict__ gate, int gs, int gcoff, int N,
+                                              int C) {
+  __shared__ float sa[256];
+  const int n = blockIdx.x;
+  const float* ad = save + (int64_t)n * C;
+  float* g = save + (int64_t)N * C + (int64_t)n * C;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) sa[c] = ad[c];
+  __syncthreads();
+  for (int co = threadIdx.x; co < C; co += blockDim.x) {
+    float v = bl[co];
+    for (int c = 0; c < C; ++c) v += wl[co * C + c] * sa[c];
+    const float sg = 1.f / (1.f + expf(-v));
+    g[co] = sg;
+    gate[(int64_t)n * gs + gcoff + co] = sg;
+  }
+}
+
+// backward of the Linear + sigmoid: dad[n][c], dwl, dbl
+__global__ void __launch_bounds__(256) k_att_bwd2(const float* __restrict__ wl, const float* __restrict__ save,
+                                                  const float* __restrict__ dgate, float* __restrict__ dad,
+                                                  float* __restrict__ dwl, float* __restrict__ dbl, int N, int C) {
+  __shared__ float sdz[256], sa[256];
+  const int n = blockIdx.x;
+  const float* ad = save + (int64_t)n * C;
+  const float* g = save + (int64_t)N * C + (int64_t)n * C;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const float gg = g[c];
+    const float dz = dgate[(int64_t)n * C + c] * gg * (1.f - gg);
+    sdz[c] = dz;
+    sa[c] = ad[c];
+    atomicAdd(dbl + c, dz);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C * C; i += blockDim.x) atomicAdd(dwl + i, sdz[i / C] * sa[i % C]);
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float d = 0.f;
+    for (int co = 0; co < C; ++co) d += wl[co * C + c] * sdz[co];
+    dad[(int64_t)n * C + c] = d;
+  }
+}
+
+// backward of dropout, dw3x3, relu, BatchNorm; writes dpool[n][bin][cs] already divided by the bin area
+__global__ void __launch_bounds__(256) k_att_bwd1(const float* __restrict__ pooled, const float* __restrict__ gamma,
+                                                  const float* __restrict__ beta, const float* __restrict__ w3,
+                                                  const float* __restrict__ mask, const float* __restrict__ save,
+                                                  const float* __restrict__ dad, float* __restrict__ dpool, int cs, int coff,
+                                                  int H, int W, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                  float* __restrict__ dw3, float* __restrict__ db3, int N, int C,
+                                                  int training) {
+  __shared__ double rs[8][32], rq[8][32];
+  __shared__ float rw[8][32][10];
+  const float* smean = save + (int64_t)N * C * 2;
+  const float* sinv = smean + C;
+  const int cl = threadIdx.x & 31, nl = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
+  const bool ok = c < C;
+  const float mean = ok ? smean[c] : 0.f, invstd = ok ? sinv[c] : 0.f, gm = ok ? gamma[c] : 0.f, bt = ok ? beta[c] : 0.f;
+  float wt[9], dwt[9], binv[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    wt[t] = ok ? w3[c * 9 + t] : 0.f;
+    dwt[t] = 0.f;
+    const int bi = t / 3, bj = t % 3;
+    binv[t] = 1.f / (float)((lhn_bin_hi(bi, H) - lhn_bin_lo(bi, H)) * (lhn_bin_hi(bj, W) - lhn_bin_lo(bj, W)));
+  }
+  double sd = 0, sdx = 0;
+  float dbias = 0.f;
+  if (ok)
+    for (int n = nl; n < N; n += 8) {
+      float da = dad[(int64_t)n * C + c];
+      if (mask) da *= mask[(int64_t)n * C + c];
+      dbias += da;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const float xh = (pooled[((int64_t)n * 9 + t) * C + c] - mean) * invstd;
+        const float u = xh * gm + bt;
+        const float r = fmaxf(u, 0.f);
+        dwt[t] += da * r;
+        const float du = u > 0.f ? da * wt[t] : 0.f;
+        sd += du;
+        sdx += (double)du * xh;
+      }
+    }
+  rs[nl][cl] = sd;
+  rq[nl][cl] = sdx;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) rw[nl][cl][t] = dwt[t];
+  rw[nl][cl][9] = dbias;
+  __syncthreads();
+  sd = 0;
+  sdx = 0;
+  for (int j = 0; j < 8; ++j) {
+    sd += rs[j][cl];
+    sdx += rq[j][cl];
+  }
+  if (nl == 0 && ok) {
+    dgamma[c] += (float)sdx;
+    dbeta[c] += (float)sd;
+    for (int t = 0; t < 10; ++t) {
+      float v = 0.f;
+      for (int j = 0; j < 8; ++j) v += rw[j][cl][t];
+      if (t < 9) dw3[c * 9 + t] += v;
+      else if (db3) db3[c] += v;
+    }
+  }
+  if (ok) {
+    const double cnt = 9.0 * N;
+    const float m1 = (float)(sd / cnt), m2 = (float)(sdx / cnt);
+    for (int n = nl; n < N; n += 8) {
+      float da = dad[(int64_t)n * C + c];
+      if (mask) da *= mask[(int64_t)n * C + c];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const float xh = (pooled[((int64_t)n * 9 + t) * C + c] - mean) * invstd;
+        const float u = xh * gm + bt;
+        const float du = u > 0.f ? da * wt[t] : 0.f;
+        const float dp = training ? gm * invstd * (du - m1 - xh * m2) : gm * invstd * du;
+        dpool[((int64_t)n * 9 + t) * cs + coff + c] = dp * binv[t];
+      }
+    }
+  }
+}
+
+extern "C" int lhn_att_mlp_fwd(const float* pooled, const float* gamma, const float* beta, float* rmean, float* rvar, int64_t* nbt,
+                               const float* w3, const float* b3, const float* wl, const float* bl, const float* dropmask,
+                               float* gate, int gate_stride, int gate_coff, float* save, int N, int C, float eps, float momentum,
+                               int training, void* stream) {
+  LHN_CHECK_ARG(pooled && gamma && beta && rmean && rvar && w3 && wl && bl && gate && save, "lhn_att_mlp_fwd: null pointer");
+  LHN_CHECK_ARG(C > 0 && C <= 256 && N > 0, "lhn_att_mlp_fwd: C=%d (<=256)", C);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_att1, dim3((C + 31) / 32), dim3(256), 0, s, pooled, gamma, beta, rmean, rvar, nbt, w3, b3, dropmask, save, N,
+                     C, eps, momentum, training);
+  hipLaunchKernelGGL(k_att2, dim3(N), dim3(128), 0, s, wl, bl, save, gate, gate_stride, gate_coff, N, C);
+  LHN_CHECK_LAUNCH("lhn_att_mlp_fwd");
+  return 0;
+}
+
+extern "C" int lhn_att_mlp_bwd(const float* pooled, const float* gamma, const float* beta, const float* w3, const float* wl,
+                               const float* dropmask, float* save, const float* dgate, float* dpool, int cstride, int coff, int H,
+                               int W, float* dgamma, float* dbeta, float* dw3, float* db3, float* dwl, float* dbl, int N, int C,
+                               void* stream) {
+  LHN_CHECK_ARG(pooled && gamma && beta && w3 && wl && save && dgate && dpool && dgamma && dbeta && dw3 && dwl && dbl,
+                "lhn_att_mlp_bwd: null pointer");
+  LHN_CHECK_ARG(C > 0 && C <= 256 && N > 0, "lhn_att_mlp_bwd: C=%d (<=256)", C);
+  hipStream_t s = (hipStream_t)stream;
+  float* dad = save + (int64_t)N * C * 2 + 2 * C;
+  hipLaunchKernelGGL(k_att_bwd2, dim3(N), dim3(256), 0, s, wl, save, dgate, dad, dwl, dbl, N, C);
+  hipLaunchKernelGGL(k_att_bwd1, dim3((C + 31) / 32), dim3(256), 0, s, pooled, gamma, beta, w3, dropmask, save, dad, dpool, cstride,
+                     coff, H, W, dgamma, dbeta, dw3, db3, N, C, 1);
+  LHN_CHECK_LAUNCH("lhn_att_mlp_bwd");
+  return 0;
+}

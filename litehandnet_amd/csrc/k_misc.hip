@@ -16,9 +16,11 @@ static inline bool pow2i(int v) { return v > 0 && (v & (v - 1)) == 0; }
 __global__ void k_bn_finalize(const double* __restrict__ stats, const float* __restrict__ gamma,
                               const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
                               int64_t* __restrict__ nbt, float* __restrict__ table, int cs, int coff, int C,
-                              float* __restrict__ save, double count, float eps, float momentum, float slope, int training) {
+                              float* __restrict__ save, double count, float eps, float momentum, float slope, int training,
+                              const float* __restrict__ cbias) {
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     double mean, var;
+    const double cb = cbias ? (double)cbias[c] : 0.0;   // bias of the conv in front: stored output excludes it
     if (training) {
       double s1 = 0, s2 = 0;
       for (int r = 0; r < LHN_STAT_REPLICAS; ++r) {
@@ -29,12 +31,12 @@ __global__ void k_bn_finalize(const double* __restrict__ stats, const float* __r
       var = s2 / count - mean * mean;
       if (var < 0) var = 0;
       if (rmean) {
-        rmean[c] = (float)((1.0 - (double)momentum) * (double)rmean[c] + (double)momentum * mean);
+        rmean[c] = (float)((1.0 - (double)momentum) * (double)rmean[c] + (double)momentum * (mean + cb));
         const double unb = count > 1 ? var * count / (count - 1.0) : var;
         rvar[c] = (float)((1.0 - (double)momentum) * (double)rvar[c] + (double)momentum * unb);
       }
     } else {
-      mean = rmean[c];
+      mean = (double)rmean[c] - cb;
       var = rvar[c];
     }
     const float invstd = (float)(1.0 / sqrt(var + (double)eps));
@@ -111,10 +113,17 @@ __global__ void __launch_bounds__(256) k_ew_fwd(EwSrcs S, int nsrc, lhn_view dst
           const int ws = nearest_src(w, S.v[k].W, dst.W);
           acc += lhn_apply_xf(*reinterpret_cast<const f4*>(base[k] + (size_t)ws * S.v[k].cstride), xf[k]) * gate[k];
         }
-      acc.x = lhn_lrelu(acc.x, out_slope);
-      acc.y = lhn_lrelu(acc.y, out_slope);
-      acc.z = lhn_lrelu(acc.z, out_slope);
-      acc.w = lhn_lrelu(acc.w, out_slope);
+      if (out_slope == LHN_SLOPE_SILU) {
+        acc.x = lhn_silu(acc.x);
+        acc.y = lhn_silu(acc.y);
+        acc.z = lhn_silu(acc.z);
+        acc.w = lhn_silu(acc.w);
+      } else {
+        acc.x = lhn_lrelu(acc.x, out_slope);
+        acc.y = lhn_lrelu(acc.y, out_slope);
+        acc.z = lhn_lrelu(acc.z, out_slope);
+        acc.w = lhn_lrelu(acc.w, out_slope);
+      }
       *reinterpret_cast<f4*>(out + (size_t)w * dst.cstride) = acc;
     }
   }
@@ -143,7 +152,15 @@ __global__ void __launch_bounds__(256) k_ew_bwd_src(lhn_view src, lhn_view dst, 
             lhn_gradview gv{nullptr, dst_dpool, nullptr};
             e += lhn_dpool_sum(gv, dst, n, hd, wd, cd);
           }
-          if (out_slope != 1.f) {
+          if (out_slope == LHN_SLOPE_SILU) {
+            // single same-size source (host-checked): recompute the pre-activation from it
+            const Xf4 sxf = lhn_load_xf(src, src.coff + 4 * c4);
+            const f4 v = lhn_load_val(src, sxf, (int64_t)(n * src.H + h) * src.W + w, n, src.coff + 4 * c4);
+            e.x *= lhn_silu_grad(v.x);
+            e.y *= lhn_silu_grad(v.y);
+            e.z *= lhn_silu_grad(v.z);
+            e.w *= lhn_silu_grad(v.w);
+          } else if (out_slope != 1.f) {
             const f4 o = *reinterpret_cast<const f4*>(dst.data + pd);
             e.x *= o.x > 0.f ? 1.f : out_slope;
             e.y *= o.y > 0.f ? 1.f : out_slope;
@@ -606,13 +623,13 @@ int lhn_reduce_replicas(float* out, const float* part, int64_t n, int nrep, int6
 
 int lhn_bn_finalize(const double* stats, const float* gamma, const float* beta, float* running_mean, float* running_var,
                     int64_t* nbt, float* table, int cstride, int coff, int C, float* save, double count, float eps,
-                    float momentum, float slope, int training, void* stream) {
+                    float momentum, float slope, int training, const float* conv_bias, void* stream) {
   LHN_CHECK_ARG(table && C > 0 && coff >= 0 && coff + C <= cstride, "lhn_bn_finalize: bad table slice");
   LHN_CHECK_ARG(training ? (stats != nullptr) : (running_mean && running_var), "lhn_bn_finalize: missing statistics");
   LHN_CHECK_ARG(!training || count >= 1, "lhn_bn_finalize: count");
   hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(C <= 64 ? 64 : (C <= 128 ? 128 : 256)), 0, (hipStream_t)stream, stats,
                      gamma, beta, running_mean, running_var, nbt, table, cstride, coff, C, save, count, eps, momentum,
-                     slope, training);
+                     slope, training, conv_bias);
   LHN_CHECK_LAUNCH("lhn_bn_finalize");
   return 0;
 }
@@ -666,6 +683,7 @@ int lhn_ew_bwd2(const lhn_view* src, const lhn_view* dst, const float* ddst, con
                 float* dsrc, int accumulate, void* stream) {
   LHN_CHECK_ARG(lhn_view_ok(src) && lhn_view_ok(dst) && ddst && dsrc && src->C == dst->C, "lhn_ew_bwd2: bad args");
   LHN_CHECK_ARG(dst->H % src->H == 0 && dst->W % src->W == 0, "lhn_ew_bwd2: non-integer upsample");
+  LHN_CHECK_ARG(out_slope != LHN_SLOPE_SILU || (dst->H == src->H && dst->W == src->W), "lhn_ew_bwd2: SiLU needs a single same-size source");
   LHN_CHECK_ARG(pow2i(src->C / 4) && src->C <= 1024, "lhn_ew_bwd2: C=%d", src->C);
   hipLaunchKernelGGL(k_ew_bwd_src, dim3(grid_cap((int64_t)src->N * src->H, 8)), dim3(256), 0, (hipStream_t)stream, *src, *dst, ddst,
                      dst_dpool, out_slope, dsrc, accumulate);

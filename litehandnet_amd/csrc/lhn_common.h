@@ -50,6 +50,12 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f16v __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ float lhn_lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
+// SiLU (models/pose_hg_ms_att.py:82,87): only the elementwise combine applies it (out_slope == LHN_SLOPE_SILU)
+__device__ __forceinline__ float lhn_silu(float v) { return v / (1.f + expf(-v)); }
+__device__ __forceinline__ float lhn_silu_grad(float v) {
+  const float s = 1.f / (1.f + expf(-v));
+  return s * (1.f + v * (1.f - s));
+}
 
 // pending transform of 4 consecutive channels of a view (absolute channel c, multiple of 4)
 struct Xf4 {
@@ -184,7 +190,8 @@ __device__ __forceinline__ void lhn_bn_finalize_block(const lhn_bnfin& f, const 
     double var = s2 / f.count - mean * mean;
     if (var < 0) var = 0;
     if (f.running_mean) {
-      f.running_mean[c] = (float)((1.0 - (double)f.momentum) * (double)f.running_mean[c] + (double)f.momentum * mean);
+      const double bm = mean + (f.conv_bias ? (double)f.conv_bias[c] : 0.0);
+      f.running_mean[c] = (float)((1.0 - (double)f.momentum) * (double)f.running_mean[c] + (double)f.momentum * bm);
       const double unb = f.count > 1 ? var * f.count / (f.count - 1.0) : var;
       f.running_var[c] = (float)((1.0 - (double)f.momentum) * (double)f.running_var[c] + (double)f.momentum * unb);
     }

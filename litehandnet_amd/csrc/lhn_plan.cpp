@@ -10,9 +10,9 @@ extern "C" int lhn_ew_bwd2(const lhn_view* src, const lhn_view* dst, const float
 
 enum {
   OP_STEM = 1, OP_PW = 2, OP_DW = 3, OP_KXK = 4, OP_FINALIZE = 5, OP_EW = 6, OP_MAXPOOL = 7, OP_AVGPOOL = 8,
-  OP_CA_MLP = 9, OP_TABLE_FILL = 10, OP_MEMSET = 11,
+  OP_CA_MLP = 9, OP_TABLE_FILL = 10, OP_MEMSET = 11, OP_ATT_MLP = 12,
   OP_STEM_BWD = 101, OP_PW_BWD = 102, OP_DW_BWD = 103, OP_KXK_BWD = 104, OP_BN_BWD = 105, OP_EW_BWD = 106,
-  OP_MAXPOOL_BWD = 107, OP_AVGPOOL_BWD = 108, OP_GATE_REDUCE = 109, OP_CA_MLP_BWD = 110,
+  OP_MAXPOOL_BWD = 107, OP_AVGPOOL_BWD = 108, OP_GATE_REDUCE = 109, OP_CA_MLP_BWD = 110, OP_ATT_MLP_BWD = 111,
 };
 
 struct Plan {
@@ -60,6 +60,7 @@ static lhn_bnfin mkfin(const Plan* P, void* ws, const lhn_op& o, void* const* pa
   f.count = (double)b.N * b.H * b.W;
   f.cstride = b.C; f.coff = o.out_coff; f.C = o.out_C;
   f.eps = o.f[0]; f.momentum = o.f[1]; f.slope = o.f[2];
+  f.conv_bias = prm<const float>(params, o.p[1]);   // biased conv + BN: the bias lives in the finalize only
   return f;
 }
 // The finalize runs as its own tiny launch unless LHN_FUSE_FINALIZE=1: measured on MI355X the in-kernel
@@ -76,7 +77,7 @@ static bool fuse_finalize() {
 static int sep_finalize(const lhn_bnfin& f, const double* stats, int training, void* stream) {
   return lhn_bn_finalize(training ? stats : nullptr, f.gamma, f.beta, f.running_mean, f.running_var,
                          training ? f.num_batches_tracked : nullptr, f.table, f.cstride, f.coff, f.C,
-                         training ? f.save_mean_invstd : nullptr, f.count, f.eps, f.momentum, f.slope, training, stream);
+                         training ? f.save_mean_invstd : nullptr, f.count, f.eps, f.momentum, f.slope, training, f.conv_bias, stream);
 }
 
 extern "C" {
@@ -159,7 +160,7 @@ int lhn_plan_run(void* plan, int phase, void* ws, void* const* params, void* con
         const bool bn = !o.i[1] && conv_has_bn(o);
         lhn_bnfin fin;
         if (bn) fin = mkfin(P, ws, o, params);
-        rc = lhn_conv_pw_fwd(&x, prm<const float>(params, o.p[0]), prm<const float>(params, o.p[1]), &y,
+        rc = lhn_conv_pw_fwd(&x, prm<const float>(params, o.p[0]), bn ? nullptr : prm<const float>(params, o.p[1]), &y,
                              (training && o.ws[0] >= 0) ? reinterpret_cast<double*>(at(ws, o.ws[0])) : nullptr, o.i[0], nchw,
                              (bn && training && fuse_finalize()) ? &fin : nullptr, stream);
         if (!rc && bn && !(training && fuse_finalize())) rc = sep_finalize(fin, reinterpret_cast<const double*>(at(ws, o.ws[0])), training, stream);
@@ -197,7 +198,7 @@ int lhn_plan_run(void* plan, int phase, void* ws, void* const* params, void* con
                              prm<const float>(params, o.p[1]), prm<float>(params, o.p[2]), prm<float>(params, o.p[3]),
                              prm<int64_t>(params, o.p[4]), reinterpret_cast<float*>(at(ws, b.table_off)), b.C, o.out_coff,
                              o.out_C, reinterpret_cast<float*>(at(ws, o.ws[1])), (double)sb.N * sb.H * sb.W, o.f[0], o.f[1],
-                             o.f[2], training, stream);
+                             o.f[2], training, nullptr, stream);
         break;
       }
       case OP_EW: {
@@ -227,6 +228,17 @@ int lhn_plan_run(void* plan, int phase, void* ws, void* const* params, void* con
                             (training && o.ws[2] >= 0) ? reinterpret_cast<const float*>(at(ws, o.ws[2])) : nullptr,
                             reinterpret_cast<float*>(at(ws, b.gate_off)), b.C, o.out_coff,
                             reinterpret_cast<float*>(at(ws, o.ws[1])), b.N, o.out_C, o.f[0], o.f[1], training, stream);
+        break;
+      }
+      case OP_ATT_MLP: {  // p: gamma, beta, rmean, rvar, nbt, w3, b3, wl, bl; ws: pooled, save, mask
+        const lhn_buf& b = P->bufs[o.out_buf];
+        rc = lhn_att_mlp_fwd(reinterpret_cast<const float*>(at(ws, o.ws[0])), prm<const float>(params, o.p[0]),
+                             prm<const float>(params, o.p[1]), prm<float>(params, o.p[2]), prm<float>(params, o.p[3]),
+                             prm<int64_t>(params, o.p[4]), prm<const float>(params, o.p[5]), prm<const float>(params, o.p[6]),
+                             prm<const float>(params, o.p[7]), prm<const float>(params, o.p[8]),
+                             (training && o.ws[2] >= 0) ? reinterpret_cast<const float*>(at(ws, o.ws[2])) : nullptr,
+                             reinterpret_cast<float*>(at(ws, b.gate_off)), b.C, o.out_coff,
+                             reinterpret_cast<float*>(at(ws, o.ws[1])), b.N, o.out_C, o.f[0], o.f[1], training, stream);
         break;
       }
       // ------------------------------------------------------------------ backward
@@ -337,6 +349,17 @@ int lhn_plan_run(void* plan, int phase, void* ws, void* const* params, void* con
                             prm<float>(grads, o.p[5]), prm<float>(grads, o.p[6]), prm<float>(grads, o.p[7]),
                             prm<float>(grads, o.p[8]), prm<float>(grads, o.p[9]), prm<float>(grads, o.p[10]), b.N, o.out_C,
                             stream);
+        break;
+      }
+      case OP_ATT_MLP_BWD: {  // p: gamma, beta, w3, wl (params) | dgamma, dbeta, dw3, db3, dwl, dbl (grads); ws: pooled, save, mask, dgate
+        const lhn_buf& b = P->bufs[o.out_buf];
+        rc = lhn_att_mlp_bwd(reinterpret_cast<const float*>(at(ws, o.ws[0])), prm<const float>(params, o.p[0]),
+                             prm<const float>(params, o.p[1]), prm<const float>(params, o.p[2]), prm<const float>(params, o.p[3]),
+                             o.ws[2] >= 0 ? reinterpret_cast<const float*>(at(ws, o.ws[2])) : nullptr,
+                             reinterpret_cast<float*>(at(ws, o.ws[1])), reinterpret_cast<const float*>(at(ws, o.ws[3])),
+                             reinterpret_cast<float*>(at(ws, b.dpool_off)), b.C, o.out_coff, b.H, b.W, prm<float>(grads, o.p[4]),
+                             prm<float>(grads, o.p[5]), prm<float>(grads, o.p[6]), prm<float>(grads, o.p[7]),
+                             prm<float>(grads, o.p[8]), prm<float>(grads, o.p[9]), b.N, o.out_C, stream);
         break;
       }
       default:

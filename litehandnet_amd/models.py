@@ -1,7 +1,7 @@
 """Model registry -- models/__init__.py:11-26 restricted to the hot path."""
 from . import _lib
 
-__all__ = ["litehandnet", "litehourglass"]
+__all__ = ["litehandnet", "litehourglass", "mynet"]
 
 
 def get_model(cfg):
@@ -10,5 +10,8 @@ def get_model(cfg):
     if name == "litehourglass":
         from .litehourglass import LiteHandNet
         return LiteHandNet(cfg)
+    if name == "mynet":
+        from .pose_hg_ms_att import MultiScaleAttentionHourglass
+        return MultiScaleAttentionHourglass(cfg)
     from .liteHandNet import LiteHandNet
     return LiteHandNet(cfg)

@@ -23,8 +23,9 @@ from . import _lib
 from ._lib import Buf, Op
 
 # op kinds (must match csrc/lhn_plan.cpp)
-STEM, PW, DW, KXK, FINALIZE, EW, MAXPOOL, AVGPOOL, CA_MLP, TABLE_FILL, MEMSET = range(1, 12)
-STEM_BWD, PW_BWD, DW_BWD, KXK_BWD, BN_BWD, EW_BWD, MAXPOOL_BWD, AVGPOOL_BWD, GATE_REDUCE, CA_MLP_BWD = range(101, 111)
+STEM, PW, DW, KXK, FINALIZE, EW, MAXPOOL, AVGPOOL, CA_MLP, TABLE_FILL, MEMSET, ATT_MLP = range(1, 13)
+STEM_BWD, PW_BWD, DW_BWD, KXK_BWD, BN_BWD, EW_BWD, MAXPOOL_BWD, AVGPOOL_BWD, GATE_REDUCE, CA_MLP_BWD, ATT_MLP_BWD = range(101, 112)
+SLOPE_SILU = 2.0       # LHN_SLOPE_SILU in include/lhn.h: the combine applies SiLU instead of a leaky ReLU
 
 ALIGN = 256
 STAT_REPLICAS = 32     # LHN_STAT_REPLICAS in include/lhn.h
@@ -218,6 +219,22 @@ class PlanBuilder:
         b.gate = True
         return y
 
+    def me_attention(self, y, att):
+        """`mynet` attention (pose_hg_ms_att.py:165-174) on the WHOLE plain buffer behind `y`; `att` is the reference's
+        nn.Sequential (1 = BatchNorm2d, 3 = depthwise 3x3 conv, 6 = Linear).  Sets the buffer's gate, returns y."""
+        b = self.bufs[y.buf]
+        assert y.coff == 0 and y.C == b.C and not b.gate, "attention gates a whole, ungated buffer"
+        Cc = y.C
+        rec = dict(op=ATT_MLP, y=y, att=att, pooled=self._ws("misc", self.N * 9 * Cc * 4),
+                   save=self._ws("misc", (3 * self.N * Cc + 2 * Cc) * 4),
+                   mask=self._ws("mask", self.N * Cc * 4) if self.p_drop > 0 else None)
+        if self.with_backward:
+            rec["dgate"] = self._ws("misc", self.N * Cc * 4)
+            b.dpool = True
+        self.recs.append(rec)
+        b.gate = True
+        return y
+
     def set_output(self, y):
         """Generic (block-level) output: materialise the consumed value into a plain buffer."""
         self.out_ref = self.ew([y])
@@ -324,16 +341,17 @@ class PlanBuilder:
                     fl = (bn.eps, bn.momentum, r["slope"])
                 else:
                     pbn, wsl, fl = (-1, -1, -1, -1, -1), (stats,), ()
+                cb = self._p(getattr(conv, "bias", None)) if bn is not None else -1   # biased conv + BN: bias goes to the finalize
                 if k == STEM:
-                    fwd.append(mk(STEM, out=out, p=(pw, -1) + pbn, ws=wsl, i=(r["k"], r["stride"], r["pad"], x.H, x.W), f=fl))
+                    fwd.append(mk(STEM, out=out, p=(pw, cb) + pbn, ws=wsl, i=(r["k"], r["stride"], r["pad"], x.H, x.W), f=fl))
                 elif k == PW:
                     o = TRef(-1, 0, out.C, out.H, out.W) if r["nchw"] else out
                     fwd.append(mk(PW, ins=(x,), out=o, p=(pw, self._p(conv.bias)) + pbn, ws=wsl,
                                   i=(r["stride"], 1 if r["nchw"] else 0), f=fl))
                 elif k == DW:
-                    fwd.append(mk(DW, ins=(x,), out=out, p=(pw, -1) + pbn, ws=wsl, i=(r["k"], r["stride"], r["pad"], r["dil"]), f=fl))
+                    fwd.append(mk(DW, ins=(x,), out=out, p=(pw, cb) + pbn, ws=wsl, i=(r["k"], r["stride"], r["pad"], r["dil"]), f=fl))
                 else:
-                    fwd.append(mk(KXK, ins=(x,), out=out, p=(pw, -1) + pbn, ws=wsl, i=(r["stride"],), f=fl))
+                    fwd.append(mk(KXK, ins=(x,), out=out, p=(pw, cb) + pbn, ws=wsl, i=(r["stride"],), f=fl))
             elif k == EW:
                 fwd.append(mk(EW, ins=r["srcs"], out=r["out"], i=(len(r["srcs"]),), f=(r["slope"],)))
             elif k == MAXPOOL:
@@ -353,6 +371,16 @@ class PlanBuilder:
                                  self._p(ca.conv1x1[3].weight), self._p(ca.conv1x1[3].bias)),
                               ws=(self._abs(r["pooled"]), self._abs(r["save"]), self._abs(r["mask"])),
                               f=(1e-5, 0.1)))
+            elif k == ATT_MLP:
+                y, att = r["y"], r["att"]
+                bn, dw, lin = att[1], att[3], att[6]
+                fwd.append(mk(AVGPOOL, ins=(y,), ws=(self._abs(r["pooled"]),), i=(3, 3, 1)))
+                fwd.append(mk(ATT_MLP, out=y,
+                              p=(self._p(bn.weight), self._p(bn.bias), self._p(bn.running_mean), self._p(bn.running_var),
+                                 self._p(bn.num_batches_tracked), self._p(dw.weight), self._p(dw.bias),
+                                 self._p(lin.weight), self._p(lin.bias)),
+                              ws=(self._abs(r["pooled"]), self._abs(r["save"]), self._abs(r["mask"])),
+                              f=(bn.eps, bn.momentum)))
             elif k == CA_MLP:
                 y, ca = r["y"], r["ca"]
                 fwd.append(mk(AVGPOOL, ins=(y,), ws=(self._abs(r["pooled"]),), i=(3, 3, 1)))
@@ -390,7 +418,8 @@ class PlanBuilder:
                             self._needs_zero_grad.add(x.buf)
                             mode = 2
                         o = TRef(-1, 0, out.C, out.H, out.W) if r["nchw"] else out
-                        body.append(mk(PW_BWD, ins=(x,), out=o, p=(pw, pw, self._p(conv.bias)),
+                        # a bias in front of a train-mode BatchNorm has an identically zero gradient
+                        body.append(mk(PW_BWD, ins=(x,), out=o, p=(pw, pw, self._p(conv.bias) if bn is None else -1),
                                        i=(r["stride"], 1 if r["nchw"] else 0, mode, 0, 0, use_coef)))
                     elif k == DW:
                         body.append(mk(DW_BWD, ins=(x,), out=out, p=(pw, pw),
@@ -410,6 +439,16 @@ class PlanBuilder:
                     mode = self._grad_mode(written, r["x"])
                     body.append(mk(AVGPOOL_BWD, ins=(r["x"],), ws=(self.bufs[r["out"].buf].off["grad"],),
                                    i=(r["OH"], r["OW"], 1 if mode == 2 else 0)))
+                elif k == ATT_MLP:
+                    y, att = r["y"], r["att"]
+                    bn, dw, lin = att[1], att[3], att[6]
+                    body.append(mk(GATE_REDUCE, out=y, ws=(-1, -1, -1, self._abs(r["dgate"]))))
+                    body.append(mk(ATT_MLP_BWD, out=y,
+                                   p=(self._p(bn.weight), self._p(bn.bias), self._p(dw.weight), self._p(lin.weight),
+                                      self._p(bn.weight), self._p(bn.bias), self._p(dw.weight), self._p(dw.bias),
+                                      self._p(lin.weight), self._p(lin.bias)),
+                                   ws=(self._abs(r["pooled"]), self._abs(r["save"]), self._abs(r["mask"]),
+                                       self._abs(r["dgate"]))))
                 elif k == CA_MLP:
                     y, ca = r["y"], r["ca"]
                     bn = ca.conv3x3.bn

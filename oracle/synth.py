@@ -14,6 +14,7 @@ def synth_state_dict(model, seed=0, mode="conditioned"):
     mode 'reference_init': what the reference's init_weights() distributions look like
     (conv ~ N(0,1); BN gamma ~ N(0,1) for variant A / 1 for B is left to the model's own init)."""
     out = {}
+    bn = {n for n, m in model.named_modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)}
     for k, v in model.state_dict().items():
         r = _rng(k, seed)
         if k.endswith("num_batches_tracked"):
@@ -27,7 +28,7 @@ def synth_state_dict(model, seed=0, mode="conditioned"):
         elif v.dim() == 4:
             fan_in = shape[1] * shape[2] * shape[3]
             a = r.normal(0, 1.0 if mode == "reference_init" else fan_in ** -0.5, shape)
-        elif ".bn." in k or "rbr_identity" in k:
+        elif k.rsplit(".", 1)[0] in bn:
             a = r.uniform(0.5, 1.5, shape) if k.endswith("weight") else r.normal(0, 0.1, shape)
         else:  # conv bias
             a = r.normal(0, 0.1, shape)

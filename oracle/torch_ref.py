@@ -16,6 +16,7 @@ Reference behaviour followed (paths relative to the reference tree):
   * channel attention              models/pose_estimation/liteHandNet/common.py:40-66
   * variant A (registered name)    models/pose_estimation/liteHandNet/liteHandNet.py:8-238
   * variant B (MSRB hourglass)     models/pose_estimation/liteHandNet/litehourglass.py:13-237
+  * `mynet` (a13)                  models/pose_hg_ms_att.py:7-265
   * deploy-time re-parameterisation repblocks.py:46-73,169-236, common.py:68-90, liteHandNet.py:240-244
   * init                           models/weight_init.py:21-32
   * loss                           loss/loss.py:69-114, loss/heatmapLoss.py:228-265
@@ -446,6 +447,172 @@ class LiteHandNet(nn.Module):
                 nn.init.zeros_(b)
 
 
+
+# --------------------------------------------------------------------------
+# `mynet`: MultiScaleAttentionHourglass  (models/pose_hg_ms_att.py:7-265, SURVEY section 8 row a13)
+# Same topology as variant A built from plain Conv2d(+bias)+BN+ReLU, a BN->SiLU->conv pre-activation unit and a
+# pooled-BN-ReLU-dw3x3-Linear attention.  Attribute names / Sequential indices follow the reference's state_dict.
+# --------------------------------------------------------------------------
+def _seq(*mods):
+    return nn.Sequential(*mods)
+
+
+def _cbr(cin, cout, k, stride=1, pad=0, groups=1, bias=True, act=None, dil=1):
+    """[conv, BN] (+ activation module when given) as a flat list -- callers splice it into a Sequential."""
+    mods = [nn.Conv2d(cin, cout, k, stride, pad, dil, groups, bias=bias), nn.BatchNorm2d(cout)]
+    if act is not None:
+        mods.append(act)
+    return mods
+
+
+class MyDWConv(nn.Module):
+    """pose_hg_ms_att.py:7-22: dw3x3+BN, ReLU, 1x1+BN, ReLU (bias=False)."""
+
+    def __init__(self, cin, cout, padding=1, dilation=1):
+        super().__init__()
+        self.depthwise_conv = _seq(*_cbr(cin, cin, 3, 1, padding, cin, False, dil=dilation))
+        self.mid_relu = nn.ReLU()
+        self.pointwise_conv = _seq(*_cbr(cin, cout, 1, bias=False))
+        self.last_relu = nn.ReLU()
+
+    def forward(self, x):
+        return self.last_relu(self.pointwise_conv(self.mid_relu(self.depthwise_conv(x))))
+
+
+class MyBottleNeck(nn.Module):
+    """:24-39: relu(x + [1x1 C->C/4, 3x3, 1x1 ->C]) with biased convs + BN."""
+
+    def __init__(self, c):
+        super().__init__()
+        q = c // 4
+        self.conv = _seq(*_cbr(c, q, 1, act=nn.ReLU()), *_cbr(q, q, 3, 1, 1, act=nn.ReLU()), *_cbr(q, c, 1))
+
+    def forward(self, x):
+        return F.relu(x + self.conv(x))
+
+
+class MyBasicBlock(nn.Module):
+    """:42-61."""
+
+    def __init__(self, cin, cout, stride=1):
+        super().__init__()
+        self.conv = _seq(*_cbr(cin, cout, 3, stride, 1, act=nn.ReLU()), *_cbr(cout, cout, 3, 1, 1))
+        self.skip_layer = _seq(*_cbr(cin, cout, 1, stride)) if (stride == 2 or cin != cout) else nn.Identity()
+
+    def forward(self, x):
+        return F.relu(self.skip_layer(x) + self.conv(x))
+
+
+class MyResidual(nn.Module):
+    """:63-72."""
+
+    def __init__(self, cin, cout, stride=1, num_block=2):
+        super().__init__()
+        self.conv1 = MyBasicBlock(cin, cout, stride)
+        self.blocks = _seq(*[MyBottleNeck(cout) for _ in range(num_block)])
+
+    def forward(self, x):
+        return self.blocks(self.conv1(x))
+
+
+class BRC(nn.Module):
+    """:74-90: BatchNorm -> SiLU -> conv (registration order conv, silu, bn)."""
+
+    def __init__(self, cin, cout, k=3, stride=1, padding=1, bias=False, dilation=1):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, k, stride, padding, dilation, bias=bias)
+        self.silu = nn.SiLU()
+        self.bn = nn.BatchNorm2d(cin)
+
+    def forward(self, x):
+        return self.conv(self.silu(self.bn(x)))
+
+
+class ME_att(nn.Module):
+    """:141-193."""
+
+    def __init__(self, cin, cout, p_drop=0.3):
+        super().__init__()
+        m = cin // 2
+        self.conv1 = BRC(cin, m, 1, 1, 0)
+        self.mid1_conv = nn.ModuleList([_seq(MyDWConv(m, m // 2), MyDWConv(m // 2, m // 2)),
+                                        _seq(MyDWConv(m, m), MyDWConv(m, m))])
+        self.mid2_conv = nn.ModuleList([_seq(MyDWConv(m, m // 2, 2, 2), MyDWConv(m // 2, m // 2)),
+                                        _seq(MyDWConv(m, m, 2, 2), MyDWConv(m, m))])
+        self.conv2 = BRC(cin, cout, 1, 1, 0)
+        self.att = _seq(nn.AdaptiveAvgPool2d((3, 3)), nn.BatchNorm2d(cout), nn.ReLU(),
+                        nn.Conv2d(cout, cout, 3, 1, 0, groups=cout), nn.Flatten(), nn.Dropout(p=p_drop),
+                        nn.Linear(cout, cout), nn.Sigmoid())
+
+    def forward(self, x):
+        t = self.conv1(x)
+        for r in range(2):
+            t = torch.cat([self.mid1_conv[r](t), self.mid2_conv[r](t)], dim=1)
+        y = self.conv2(t + x)
+        return y * self.att(y)[:, :, None, None]
+
+
+class _HourglassM(nn.Module):
+    """:93-138 (same data flow as variant A's hourglass)."""
+
+    def __init__(self, levels, c, blocks, p_drop):
+        super().__init__()
+        assert len(blocks) == levels - 1
+        self.num_levels = levels
+        self.encoder = nn.ModuleList([ME_att(c, c, p_drop)])
+        self.decoder = nn.ModuleList()
+        for nb in blocks:
+            self.encoder.append(MyResidual(c, c, 2, nb))
+            self.decoder.append(MyResidual(c, c))
+        self.decoder.append(ME_att(c, c, p_drop))
+
+    forward = _HourglassA.forward
+
+
+class _StemM(nn.Module):
+    """my_pelee_stem :196-228."""
+
+    def __init__(self, cout, min_mid=32):
+        super().__init__()
+        m = max(cout // 4, min_mid)
+        self.conv1 = _seq(*_cbr(3, m, 3, 2, 1, bias=False, act=nn.LeakyReLU()),
+                          *_cbr(m, m, 3, 1, 1, m, False, act=nn.LeakyReLU()))
+        self.branch1 = _seq(*_cbr(m, m, 1, act=nn.ReLU()), *_cbr(m, m, 3, 2, 1, act=nn.ReLU()))
+        self.branch2 = nn.MaxPool2d(2, 2, ceil_mode=True)
+        self.conv1x1 = nn.Conv2d(2 * m, cout, 1)
+
+    forward = _StemA.forward
+
+
+class MultiScaleAttentionHourglass(nn.Module):
+    """:231-265.  cfg keys: MODEL.{num_stage,input_channel,output_channel,num_block,output_acitivation}."""
+
+    def __init__(self, cfg, p_drop=0.3):
+        super().__init__()
+        M = cfg.MODEL
+        c = M.get("input_channel", 128)
+        self.with_activation = M.get("output_acitivation", False)
+        self.pre = _StemM(c)
+        self.hgs = _HourglassM(M.get("num_stage", 4), c, M.get("num_block", [2, 2, 2]), p_drop)
+        self.features = _seq(MyBottleNeck(c), *_cbr(c, c, 1, act=nn.LeakyReLU()))
+        self.outs = nn.Conv2d(c, M.get("output_channel", cfg.DATASET.num_joints), 1)
+        self.init_weights()
+
+    def forward(self, x):
+        y = self.outs(self.features(self.hgs(self.pre(x))[-1]))
+        return F.leaky_relu(y, 0.5) if self.with_activation else y
+
+    def init_weights(self):  # :256-262: conv weight ~ N(0,1), bias 0 (weight_init.py:28-32); BN gamma 1, beta 0
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.normal_(m.weight, 0, 1)
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.ones_(m.weight)
+                nn.init.zeros_(m.bias)
+
+
 def get_model(cfg, p_drop=0.3):
     """Mirror of models/__init__.py:20-26 restricted to the hot path.
 
@@ -456,6 +623,8 @@ def get_model(cfg, p_drop=0.3):
         return LiteHandNet(cfg, p_drop)
     if name == "litehourglass":
         return LiteHourglassNet(cfg, p_drop)
+    if name == "mynet":
+        return MultiScaleAttentionHourglass(cfg, p_drop)
     raise AssertionError(f"model <{name}> is outside the hot path")
 
 

@@ -4,14 +4,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import collections
 from litehandnet_amd import get_model
 from litehandnet_amd.config import litehandnet_cfg
-from litehandnet_amd.plan import PlanBuilder, STEM, PW, DW, KXK, EW, MAXPOOL, AVGPOOL, CA_MLP, TABLE_FILL
+from litehandnet_amd.plan import PlanBuilder, STEM, PW, DW, KXK, EW, MAXPOOL, AVGPOOL, CA_MLP, TABLE_FILL, ATT_MLP
 variant = sys.argv[1] if len(sys.argv) > 1 else "B"
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 m = get_model(litehandnet_cfg(variant))
 tensors = list(m.state_dict(keep_vars=True).values())
 pb = PlanBuilder(N, {id(t): j for j, t in enumerate(tensors)}, image_hw=(256, 256), with_backward=False, p_drop=0.0)
 y = m.emit(pb, pb.image())
-names = {STEM: "stem", PW: "pw", DW: "dw", KXK: "kxk", EW: "ew", MAXPOOL: "maxpool", AVGPOOL: "avgpool", CA_MLP: "ca", TABLE_FILL: "table"}
+names = {STEM: "stem", PW: "pw", DW: "dw", KXK: "kxk", EW: "ew", MAXPOOL: "maxpool", AVGPOOL: "avgpool", CA_MLP: "ca", TABLE_FILL: "table", ATT_MLP: "ca"}
 tot = collections.Counter()
 for r in pb.recs:
     k = r["op"]
@@ -23,7 +23,7 @@ for r in pb.recs:
         o = r["out"]
         mb = N * 4 * o.H * o.W * o.C * (1 + len(r["srcs"])) / 1e6
         print(f"{'ew':8s} " + " + ".join(f"b{s.buf}[{s.coff}:{s.coff + s.C}]{s.H}x{s.W}" for s in r["srcs"]) + f" -> b{o.buf}[{o.coff}:{o.coff + o.C}] {o.H}x{o.W} slope={r['slope']} {mb:.1f}MB")
-    elif k == CA_MLP:
+    elif k in (CA_MLP, ATT_MLP):
         yv = r["y"]
         mb = N * 4 * yv.H * yv.W * yv.C / 1e6
         print(f"{'ca':8s} gate on b{yv.buf} {yv.H}x{yv.W}x{yv.C} (pool reads {mb:.1f}MB)")

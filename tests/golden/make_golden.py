@@ -55,7 +55,7 @@ def _load_reference():
 
 def _no_dropout(model):
     for m in model.modules():
-        if isinstance(m, torch.nn.Dropout2d):
+        if isinstance(m, (torch.nn.Dropout2d, torch.nn.Dropout)):
             m.p = 0.0
 
 
@@ -133,6 +133,22 @@ def main():
     _model_case(refB, oraB, 4, 256, 5, "B_256", out)
     _model_case(refA, oraA, 8, 64, 4, "A_64", out)
     _model_case(refA, oraA, 4, 256, 6, "A_256", out)
+
+    # ---- `mynet` (models/pose_hg_ms_att.py); known answer 2,240,405 parameters
+    cfgM = litehandnet_cfg("M")
+    refM, oraM = ref_models.get_model(cfgM), torch_ref.get_model(cfgM)
+    assert sum(p.numel() for p in refM.parameters()) == 2240405
+    assert list(refM.state_dict()) == list(oraM.state_dict())
+    _model_case(refM, oraM, 8, 64, 8, "M_64", out)
+    _model_case(refM, oraM, 4, 256, 9, "M_256", out)
+    sd = synth.synth_state_dict(refM, 10)
+    refM.load_state_dict(sd); oraM.load_state_dict(sd)
+    refM.eval(); oraM.eval()
+    x = synth.synth_images(2, 64, 11)
+    with torch.no_grad():
+        yr, yo = refM(x).numpy(), oraM(x).numpy()
+    assert np.array_equal(yr, yo)
+    np.savez_compressed(os.path.join(HERE, "model_M_64_eval.npz"), seed=11, heatmap=yr, weights_seed=10)
 
     # ---- variant B with CA everywhere + rbu_ca='ca' (exercise gates in the hourglass), eval-mode BN too
     cfgB2 = litehandnet_cfg("B", rbu_ca="ca")

@@ -19,7 +19,7 @@ GRAD_TOL = 1e-3    # gradients vs the float64 oracle, relative to the gradient's
 
 def _no_dropout(m):
     for x in m.modules():
-        if isinstance(x, torch.nn.Dropout2d):
+        if isinstance(x, (torch.nn.Dropout2d, torch.nn.Dropout)):
             x.p = 0.0
 
 
@@ -358,3 +358,47 @@ def test_deploy_units_vs_oracle(dev):
             yr = ref.double()(x.double())
             yo = ours(x.to(dev))
         assert _rel(yo, yr) < FWD_TOL, (j, _rel(yo, yr))
+
+
+# ---------------------------------------------------------------- `mynet` (models/pose_hg_ms_att.py, section 8 row a13)
+def test_mynet_blocks(dev):
+    """Blocks of pose_hg_ms_att.py one by one: biased conv + BN (bias lives in the BN finalize), BN -> SiLU -> conv,
+    pooled-BN-ReLU-dw3x3-Linear attention."""
+    from litehandnet_amd import pose_hg_ms_att as pm
+    _check_block(pm.DWConv(64, 32, padding=2, dilation=2), torch_ref.MyDWConv(64, 32, 2, 2), _x(2, 64, 16, 16), dev)
+    _check_block(pm.BottleNeck(128), torch_ref.MyBottleNeck(128), _x(4, 128, 8, 8), dev, seed=1)
+    for stride in (1, 2):
+        _check_block(pm.BasicBlock(128, 128, stride), torch_ref.MyBasicBlock(128, 128, stride), _x(4, 128, 8, 8), dev, seed=2)
+    _check_block(pm.BRC(64, 32, 1, 1, 0), torch_ref.BRC(64, 32, 1, 1, 0), _x(4, 64, 8, 12), dev, seed=3)
+    _check_block(pm.ME_att(128, 128, p_drop=0.0), torch_ref.ME_att(128, 128, 0.0), _x(4, 128, 16, 16), dev, seed=4)
+    _check_block(pm.my_pelee_stem(128), torch_ref._StemM(128), _x(2, 3, 64, 64), dev, seed=5, no_dx=True)
+
+
+def test_mynet_contract(dev):
+    from litehandnet_amd import get_model
+    cfg = litehandnet_cfg("M")
+    ours, ref = get_model(cfg), torch_ref.get_model(cfg)
+    assert list(ours.state_dict()) == list(ref.state_dict())
+    for (k, a), (_, b) in zip(ours.state_dict().items(), ref.state_dict().items()):
+        assert a.shape == b.shape, k
+    assert sum(p.numel() for p in ours.parameters()) == 2240405       # test_models_performance.ipynb (SURVEY section 8 a13)
+
+
+def test_model_M_64_golden(dev, golden_dir):
+    _model_case(dev, golden_dir, "M_64", variant="M")
+
+
+def test_model_M_256_golden(dev, golden_dir):
+    _model_case(dev, golden_dir, "M_256", variant="M")
+
+
+def test_model_M_eval_golden(dev, golden_dir):
+    """Eval mode exercises the conv-bias-inside-running-mean path: shift = beta - (running_mean - bias) * scale."""
+    from litehandnet_amd import get_model
+    g = np.load(os.path.join(golden_dir, "model_M_64_eval.npz"))
+    m = get_model(litehandnet_cfg("M"))
+    m.load_state_dict(synth.synth_state_dict(m, int(g["weights_seed"])))
+    m.to(dev).eval()
+    with torch.no_grad():
+        y = m(synth.synth_images(2, 64, int(g["seed"])).to(dev))
+    assert np.abs(y.cpu().numpy() - g["heatmap"]).max() <= FWD_TOL * np.abs(g["heatmap"]).max()

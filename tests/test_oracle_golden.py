@@ -64,6 +64,19 @@ def test_model_Bca_64(golden_dir):
     _run_case(golden_dir, "Bca_64", "B", rbu_ca="ca")
 
 
+def test_model_M_64(golden_dir):
+    """`mynet` (models/pose_hg_ms_att.py): oracle vs the reference-generated fixture; 2,240,405 parameters."""
+    _run_case(golden_dir, "M_64", "M")
+    m = torch_ref.get_model(litehandnet_cfg("M"))
+    assert sum(p.numel() for p in m.parameters()) == 2240405
+    g = np.load(os.path.join(golden_dir, "model_M_64_eval.npz"))
+    m.load_state_dict(synth.synth_state_dict(m, int(g["weights_seed"])))
+    m.eval()
+    with torch.no_grad():
+        y = m(synth.synth_images(2, 64, int(g["seed"]))).numpy()
+    assert np.abs(y - g["heatmap"]).max() <= 1e-5 * np.abs(g["heatmap"]).max()
+
+
 def test_eval_mode(golden_dir):
     for tag, variant, wseed in (("B", "B", 5), ("A", "A", 6)):
         g = np.load(os.path.join(golden_dir, f"model_{tag}_64_eval.npz"))
