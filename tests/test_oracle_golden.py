@@ -13,7 +13,7 @@ from oracle import synth, torch_ref
 
 def _no_dropout(m):
     for x in m.modules():
-        if isinstance(x, torch.nn.Dropout2d):
+        if isinstance(x, (torch.nn.Dropout2d, torch.nn.Dropout)):
             x.p = 0.0
 
 
