@@ -397,9 +397,8 @@ static int launch_kxk(const lhn_view* x, const float* w, const lhn_view* y, cons
     }
     attr_done = true;
   }
-  int per_cu = (int)((160 * 1024) / lds);
-  if (per_cu > 4) per_cu = 4;
-  if (per_cu < 1) per_cu = 1;
+  static int per_cu = 0;
+  if (!per_cu) per_cu = lhn_resident_per_cu(&k_kxk<KD, NT, MODE, TAPS, PLAIN>, lds, 4);
   int grid = lhn_num_cus() * per_cu;
   if (grid > ntiles) grid = ntiles;
   lhn_gradview g;
@@ -423,9 +422,8 @@ static int launch_kxk_wgrad(const lhn_view* x, const lhn_view* y, const lhn_grad
     }
     attr_done = true;
   }
-  int per_cu = (int)((160 * 1024) / lds);
-  if (per_cu > 3) per_cu = 3;
-  if (per_cu < 1) per_cu = 1;
+  static int per_cu = 0;
+  if (!per_cu) per_cu = lhn_resident_per_cu(&k_kxk_wgrad<CIN, NTO, TAPS, PLAIN>, lds, 3);
   int grid = TAPS == 1 ? lhn_num_cus() * per_cu : lhn_num_cus() / 4;      // x 9 taps
   if (grid < 1) grid = 1;
   if (grid > ntiles) grid = ntiles;

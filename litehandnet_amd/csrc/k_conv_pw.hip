@@ -19,7 +19,7 @@ __global__ void __launch_bounds__(256) k_pw_fwd(lhn_view x, const float* __restr
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Ws = smem;                    // [32*NT][LDA]
   float* As = smem + 32 * NT * LDA;    // [128][LDA]
-  float* red = As + 128 * LDA;         // [4][32*NT][2]
+  float* red = As;                     // [4][32*NT][2]: aliases the A tile after the last tile's trailing barrier
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
 
@@ -166,7 +166,7 @@ static int launch_pw_fwd(const lhn_view* x, const float* w, const float* bias, c
   if (fin && stats) f = *fin; else f.counter = nullptr;
   const int M = y->N * y->H * y->W;
   const int ntiles = (M + 127) / 128;
-  const size_t lds = (size_t)((32 * NT + 128) * (CIN + 4) + 4 * 32 * NT * 2) * sizeof(float);
+  const size_t lds = (size_t)((32 * NT + 128) * (CIN + 4)) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pw_fwd<CIN, NT>),
@@ -176,9 +176,8 @@ static int launch_pw_fwd(const lhn_view* x, const float* w, const float* bias, c
     }
     attr_done = true;
   }
-  int per_cu = (int)((160 * 1024) / lds);
-  if (per_cu > 4) per_cu = 4;
-  if (per_cu < 1) per_cu = 1;
+  static int per_cu = 0;
+  if (!per_cu) per_cu = lhn_resident_per_cu(&k_pw_fwd<CIN, NT>, lds, 4);
   int grid = lhn_num_cus() * per_cu;
   if (grid > ntiles) grid = ntiles;
   hipLaunchKernelGGL((k_pw_fwd<CIN, NT>), dim3(grid), dim3(256), lds, s, *x, w, bias, *y, stats, stride, y_nchw, cout, M,
@@ -281,20 +280,35 @@ __global__ void __launch_bounds__(256) k_pw_bwd(lhn_view x, const float* __restr
     return ((int64_t)n * x.H + ho * stride) * x.W + wo * stride;
   };
 
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    // ---- stage X
+  // global loads of a tile go to registers (issue) one iteration ahead of their transform + LDS store (commit), so the
+  // next tile's HBM latency overlaps this tile's MFMA work
+  f4 xraw[XPF], yraw[YPF], ydz[YPF];
+  auto issue = [&](int tile) {
+#pragma unroll
+    for (int p = 0; p < XPF; ++p) {
+      const int m = min(tile * 64 + xr0 + p * XRP, M - 1);      // clamped (branch-free); commit() zeroes rows >= M
+      xraw[p] = *reinterpret_cast<const f4*>(x.data + in_pix(m) * x.cstride + xabs);
+    }
+    if (!dy_nchw && ych_ok) {
+#pragma unroll
+      for (int p = 0; p < YPF; ++p) {
+        const int m = min(tile * 64 + yr0 + p * YRP, M - 1);
+        yraw[p] = *reinterpret_cast<const f4*>(y.data + (int64_t)m * y.cstride + yabs);
+        ydz[p] = *reinterpret_cast<const f4*>(gy.dz + (int64_t)m * y.cstride + yabs);
+      }
+    }
+  };
+  auto commit = [&](int tile) {
 #pragma unroll
     for (int p = 0; p < XPF; ++p) {
       const int row = xr0 + p * XRP, m = tile * 64 + row;
       f4 v = (f4){0.f, 0.f, 0.f, 0.f};
       if (m < M) {
-        const f4 raw = *reinterpret_cast<const f4*>(x.data + in_pix(m) * x.cstride + xabs);
-        v = lhn_apply_xf(raw, xxf);
+        v = lhn_apply_xf(xraw[p], xxf);
         if (x.gate) v *= *reinterpret_cast<const f4*>(x.gate + (int64_t)(m / HoWo) * x.cstride + xabs);
       }
       *reinterpret_cast<f4*>(Xs + row * LDX + 4 * xc4) = v;
     }
-    // ---- stage dY
     if (dy_nchw) {
       for (int i = tid; i < 64 * COP; i += 256) {
         const int row = i & 63, co = i >> 6, m = tile * 64 + row;
@@ -313,16 +327,21 @@ __global__ void __launch_bounds__(256) k_pw_bwd(lhn_view x, const float* __restr
         if (m < M && ych_ok) {
           const int n = m / HoWo, r = m - n * HoWo;
           const int h = r / y.W, ww = r - h * y.W;
-          const f4 raw = *reinterpret_cast<const f4*>(y.data + (int64_t)m * y.cstride + yabs);
-          const f4 dz = *reinterpret_cast<const f4*>(gy.dz + (int64_t)m * y.cstride + yabs);
-          const f4 du = lhn_grad_du(y, gy, yxf, raw, dz, n, h, ww, yabs);
-          v = ygr.A * du + ygr.B * raw + ygr.Cc;
+          const f4 du = lhn_grad_du(y, gy, yxf, yraw[p], ydz[p], n, h, ww, yabs);
+          v = ygr.A * du + ygr.B * yraw[p] + ygr.Cc;
           bsum += v;
         }
         *reinterpret_cast<f4*>(dYs + row * LDY + 4 * yc4) = v;
       }
     }
+  };
+
+  int tile = blockIdx.x;
+  if (tile < ntiles) issue(tile);
+  for (; tile < ntiles; tile += gridDim.x) {
+    commit(tile);
     __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x);
 
     // ---- dW += dY^T X   (K = 64 pixels)
 #pragma unroll 4
@@ -441,9 +460,8 @@ static int launch_pw_bwd(const lhn_view* x, const float* w, const lhn_view* y, c
     }
     attr_done = true;
   }
-  int per_cu = (int)((160 * 1024) / lds);
-  if (per_cu > 2) per_cu = 2;
-  if (per_cu < 1) per_cu = 1;
+  static int per_cu = 0;
+  if (!per_cu) per_cu = lhn_resident_per_cu(&k_pw_bwd<CIN, NTO>, lds, 3);
   int grid = lhn_num_cus() * per_cu;
   if (grid > ntiles) grid = ntiles;
   lhn_gradview g = *gy;

@@ -45,6 +45,23 @@ static inline int lhn_num_cus() {
 }
 
 #ifdef __HIPCC__
+// Workgroups of `kernel` (256 threads, `dyn_lds` bytes of dynamic LDS) that are resident on one CU at the same time: the
+// occupancy API, never more than the LDS arithmetic with the kernel's static segment included (a persistent grid that
+// over-estimates this by one runs a second, half-empty round -- measured: 3 x 54,784 B does not fit 160 KB).
+template <typename F>
+static inline int lhn_resident_per_cu(F kernel, size_t dyn_lds, int cap) {
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, 256, dyn_lds) != hipSuccess || n < 1) n = 1;
+  hipFuncAttributes a;
+  if (hipFuncGetAttributes(&a, reinterpret_cast<const void*>(kernel)) == hipSuccess) {
+    size_t per = (dyn_lds + a.sharedSizeBytes + 1023) / 1024 * 1024;
+    const int by_lds = per ? (int)((160 * 1024) / per) : n;
+    if (by_lds < n) n = by_lds;
+  }
+  if (n > cap) n = cap;
+  return n < 1 ? 1 : n;
+}
+
 // ---------------------------------------------------------------- device side
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f16v __attribute__((ext_vector_type(16)));
