@@ -236,8 +236,15 @@ __global__ void __launch_bounds__(256) k_pw_bwd(lhn_view x, const float* __restr
   constexpr int NTI = CIN / 32;
   constexpr int COP = 32 * NTO;
   constexpr int LDW = CIN + 4, LDY = COP + 4, LDX = CIN + 4;
-  constexpr int NDW = (NTO * NTI + 3) / 4;   // dW tiles per wave
-  constexpr int NDX = (NTI + 1) / 2;         // dX ci-tiles per wave
+  // MFMA work split: dX has 2*NTI tiles of 16*NTO MFMAs, dW has T = NTO*NTI tiles of 32 MFMAs (equal totals).  With
+  // CIN = 32 (NTI == 1) dX only occupies waves 0,1, so dW goes to waves 2,3; when there are fewer dW tiles than dW
+  // waves the 64-pixel K range of a tile is split across waves (partial sums meet in the final atomic flush).
+  constexpr int T = NTO * NTI;
+  constexpr bool DW_HI = (NTI == 1);
+  constexpr int DWW = DW_HI ? 2 : 4;                   // waves that compute dW
+  constexpr int KS = T < DWW ? DWW / T : 1;            // K parts per dW tile
+  constexpr int NDW = (T * KS + DWW - 1) / DWW;        // dW accumulators per wave
+  constexpr int NDX = (NTI + 1) / 2;                   // dX ci-tiles per wave
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Ws = smem;                 // [COP][LDW]
   float* dYs = Ws + COP * LDW;      // [64][LDY]
@@ -344,16 +351,20 @@ __global__ void __launch_bounds__(256) k_pw_bwd(lhn_view x, const float* __restr
     if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x);
 
     // ---- dW += dY^T X   (K = 64 pixels)
+    const int dwave = DW_HI ? wave - 2 : wave;
+    if (dwave >= 0) {
+      const int kpart = KS > 1 ? dwave % KS : 0;
 #pragma unroll 4
-    for (int ks = 0; ks < 32; ++ks) {
-      const float* dyr = dYs + (2 * ks + lh) * LDY + l31;
-      const float* xr = Xs + (2 * ks + lh) * LDX + l31;
+      for (int ks = kpart * (32 / KS); ks < (kpart + 1) * (32 / KS); ++ks) {
+        const float* dyr = dYs + (2 * ks + lh) * LDY + l31;
+        const float* xr = Xs + (2 * ks + lh) * LDX + l31;
 #pragma unroll
-      for (int t = 0; t < NDW; ++t) {
-        const int tl = wave + 4 * t;
-        if (tl < NTO * NTI) {
-          const int it = tl / NTI, jt = tl % NTI;
-          accw[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(dyr[32 * it], xr[32 * jt], accw[t], 0, 0, 0);
+        for (int t = 0; t < NDW; ++t) {
+          const int tl = (dwave + DWW * t) / KS;
+          if (tl < T) {
+            const int it = tl / NTI, jt = tl % NTI;
+            accw[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(dyr[32 * it], xr[32 * jt], accw[t], 0, 0, 0);
+          }
         }
       }
     }
@@ -403,8 +414,9 @@ __global__ void __launch_bounds__(256) k_pw_bwd(lhn_view x, const float* __restr
   dw += (size_t)(blockIdx.x % nrep) * rep_stride;
 #pragma unroll
   for (int t = 0; t < NDW; ++t) {
-    const int tl = wave + 4 * t;
-    if (tl < NTO * NTI) {
+    const int dwave = DW_HI ? wave - 2 : wave;
+    const int tl = dwave >= 0 ? (dwave + DWW * t) / KS : T;
+    if (tl < T) {
       const int it = tl / NTI, jt = tl % NTI;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
