@@ -499,24 +499,48 @@ __global__ void __launch_bounds__(256) k_dwk_fwd_lds(lhn_view x, const float* __
     wl[i] = (f4){w[(cc + 0) * KK + k], w[(cc + 1) * KK + k], w[(cc + 2) * KK + k], w[(cc + 3) * KK + k]};
   }
   f4 s = (f4){0.f, 0.f, 0.f, 0.f}, q = s;
-  for (int t = blockIdx.x; t < ntile; t += gridDim.x) {
+  // halo staging in two phases: issue() sends every global load of a tile (clamped coordinates, no branches, so they
+  // are all in flight together) into registers one tile AHEAD; commit() transforms, zeroes the padding and writes LDS
+  constexpr int NIT = (T::PIX + 31) / 32;
+  f4 raw[NIT];
+  auto issue = [&](int t) {
+    int r = t / cgroups;
+    const int tw = r % tiles_w;
+    r /= tiles_w;
+    const int th = r % tiles_h, n = r / tiles_h;
+    const int h0 = th * TH - T::P, w0 = tw * TW - T::P;
+    const float* xin = x.data + (size_t)n * x.H * x.W * x.cstride + cin;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int i = min(pl + 32 * it, T::PIX - 1);
+      const int ph = i / T::WW, pw = i - ph * T::WW;
+      const int ih = min(max(h0 + ph, 0), x.H - 1), iw = min(max(w0 + pw, 0), x.W - 1);
+      raw[it] = *reinterpret_cast<const f4*>(xin + ((size_t)ih * x.W + iw) * x.cstride);
+    }
+  };
+  int t = blockIdx.x;
+  if (t < ntile) issue(t);
+  for (; t < ntile; t += gridDim.x) {
     int r = t / cgroups;
     const int tw = r % tiles_w;
     r /= tiles_w;
     const int th = r % tiles_h, n = r / tiles_h;
     const f4 gate = x.gate ? *reinterpret_cast<const f4*>(x.gate + (size_t)n * x.cstride + cin) : (f4){1.f, 1.f, 1.f, 1.f};
     const int h0 = th * TH - T::P, w0 = tw * TW - T::P;
-    const float* xin = x.data + (size_t)n * x.H * x.W * x.cstride + cin;
     __syncthreads();   // previous tile fully consumed (and wl visible)
-    for (int i = pl; i < T::PIX; i += 32) {
-      const int ph = i / T::WW, pw = i - ph * T::WW;
-      const int ih = h0 + ph, iw = w0 + pw;
-      f4 v = (f4){0.f, 0.f, 0.f, 0.f};
-      if (ih >= 0 && ih < x.H && iw >= 0 && iw < x.W)
-        v = lhn_apply_xf(*reinterpret_cast<const f4*>(xin + ((size_t)ih * x.W + iw) * x.cstride), xf) * gate;
-      tile[i * 8 + c4] = v;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int i = pl + 32 * it;
+      if (i < T::PIX) {
+        const int ph = i / T::WW, pw = i - ph * T::WW;
+        const int ih = h0 + ph, iw = w0 + pw;
+        const bool inb = ih >= 0 && ih < x.H && iw >= 0 && iw < x.W;
+        const f4 v = lhn_apply_xf(raw[it], xf) * gate;
+        tile[i * 8 + c4] = inb ? v : (f4){0.f, 0.f, 0.f, 0.f};
+      }
     }
     __syncthreads();
+    if (t + (int)gridDim.x < ntile) issue(t + gridDim.x);
     const int wo = tw * TW + pl;
     if (wo < y.W) {
       const f4* col = tile + (pl + T::P) * 8 + c4;    // centre column of this thread, tile row 0
@@ -631,17 +655,39 @@ __global__ void __launch_bounds__(256) k_dwk_bwd_lds(lhn_view x, const float* __
     const f4 ygate = y.gate ? *reinterpret_cast<const f4*>(y.gate + (size_t)n * y.cstride + cy) : (f4){1.f, 1.f, 1.f, 1.f};
     const int h0 = th * TH - T::P, w0 = tw * TW - T::P;
     __syncthreads();
-    for (int i = pl; i < T::PIX; i += 32) {
-      const int ph = i / T::WW, pw = i - ph * T::WW;
-      const int ih = h0 + ph, iw = w0 + pw;
-      f4 vx = (f4){0.f, 0.f, 0.f, 0.f}, vy = vx;
-      if (ih >= 0 && ih < x.H && iw >= 0 && iw < x.W) {     // stride 1, "same" padding: x and y share their geometry
+    {
+      // all global loads of the halo tile first (clamped, branch-free), then the dy / x transforms and the LDS stores
+      constexpr int NIT = (T::PIX + 31) / 32;
+      f4 rx[NIT], ry[NIT], rz[NIT];
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int i = min(pl + 32 * it, T::PIX - 1);
+        const int ph = i / T::WW, pw = i - ph * T::WW;
+        const int ih = min(max(h0 + ph, 0), x.H - 1), iw = min(max(w0 + pw, 0), x.W - 1);
         const size_t pix = (size_t)(n * x.H + ih) * x.W + iw;
-        vx = lhn_apply_xf(*reinterpret_cast<const f4*>(x.data + pix * x.cstride + cx), xxf) * xgate;
-        vy = dw_dy_at(y, gy, yxf, ygr, ygate, pix * y.cstride + cy, n, ih, iw, cy);
+        rx[it] = *reinterpret_cast<const f4*>(x.data + pix * x.cstride + cx);
+        ry[it] = *reinterpret_cast<const f4*>(y.data + pix * y.cstride + cy);
+        rz[it] = *reinterpret_cast<const f4*>(gy.dz + pix * y.cstride + cy);
       }
-      tx[i * 8 + c4] = vx;
-      tdy[i * 8 + c4] = vy;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int i = pl + 32 * it;
+        if (i < T::PIX) {
+          const int ph = i / T::WW, pw = i - ph * T::WW;
+          const int ih = h0 + ph, iw = w0 + pw;
+          const bool inb = ih >= 0 && ih < x.H && iw >= 0 && iw < x.W;   // stride 1, "same" padding: x and y share geometry
+          const f4 vx = lhn_apply_xf(rx[it], xxf) * xgate;
+          f4 e = rz[it] * ygate;
+          const f4 u = ry[it] * yxf.sc + yxf.sh;
+          const f4 dl = (f4){u.x > 0.f ? 1.f : yxf.sl.x, u.y > 0.f ? 1.f : yxf.sl.y, u.z > 0.f ? 1.f : yxf.sl.z,
+                             u.w > 0.f ? 1.f : yxf.sl.w};
+          if (gy.dpool && inb) e += lhn_dpool_sum(gy, y, n, ih, iw, cy);
+          const f4 vy = ygr.A * (e * dl) + ygr.B * ry[it] + ygr.Cc;
+          const f4 z = (f4){0.f, 0.f, 0.f, 0.f};
+          tx[i * 8 + c4] = inb ? vx : z;
+          tdy[i * 8 + c4] = inb ? vy : z;
+        }
+      }
     }
     __syncthreads();
     const int wcol = tw * TW + colw;
