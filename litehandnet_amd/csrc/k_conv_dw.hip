@@ -65,21 +65,25 @@ __global__ void __launch_bounds__(256) k_dw_fwd(lhn_view x, const float* __restr
     }
   }
   if (stats) {
-    red[tid * 2] = s;
-    red[tid * 2 + 1] = q;
-    __syncthreads();
-    if (tid < C4) {
-      double sd[4] = {0, 0, 0, 0}, qd[4] = {0, 0, 0, 0};
-      for (int j = 0; j < PL; ++j) {
-        const f4 a = red[(j * C4 + tid) * 2], b = red[(j * C4 + tid) * 2 + 1];
-        sd[0] += a.x; sd[1] += a.y; sd[2] += a.z; sd[3] += a.w;
-        qd[0] += b.x; qd[1] += b.y; qd[2] += b.z; qd[3] += b.w;
-      }
-      double* st = stats + (size_t)(blockIdx.x % LHN_STAT_REPLICAS) * 2 * C;
+    double* st = stats + (size_t)(blockIdx.x % LHN_STAT_REPLICAS) * 2 * C;
+    if (C4 <= 32) {
+      lhn_block_stat_atomics(s, q, C4, red, st, st + C);
+    } else {
+      red[tid * 2] = s;
+      red[tid * 2 + 1] = q;
+      __syncthreads();
+      if (tid < C4) {
+        double sd[4] = {0, 0, 0, 0}, qd[4] = {0, 0, 0, 0};
+        for (int j = 0; j < PL; ++j) {
+          const f4 a = red[(j * C4 + tid) * 2], b = red[(j * C4 + tid) * 2 + 1];
+          sd[0] += a.x; sd[1] += a.y; sd[2] += a.z; sd[3] += a.w;
+          qd[0] += b.x; qd[1] += b.y; qd[2] += b.z; qd[3] += b.w;
+        }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        atomicAdd(st + 4 * tid + j, sd[j]);
-        atomicAdd(st + C + 4 * tid + j, qd[j]);
+        for (int j = 0; j < 4; ++j) {
+          atomicAdd(st + 4 * tid + j, sd[j]);
+          atomicAdd(st + C + 4 * tid + j, qd[j]);
+        }
       }
     }
     if (fin.counter && lhn_last_block(fin.counter)) lhn_bn_finalize_block(fin, stats);
@@ -590,25 +594,9 @@ __global__ void __launch_bounds__(256) k_dwk_fwd_lds(lhn_view x, const float* __
     }
   }
   if (stats) {
-    __syncthreads();
-    red[tid * 2] = s;
-    red[tid * 2 + 1] = q;
-    __syncthreads();
-    if (tid < 8) {
-      double sd[4] = {0, 0, 0, 0}, qd[4] = {0, 0, 0, 0};
-      for (int j = 0; j < 32; ++j) {
-        const f4 a = red[(j * 8 + tid) * 2], b = red[(j * 8 + tid) * 2 + 1];
-        sd[0] += a.x; sd[1] += a.y; sd[2] += a.z; sd[3] += a.w;
-        qd[0] += b.x; qd[1] += b.y; qd[2] += b.z; qd[3] += b.w;
-      }
-      const int C = x.C;
-      double* st = stats + (size_t)((blockIdx.x / cgroups) % LHN_STAT_REPLICAS) * 2 * C + cg * 32;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        atomicAdd(st + 4 * tid + j, sd[j]);
-        atomicAdd(st + C + 4 * tid + j, qd[j]);
-      }
-    }
+    const int C = x.C;
+    double* st = stats + (size_t)((blockIdx.x / cgroups) % LHN_STAT_REPLICAS) * 2 * C + cg * 32;
+    lhn_block_stat_atomics(s, q, 8, red, st, st + C);
     if (fin.counter && lhn_last_block(fin.counter)) lhn_bn_finalize_block(fin, stats);
   }
 }
@@ -770,20 +758,30 @@ __global__ void __launch_bounds__(256) k_dwk_bwd_lds(lhn_view x, const float* __
   // ---- flush dW
   float* dwr = dw + (size_t)((blockIdx.x / cgroups) % nrep) * rep_stride;
   if (REGACC) {
+    // lanes of a wave that share c4 (lane bits 3..5 differ) meet by xor-shuffles, the four waves through LDS (the dy tile
+    // is dead by now), then one thread per (tap, c4) adds four floats
 #pragma unroll
-    for (int k = 0; k < KK; ++k) {
-      __syncthreads();
-      red[tid] = accw[REGACC ? k : 0];
-      __syncthreads();
-      if (tid < 8) {
-        f4 sacc = (f4){0.f, 0.f, 0.f, 0.f};
-        for (int j = 0; j < 32; ++j) sacc += red[j * 8 + tid];
-        const int cb = cg * 32 + 4 * tid;
-        atomicAdd(dwr + (cb + 0) * KK + k, sacc.x);
-        atomicAdd(dwr + (cb + 1) * KK + k, sacc.y);
-        atomicAdd(dwr + (cb + 2) * KK + k, sacc.z);
-        atomicAdd(dwr + (cb + 3) * KK + k, sacc.w);
+    for (int k = 0; k < KK; ++k)
+#pragma unroll
+      for (int o = 8; o < 64; o <<= 1) {
+        accw[k].x += __shfl_xor(accw[k].x, o, 64);
+        accw[k].y += __shfl_xor(accw[k].y, o, 64);
+        accw[k].z += __shfl_xor(accw[k].z, o, 64);
+        accw[k].w += __shfl_xor(accw[k].w, o, 64);
       }
+    __syncthreads();
+    if ((tid & 63) < 8)
+#pragma unroll
+      for (int k = 0; k < KK; ++k) tdy[(k * 4 + (tid >> 6)) * 8 + c4] = accw[k];
+    __syncthreads();
+    if (tid < KK * 8) {
+      const int k = tid >> 3, cc = tid & 7;
+      const f4 sacc = tdy[(k * 4 + 0) * 8 + cc] + tdy[(k * 4 + 1) * 8 + cc] + tdy[(k * 4 + 2) * 8 + cc] + tdy[(k * 4 + 3) * 8 + cc];
+      const int cb = cg * 32 + 4 * cc;
+      atomicAdd(dwr + (cb + 0) * KK + k, sacc.x);
+      atomicAdd(dwr + (cb + 1) * KK + k, sacc.y);
+      atomicAdd(dwr + (cb + 2) * KK + k, sacc.z);
+      atomicAdd(dwr + (cb + 3) * KK + k, sacc.w);
     }
   } else {
     __syncthreads();

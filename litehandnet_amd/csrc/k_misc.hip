@@ -563,21 +563,25 @@ __global__ void __launch_bounds__(256) k_bn_bwd_reduce(lhn_view y, lhn_gradview 
       q += du * ((raw - mean) * inv);
     }
   }
-  red[threadIdx.x * 2] = s;
-  red[threadIdx.x * 2 + 1] = q;
-  __syncthreads();
-  if (threadIdx.x < C4) {
-    double sd[4] = {0, 0, 0, 0}, qd[4] = {0, 0, 0, 0};
-    for (int j = 0; j < PL; ++j) {
-      const f4 a = red[(j * C4 + threadIdx.x) * 2], b = red[(j * C4 + threadIdx.x) * 2 + 1];
-      sd[0] += a.x; sd[1] += a.y; sd[2] += a.z; sd[3] += a.w;
-      qd[0] += b.x; qd[1] += b.y; qd[2] += b.z; qd[3] += b.w;
-    }
-    double* st = sums + (size_t)(blockIdx.x % LHN_STAT_REPLICAS) * 2 * y.C;
+  double* st = sums + (size_t)(blockIdx.x % LHN_STAT_REPLICAS) * 2 * y.C;
+  if (C4 <= 32) {
+    lhn_block_stat_atomics(s, q, C4, red, st, st + y.C);
+  } else {
+    red[threadIdx.x * 2] = s;
+    red[threadIdx.x * 2 + 1] = q;
+    __syncthreads();
+    if (threadIdx.x < C4) {
+      double sd[4] = {0, 0, 0, 0}, qd[4] = {0, 0, 0, 0};
+      for (int j = 0; j < PL; ++j) {
+        const f4 a = red[(j * C4 + threadIdx.x) * 2], b = red[(j * C4 + threadIdx.x) * 2 + 1];
+        sd[0] += a.x; sd[1] += a.y; sd[2] += a.z; sd[3] += a.w;
+        qd[0] += b.x; qd[1] += b.y; qd[2] += b.z; qd[3] += b.w;
+      }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      atomicAdd(st + 4 * threadIdx.x + j, sd[j]);
-      atomicAdd(st + y.C + 4 * threadIdx.x + j, qd[j]);
+      for (int j = 0; j < 4; ++j) {
+        atomicAdd(st + 4 * threadIdx.x + j, sd[j]);
+        atomicAdd(st + y.C + 4 * threadIdx.x + j, qd[j]);
+      }
     }
   }
   if (fin.counter && lhn_last_block(fin.counter)) lhn_bn_bwd_finalize_block(fin, sums, save);
