@@ -36,7 +36,8 @@ typedef struct lhn_view {
 /* gradient-side companion of a BatchNorm'd conv output (see DESIGN.md "backward") */
 typedef struct lhn_gradview {
   const float* dz;       /* gradient w.r.t. the consumed value z, same geometry as the forward view  */
-  const float* dpool;    /* [N][9][cstride] d(loss)/d(pooled)/|bin| from channel attention, or NULL  */
+  const float* dpool;    /* [N][25][cstride] channel-attention pooled gradient per bin-overlap segment
+                          * (sum over the segment's bins of d(loss)/d(pooled)/|bin|), or NULL          */
   const float* coef;     /* [3][cstride]  A | B | C :  dy = A*du + B*y + C   (NULL: dy = du)          */
 } lhn_gradview;
 

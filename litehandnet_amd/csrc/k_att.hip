@@ -116,7 +116,7 @@ __global__ void __launch_bounds__(256) k_att_bwd2(const float* __restrict__ wl, 
   }
 }
 
-// backward of dropout, dw3x3, relu, BatchNorm; writes dpool[n][bin][cs] already divided by the bin area
+// backward of dropout, dw3x3, relu, BatchNorm; writes the 25-segment pooled gradient (lhn_dpool_store)
 __global__ void __launch_bounds__(256) k_att_bwd1(const float* __restrict__ pooled, const float* __restrict__ gamma,
                                                   const float* __restrict__ beta, const float* __restrict__ w3,
                                                   const float* __restrict__ mask, const float* __restrict__ save,
@@ -185,14 +185,16 @@ __global__ void __launch_bounds__(256) k_att_bwd1(const float* __restrict__ pool
     for (int n = nl; n < N; n += 8) {
       float da = dad[(int64_t)n * C + c];
       if (mask) da *= mask[(int64_t)n * C + c];
+      float dseg[9];
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         const float xh = (pooled[((int64_t)n * 9 + t) * C + c] - mean) * invstd;
         const float u = xh * gm + bt;
         const float du = u > 0.f ? da * wt[t] : 0.f;
         const float dp = training ? gm * invstd * (du - m1 - xh * m2) : gm * invstd * du;
-        dpool[((int64_t)n * 9 + t) * cs + coff + c] = dp * binv[t];
+        dseg[t] = dp * binv[t];
       }
+      lhn_dpool_store(dpool, n, cs, coff + c, dseg);
     }
   }
 }

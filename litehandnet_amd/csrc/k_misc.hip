@@ -516,11 +516,13 @@ __global__ void __launch_bounds__(256) k_ca_bwd1(const float* __restrict__ poole
       const float xh = (a[(int64_t)n * C + c] - mean) * invstd;
       float da = gm * invstd * d;
       if (training) da = gm * invstd * (d - (float)(sd / N) - xh * (float)(sdx / N));
+      float dseg[9];
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         dwt[t] += da * pooled[((int64_t)n * 9 + t) * C + c];
-        dpool[((int64_t)n * 9 + t) * cs + coff + c] = da * wt[t] * binv[t];
+        dseg[t] = da * wt[t] * binv[t];
       }
+      lhn_dpool_store(dpool, n, cs, coff + c, dseg);
     }
 #pragma unroll
   for (int t = 0; t < 9; ++t) rw[nl][cl][t] = dwt[t];

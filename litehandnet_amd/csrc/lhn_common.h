@@ -131,18 +131,35 @@ __device__ __forceinline__ Gr4 lhn_load_coef(const lhn_gradview& g, int cstride,
 __device__ __forceinline__ int lhn_bin_lo(int i, int S) { return (i * S) / 3; }
 __device__ __forceinline__ int lhn_bin_hi(int i, int S) { return ((i + 1) * S + 2) / 3; }
 
+// The pooled gradient is stored per SEGMENT, not per bin: the three (possibly overlapping) bins cut each axis into at
+// most five segments -- {bin0}, {bin0,bin1}, {bin1}, {bin1,bin2}, {bin2} -- and the attention backward writes
+// dpool[n][sh*5+sw][c] = sum of (d loss / d pooled[bin]) / |bin| over the bins of segment (sh, sw).  A consumer then needs
+// ONE branch-free load per pixel instead of a divergent loop over up to four bins (H, W >= 2).
+#define LHN_DPOOL_SLOTS 25
+__device__ __forceinline__ int lhn_pool_seg(int h, int S) {
+  return (h >= lhn_bin_lo(1, S)) + (h >= lhn_bin_hi(0, S)) + (h >= lhn_bin_lo(2, S)) + (h >= lhn_bin_hi(1, S));
+}
 __device__ __forceinline__ f4 lhn_dpool_sum(const lhn_gradview& g, const lhn_view& v, int n, int h, int w, int c_abs) {
-  f4 s = (f4){0.f, 0.f, 0.f, 0.f};
+  const int slot = lhn_pool_seg(h, v.H) * 5 + lhn_pool_seg(w, v.W);
+  return *reinterpret_cast<const f4*>(g.dpool + ((int64_t)n * LHN_DPOOL_SLOTS + slot) * v.cstride + c_abs);
+}
+// writer side: d[t] = d loss / d pooled[bin t] / |bin t| for the 9 bins of one (n, channel) -> the 25 segment sums
+__device__ __forceinline__ void lhn_dpool_store(float* dpool, int64_t n, int cs, int c_abs, const float (&d)[9]) {
 #pragma unroll
-  for (int bi = 0; bi < 3; ++bi) {
-    if (h < lhn_bin_lo(bi, v.H) || h >= lhn_bin_hi(bi, v.H)) continue;
+  for (int sh = 0; sh < 5; ++sh)
 #pragma unroll
-    for (int bj = 0; bj < 3; ++bj) {
-      if (w < lhn_bin_lo(bj, v.W) || w >= lhn_bin_hi(bj, v.W)) continue;
-      s += *reinterpret_cast<const f4*>(g.dpool + ((int64_t)n * 9 + bi * 3 + bj) * v.cstride + c_abs);
+    for (int sw = 0; sw < 5; ++sw) {
+      float v = 0.f;
+#pragma unroll
+      for (int bi = 0; bi < 3; ++bi)
+#pragma unroll
+        for (int bj = 0; bj < 3; ++bj) {
+          const bool rin = (sh == 2 * bi) || (sh == 2 * bi - 1) || (sh == 2 * bi + 1);
+          const bool cin = (sw == 2 * bj) || (sw == 2 * bj - 1) || (sw == 2 * bj + 1);
+          if (rin && cin) v += d[bi * 3 + bj];
+        }
+      dpool[(n * LHN_DPOOL_SLOTS + sh * 5 + sw) * cs + c_abs] = v;
     }
-  }
-  return s;
 }
 // returns du (gradient at the BN output) and, through *val_out, nothing else; raw = y
 __device__ __forceinline__ f4 lhn_grad_du(const lhn_view& v, const lhn_gradview& g, const Xf4& t, f4 raw, f4 dz,

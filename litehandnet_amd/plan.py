@@ -262,7 +262,7 @@ class PlanBuilder:
                 base += _al(3 * b.C * 4)
             if self.with_backward and b.dpool:
                 b.off["dpool"] = base
-                base += _al(N * 9 * b.C * 4)
+                base += _al(N * 25 * b.C * 4)      # LHN_DPOOL_SLOTS: 5 x 5 bin-overlap segments
         for b in self.bufs:
             b.off["data"] = base
             base += _al(N * b.H * b.W * b.C * 4)
