@@ -255,16 +255,36 @@ __global__ void __launch_bounds__(256) k_avgpool_fwd(lhn_view x, float* __restri
   const int c4 = threadIdx.x % C4, pl = threadIdx.x / C4;
   const int ca = x.coff + 4 * c4;
   const Xf4 xf = lhn_load_xf(x, ca);
-  f4 s = (f4){0.f, 0.f, 0.f, 0.f};
-  for (int p = pl; p < cnt; p += PL) {
-    const int h = h0 + p / bw, w = w0 + p % bw;
-    s += lhn_load_val(x, xf, ((int64_t)n * x.H + h) * x.W + w, n, ca);
+  // four independent loads in flight per thread; the (per-image) gate factors out of the sum
+  const float* base = x.data + (int64_t)n * x.H * x.W * x.cstride + ca;
+  auto at = [&](int p) { return *reinterpret_cast<const f4*>(base + (int64_t)((h0 + p / bw) * x.W + w0 + p % bw) * x.cstride); };
+  f4 s0 = (f4){0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+  int p = pl;
+  for (; p + 3 * PL < cnt; p += 4 * PL) {
+    const f4 a = at(p), b2 = at(p + PL), c2 = at(p + 2 * PL), d2 = at(p + 3 * PL);
+    s0 += lhn_apply_xf(a, xf);
+    s1 += lhn_apply_xf(b2, xf);
+    s2 += lhn_apply_xf(c2, xf);
+    s3 += lhn_apply_xf(d2, xf);
   }
-  red[threadIdx.x] = s;
+  for (; p < cnt; p += PL) s0 += lhn_apply_xf(at(p), xf);
+  f4 s = (s0 + s1) + (s2 + s3);
+  if (x.gate) s *= *reinterpret_cast<const f4*>(x.gate + (int64_t)n * x.cstride + ca);
+  // lanes of a wave that share c4 meet by xor-shuffles, the four waves through LDS
+  for (int o = C4; o < 64; o <<= 1) {
+    s.x += __shfl_xor(s.x, o, 64); s.y += __shfl_xor(s.y, o, 64); s.z += __shfl_xor(s.z, o, 64); s.w += __shfl_xor(s.w, o, 64);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (C4 <= 64 && lane < C4) red[wave * C4 + lane] = s;
+  if (C4 > 64) red[threadIdx.x] = s;
   __syncthreads();
   if (threadIdx.x < C4) {
     f4 t = (f4){0.f, 0.f, 0.f, 0.f};
-    for (int j = 0; j < PL; ++j) t += red[j * C4 + threadIdx.x];
+    if (C4 <= 64) {
+      for (int j = 0; j < 4; ++j) t += red[j * C4 + threadIdx.x];
+    } else {
+      for (int j = 0; j < PL; ++j) t += red[j * C4 + threadIdx.x];
+    }
     const float inv = 1.f / (float)cnt;
     *reinterpret_cast<f4*>(out + (int64_t)b * x.C + 4 * threadIdx.x) = t * inv;
   }

@@ -139,7 +139,7 @@ def main():
     refM, oraM = ref_models.get_model(cfgM), torch_ref.get_model(cfgM)
     assert sum(p.numel() for p in refM.parameters()) == 2240405
     assert list(refM.state_dict()) == list(oraM.state_dict())
-    _model_case(refM, oraM, 8, 64, 8, "M_64", out)
+    _model_case(refM, oraM, 8, 128, 8, "M_128", out)
     _model_case(refM, oraM, 4, 256, 9, "M_256", out)
     sd = synth.synth_state_dict(refM, 10)
     refM.load_state_dict(sd); oraM.load_state_dict(sd)

@@ -384,8 +384,8 @@ def test_mynet_contract(dev):
     assert sum(p.numel() for p in ours.parameters()) == 2240405       # test_models_performance.ipynb
 
 
-def test_model_M_64_golden(dev, golden_dir):
-    _model_case(dev, golden_dir, "M_64", variant="M")
+def test_model_M_128_golden(dev, golden_dir):
+    _model_case(dev, golden_dir, "M_128", variant="M")
 
 
 def test_model_M_256_golden(dev, golden_dir):

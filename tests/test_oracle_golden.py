@@ -64,9 +64,9 @@ def test_model_Bca_64(golden_dir):
     _run_case(golden_dir, "Bca_64", "B", rbu_ca="ca")
 
 
-def test_model_M_64(golden_dir):
+def test_model_M_128(golden_dir):
     """`mynet` (models/pose_hg_ms_att.py): oracle vs the reference-generated fixture; 2,240,405 parameters."""
-    _run_case(golden_dir, "M_64", "M")
+    _run_case(golden_dir, "M_128", "M")
     m = torch_ref.get_model(litehandnet_cfg("M"))
     assert sum(p.numel() for p in m.parameters()) == 2240405
     g = np.load(os.path.join(golden_dir, "model_M_64_eval.npz"))
