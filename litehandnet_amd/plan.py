@@ -399,6 +399,32 @@ class PlanBuilder:
             written = {}
             self._needs_zero_grad = set()
             body = []
+            # Gradient aliasing: a source of a plain (slope 1, same-size, whole-buffer) combine whose ONLY reader is
+            # that combine receives exactly d(out) -- its gradient buffer becomes an alias of the output's and the
+            # copy launch disappears (MSRB: the gated branch buffer of every residual add).
+            uses = {}
+            for r in self.recs:
+                for t in ([r["x"]] if r["op"] in (PW, DW, KXK, MAXPOOL, AVGPOOL) else r["srcs"] if r["op"] == EW else []):
+                    uses.setdefault(t.buf, []).append(r)
+            aliased = set()
+            for r in reversed(self.recs):
+                if r["op"] != EW or r["slope"] != 1.0:
+                    continue
+                out = r["out"]
+                ob = self.bufs[out.buf]
+                if out.coff != 0 or out.C != ob.C or ob.gate or ob.dpool:
+                    continue
+                for t in r["srcs"]:
+                    if t.buf < 0 or t.buf == out.buf or t.buf in aliased or len(uses.get(t.buf, ())) != 1:
+                        continue
+                    tb = self.bufs[t.buf]
+                    if (self.in_ref is not None and t.buf == self.in_ref.buf) or t.coff != 0 or t.C != tb.C:
+                        continue
+                    if (t.H, t.W) != (out.H, out.W) or sum(1 for q in r["srcs"] if q.buf == t.buf) != 1:
+                        continue
+                    tb.off["grad"] = ob.off["grad"]
+                    aliased.add(t.buf)
+            self.grad_aliases = len(aliased)
             for r in reversed(self.recs):
                 k = r["op"]
                 if k in (STEM, PW, DW, KXK):
@@ -428,7 +454,7 @@ class PlanBuilder:
                         body.append(mk(KXK_BWD, ins=(x,), out=out, p=(pw, pw), i=(r["stride"], 0, mode, 0, 0, use_coef)))
                 elif k == EW:
                     for s in r["srcs"]:
-                        if s.buf == self._no_grad_buf:
+                        if s.buf == self._no_grad_buf or (s.buf in aliased and self.bufs[s.buf].off["grad"] == self.bufs[r["out"].buf].off["grad"]):
                             continue
                         mode = self._grad_mode(written, s)
                         body.append(mk(EW_BWD, ins=(s,), out=r["out"], i=(1 if mode == 2 else 0,), f=(r["slope"],)))
