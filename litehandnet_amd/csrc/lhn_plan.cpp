@@ -1,6 +1,7 @@
 // Static plan executor: one call enqueues a whole forward or backward pass on a HIP stream.
 // The plan (buffers + op lists) is produced by the Python mirror of the reference's module tree;
 // this file only resolves offsets into the workspace arena / parameter array and calls the launchers.
+#include <stdint.h>
 #include <stdlib.h>
 #include <vector>
 #include "lhn_common.h"
@@ -15,9 +16,22 @@ enum {
   OP_MAXPOOL_BWD = 107, OP_AVGPOOL_BWD = 108, OP_GATE_REDUCE = 109, OP_CA_MLP_BWD = 110, OP_ATT_MLP_BWD = 111,
 };
 
+// One captured launch sequence (hipGraph) of a phase for one set of pointers.
+struct GraphEntry {
+  int phase, training, nrep, seen;
+  int64_t rstr;
+  void *ws, *io0, *io1;
+  uint64_t phash, ghash;
+  hipGraphExec_t exec;
+  uint64_t last_use;
+};
+
 struct Plan {
   std::vector<lhn_buf> bufs;
   std::vector<lhn_op> fwd, bwd;
+  std::vector<GraphEntry> graphs;      // LHN_GRAPH=1: replayed instead of ~150-400 individual launches
+  uint64_t tick = 0;
+  int graph_misses = 0;
 };
 
 static inline char* at(void* ws, int64_t off) { return off < 0 ? nullptr : static_cast<char*>(ws) + off; }
@@ -104,15 +118,16 @@ void* lhn_plan_create(const lhn_buf* bufs, int nbufs, const lhn_op* fwd, int nfw
   return p;
 }
 
-void lhn_plan_destroy(void* plan) { delete static_cast<Plan*>(plan); }
+void lhn_plan_destroy(void* plan) {
+  Plan* p = static_cast<Plan*>(plan);
+  if (!p) return;
+  for (GraphEntry& g : p->graphs)
+    if (g.exec) (void)hipGraphExecDestroy(g.exec);
+  delete p;
+}
 
-int lhn_plan_run(void* plan, int phase, void* ws, void* const* params, void* const* grads, void* const* io, int training,
-                 int grad_replicas, int64_t grad_rep_stride, void* stream) {
-  const int nrep = grad_replicas < 1 ? 1 : grad_replicas;
-  const int64_t rstr = grad_rep_stride;
-  LHN_CHECK_ARG(plan && ws && params && io, "lhn_plan_run: null argument");
-  LHN_CHECK_ARG(phase == 0 || (phase == 1 && grads), "lhn_plan_run: phase %d", phase);
-  const Plan* P = static_cast<const Plan*>(plan);
+static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void* const* grads, void* const* io, int training,
+                   int nrep, int64_t rstr, void* stream) {
   const std::vector<lhn_op>& ops = phase == 0 ? P->fwd : P->bwd;
   hipStream_t s = static_cast<hipStream_t>(stream);
   int rc = 0;
@@ -368,5 +383,102 @@ int lhn_plan_run(void* plan, int phase, void* ws, void* const* params, void* con
     }
   }
   return rc;
+}
+
+static bool graphs_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("LHN_GRAPH");
+    v = (e && e[0] == '1') ? 1 : 0;
+  }
+  return v == 1;
+}
+static uint64_t hash_ptrs(void* const* a, const std::vector<lhn_op>& ops, bool grads) {
+  // only the entries the ops reference (p[] indices) matter; FNV-1a over their values
+  uint64_t h = 1469598103934665603ull;
+  if (!a) return h;
+  for (const lhn_op& o : ops)
+    for (int k = 0; k < 12; ++k)
+      if (o.p[k] >= 0) {
+        h ^= reinterpret_cast<uint64_t>(a[o.p[k]]);
+        h *= 1099511628211ull;
+      }
+  (void)grads;
+  return h;
+}
+
+// Runs one phase.  With LHN_GRAPH=1 the launch sequence of a (phase, pointer set) is captured into a hipGraph the second
+// time it is seen and replayed afterwards (one graph launch instead of 150-400 kernel launches: the small-batch /
+// low-resolution end of the network is launch-bound).  The plan is static, so a graph is valid for as long as the
+// workspace, parameter, gradient and io pointers repeat; a different pointer set simply gets its own graph (LRU of 8),
+// and a plan whose pointers never repeat falls back to plain launches.
+int lhn_plan_run(void* plan, int phase, void* ws, void* const* params, void* const* grads, void* const* io, int training,
+                 int grad_replicas, int64_t grad_rep_stride, void* stream) {
+  const int nrep = grad_replicas < 1 ? 1 : grad_replicas;
+  const int64_t rstr = grad_rep_stride;
+  LHN_CHECK_ARG(plan && ws && params && io, "lhn_plan_run: null argument");
+  LHN_CHECK_ARG(phase == 0 || (phase == 1 && grads), "lhn_plan_run: phase %d", phase);
+  Plan* P = static_cast<Plan*>(plan);
+  // (the legacy default stream cannot be captured: graphs need the caller to run on a real stream)
+  if (!graphs_enabled() || stream == nullptr || P->graph_misses > 64) return run_ops(P, phase, ws, params, grads, io, training, nrep, rstr, stream);
+  const std::vector<lhn_op>& ops = phase == 0 ? P->fwd : P->bwd;
+  const uint64_t ph = hash_ptrs(params, ops, false), gh = phase == 1 ? hash_ptrs(grads, ops, true) : 0;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  GraphEntry* e = nullptr;
+  for (GraphEntry& g : P->graphs)
+    if (g.phase == phase && g.training == training && g.nrep == nrep && g.rstr == rstr && g.ws == ws && g.io0 == io[0] &&
+        g.io1 == io[1] && g.phash == ph && g.ghash == gh) {
+      e = &g;
+      break;
+    }
+  ++P->tick;
+  if (e && e->exec) {
+    e->last_use = P->tick;
+    if (hipGraphLaunch(e->exec, s) != hipSuccess) {
+      lhn_set_error("lhn_plan_run: hipGraphLaunch failed");
+      return 2;
+    }
+    return 0;
+  }
+  if (!e) {  // first sighting: run eagerly (also initialises every kernel's one-time attributes), remember the key
+    ++P->graph_misses;
+    if (P->graphs.size() >= 8) {
+      size_t victim = 0;
+      for (size_t i = 1; i < P->graphs.size(); ++i)
+        if (P->graphs[i].last_use < P->graphs[victim].last_use) victim = i;
+      if (P->graphs[victim].exec) (void)hipGraphExecDestroy(P->graphs[victim].exec);
+      P->graphs.erase(P->graphs.begin() + victim);
+    }
+    P->graphs.push_back(GraphEntry{phase, training, nrep, 1, rstr, ws, io[0], io[1], ph, gh, nullptr, P->tick});
+    return run_ops(P, phase, ws, params, grads, io, training, nrep, rstr, stream);
+  }
+  // second sighting: capture, instantiate, launch
+  e->last_use = P->tick;
+  hipGraph_t graph = nullptr;
+  if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) != hipSuccess)
+    return run_ops(P, phase, ws, params, grads, io, training, nrep, rstr, stream);
+  const int rc = run_ops(P, phase, ws, params, grads, io, training, nrep, rstr, stream);
+  const hipError_t ec = hipStreamEndCapture(s, &graph);
+  if (rc != 0 || ec != hipSuccess || !graph) {
+    if (graph) (void)hipGraphDestroy(graph);
+    (void)hipGetLastError();
+    P->graph_misses = 1000;     // capture is not possible here: stay on plain launches
+    return rc != 0 ? rc : run_ops(P, phase, ws, params, grads, io, training, nrep, rstr, stream);
+  }
+  hipGraphExec_t exec = nullptr;
+  const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (ei != hipSuccess || !exec) {
+    (void)hipGetLastError();
+    P->graph_misses = 1000;
+    return run_ops(P, phase, ws, params, grads, io, training, nrep, rstr, stream);
+  }
+  e->exec = exec;
+  P->graph_misses = 0;
+  if (hipGraphLaunch(exec, s) != hipSuccess) {
+    lhn_set_error("lhn_plan_run: hipGraphLaunch failed");
+    return 2;
+  }
+  return 0;
 }
 }  // extern "C"

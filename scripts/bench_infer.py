@@ -11,8 +11,11 @@ m = get_model(litehandnet_cfg(variant)).cuda().eval()
 x = torch.randn(bs, 3, 256, 256, device="cuda")
 
 
+side = torch.cuda.Stream()
+
+
 def timeit(tag):
-    with torch.no_grad():
+    with torch.no_grad(), torch.cuda.stream(side):
         for _ in range(5):
             m(x)
         torch.cuda.synchronize()

@@ -402,3 +402,23 @@ def test_model_M_eval_golden(dev, golden_dir):
     with torch.no_grad():
         y = m(synth.synth_images(2, 64, int(g["seed"])).to(dev))
     assert np.abs(y.cpu().numpy() - g["heatmap"]).max() <= FWD_TOL * np.abs(g["heatmap"]).max()
+
+
+def test_hipgraph_replay_matches_plain_launches(dev):
+    """LHN_GRAPH=1: lhn_plan_run captures the launch sequence into a hipGraph on its second sighting and replays it.
+    Five training iterations on a side stream must give bit-identical forward sums; gradient sums agree to fp32
+    atomics noise (weight-gradient replicas are combined by atomics in either mode)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for mode in ("0", "1"):
+        env = dict(os.environ, LHN_GRAPH=mode)
+        out = subprocess.run([sys.executable, os.path.join(root, "scripts", "check_graph.py")], env=env, capture_output=True,
+                             text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        line = [l for l in out.stdout.splitlines() if l.startswith("CHECK")][0]
+        res[mode] = [tuple(float(v) for v in t.split("/")) for t in line.split()[1:]]
+    for (y0, g0), (y1, g1) in zip(res["0"], res["1"]):
+        assert y0 == y1
+        assert abs(g0 - g1) <= 1e-5 * abs(g0)
