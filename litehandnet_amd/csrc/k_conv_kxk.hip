@@ -56,6 +56,7 @@ __global__ void __launch_bounds__(256) k_kxk(lhn_view x, const float* __restrict
   float* red = As + BM * LDA;         // [4][32*NT][2]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
   const int c4 = tid % C4, row0 = tid / C4;
+  const int n0 = blockIdx.y * 32 * NT;        // N split: this block's first output feature (small M: more blocks)
   const lhn_view& av = MODE == 0 ? x : y;
   const lhn_view& ov = MODE == 0 ? y : x;
   const int OW = ov.W, OHW = ov.H * ov.W;
@@ -138,10 +139,10 @@ __global__ void __launch_bounds__(256) k_kxk(lhn_view x, const float* __restrict
         float v = 0.f;
         if (MODE == 0 || TAPS > 1) {
           const int nn = i / KD, kk = i - nn * KD;
-          if (nn < nout) v = MODE == 0 ? w[((size_t)nn * cin_total + kk) * TAPS + tap] : w[((size_t)kk * cin_total + nn) * TAPS + tap];
+          if (n0 + nn < nout) v = MODE == 0 ? w[((size_t)(n0 + nn) * cin_total + kk) * TAPS + tap] : w[((size_t)kk * cin_total + n0 + nn) * TAPS + tap];
         } else {   // 1x1 dgrad: W[co = k][ci = n], coalesced along n
           const int kk = i / (32 * NT), nn = i - kk * (32 * NT);
-          if (nn < nout) v = w[(size_t)kk * cin_total + nn];
+          if (n0 + nn < nout) v = w[(size_t)kk * cin_total + n0 + nn];
         }
         t[j] = v;
       }
@@ -227,7 +228,7 @@ __global__ void __launch_bounds__(256) k_kxk(lhn_view x, const float* __restrict
     const int mbase = tile * BM + wave * 32 + 4 * lh;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      const int ch = j * 32 + l31;
+      const int ch = n0 + j * 32 + l31;
       if (ch >= nout) continue;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -258,7 +259,7 @@ __global__ void __launch_bounds__(256) k_kxk(lhn_view x, const float* __restrict
       }
     }
     __syncthreads();
-    if (tid < 32 * NT && tid < nout) {
+    if (tid < 32 * NT && n0 + tid < nout) {
       double s = 0, q = 0;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -266,8 +267,8 @@ __global__ void __launch_bounds__(256) k_kxk(lhn_view x, const float* __restrict
         q += (double)red[(k * 32 * NT + tid) * 2 + 1];
       }
       double* st = stats + (size_t)(blockIdx.x % LHN_STAT_REPLICAS) * 2 * nout;
-      atomicAdd(st + tid, s);
-      atomicAdd(st + nout + tid, q);
+      atomicAdd(st + n0 + tid, s);
+      atomicAdd(st + nout + n0 + tid, q);
     }
     if (fin.counter && lhn_last_block(fin.counter)) lhn_bn_finalize_block(fin, stats);
   }
@@ -382,7 +383,7 @@ __global__ void __launch_bounds__(256) k_kxk_wgrad(lhn_view x, lhn_view y, lhn_g
 
 template <int KD, int NT, int MODE, int TAPS, bool PLAIN = false>
 static int launch_kxk(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, double* stats, float* dx,
-                      int dx_acc, int stride, int nout, hipStream_t s, const lhn_bnfin* finp = nullptr) {
+                      int dx_acc, int stride, int nout, hipStream_t s, const lhn_bnfin* finp = nullptr, int nsplit = 1) {
   lhn_bnfin fin;
   if (finp && stats) fin = *finp; else fin.counter = nullptr;
   const lhn_view* ov = MODE == 0 ? y : x;
@@ -403,7 +404,7 @@ static int launch_kxk(const lhn_view* x, const float* w, const lhn_view* y, cons
   if (grid > ntiles) grid = ntiles;
   lhn_gradview g;
   if (gy) g = *gy; else g.dz = g.dpool = g.coef = nullptr;
-  hipLaunchKernelGGL((k_kxk<KD, NT, MODE, TAPS, PLAIN>), dim3(grid), dim3(256), lds, s, *x, w, *y, g, stats, dx, dx_acc, stride, nout, M, ntiles, fin);
+  hipLaunchKernelGGL((k_kxk<KD, NT, MODE, TAPS, PLAIN>), dim3(grid, nsplit), dim3(256), lds, s, *x, w, *y, g, stats, dx, dx_acc, stride, nout, M, ntiles, fin);
   return 0;
 }
 
@@ -436,14 +437,23 @@ static int kxk_geometry_ok(const lhn_view* x, const lhn_view* y, int stride) {
   return y->N == x->N && y->H == (x->H - 1) / stride + 1 && y->W == (x->W - 1) / stride + 1;
 }
 
+// Small maps give few 128-pixel tiles (8x8 maps at batch 64: 32 tiles for 256 CUs): split the N = 32*nt output features
+// over gridDim.y so that about two workgroups per CU exist.  Returns the per-block tile count (1, 2 or 4 -> nt / splits).
+static int kxk_nt_block(int M, int nt) {
+  const int ntiles = (M + 127) / 128;
+  int splits = 1;
+  while (splits < nt && nt % (splits * 2) == 0 && ntiles * splits < 2 * lhn_num_cus()) splits *= 2;
+  return nt / splits;
+}
+
 extern "C" int lhn_conv_kxk_fwd(const lhn_view* x, const float* w, const lhn_view* y, double* stats, int stride,
                                 const lhn_bnfin* fin, void* stream) {
   LHN_CHECK_ARG(lhn_view_ok(x) && lhn_view_ok(y) && w, "lhn_conv_kxk_fwd: bad view / null pointer");
   LHN_CHECK_ARG((stride == 1 || stride == 2) && kxk_geometry_ok(x, y, stride), "lhn_conv_kxk_fwd: geometry / stride %d", stride);
-  const int nt = (y->C + 31) / 32;
+  const int ntot = (y->C + 31) / 32, nt = (ntot == 1 || ntot == 2 || ntot == 4) ? kxk_nt_block(y->N * y->H * y->W, ntot) : ntot;
   hipStream_t s = (hipStream_t)stream;
   int rc = -1;
-#define KF(CI, NTV) if (x->C == CI && nt == NTV) rc = launch_kxk<CI, NTV, 0, 9>(x, w, y, nullptr, stats, nullptr, 0, stride, y->C, s, fin);
+#define KF(CI, NTV) if (x->C == CI && nt == NTV) rc = launch_kxk<CI, NTV, 0, 9>(x, w, y, nullptr, stats, nullptr, 0, stride, y->C, s, fin, ntot / nt);
   KF(32, 1) KF(64, 2) KF(128, 4) KF(32, 2) KF(64, 1) KF(64, 4) KF(128, 2) KF(128, 1) KF(32, 4)
 #undef KF
   LHN_CHECK_ARG(rc != -1, "lhn_conv_kxk_fwd: unsupported channels Cin=%d Cout=%d", x->C, y->C);
@@ -464,8 +474,9 @@ extern "C" int lhn_conv_kxk_bwd(const lhn_view* x, const float* w, const lhn_vie
   const bool plain = pe ? (pe[0] == '1') : ((x->C * y->C >= 64 * 64) || gy->dpool);
   if (plain) launch_dy_inplace(y, gy, s);
   if (dx) {
-    const int nt = (x->C + 31) / 32;   // GEMM N = Cin, K = Cout
-#define KB(CO, NTV) if (y->C == CO && nt == NTV) rc = plain ? launch_kxk<CO, NTV, 1, 9, true>(x, w, y, gy, nullptr, dx, dx_accumulate, stride, x->C, s) : launch_kxk<CO, NTV, 1, 9, false>(x, w, y, gy, nullptr, dx, dx_accumulate, stride, x->C, s);
+    // GEMM N = Cin, K = Cout
+    const int ntot = (x->C + 31) / 32, nt = (ntot == 1 || ntot == 2 || ntot == 4) ? kxk_nt_block(x->N * x->H * x->W, ntot) : ntot;
+#define KB(CO, NTV) if (y->C == CO && nt == NTV) rc = plain ? launch_kxk<CO, NTV, 1, 9, true>(x, w, y, gy, nullptr, dx, dx_accumulate, stride, x->C, s, nullptr, ntot / nt) : launch_kxk<CO, NTV, 1, 9, false>(x, w, y, gy, nullptr, dx, dx_accumulate, stride, x->C, s, nullptr, ntot / nt);
     KB(32, 1) KB(64, 2) KB(128, 4) KB(32, 2) KB(64, 1) KB(64, 4) KB(128, 2) KB(128, 1) KB(32, 4)
 #undef KB
     LHN_CHECK_ARG(rc != -1, "lhn_conv_kxk_bwd: unsupported channels Cin=%d Cout=%d", x->C, y->C);
