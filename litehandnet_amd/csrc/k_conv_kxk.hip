@@ -274,6 +274,9 @@ __global__ void __launch_bounds__(256) k_kxk(lhn_view x, const float* __restrict
   }
 }
 
+// wgrad: blockIdx.y = tap, blockIdx.z = group of 32*NTO output channels (co0).  When gridDim.x <= nrep every (pixel
+// chunk, tap, co group) owns a private slice of gradient replica blockIdx.x and the flush is a plain read-add-write: the
+// float atomics of the flush (gridDim.x * |dW| of them, ~38 G/s) were the whole cost of this kernel on small maps.
 // wgrad: blockIdx.y = tap.  64-pixel tiles; dYs[m][co], Xs[m][ci] (X shifted by the tap) -> dW_tap += dY^T X.
 template <int CIN, int NTO, int TAPS, bool PLAIN = false>
 __global__ void __launch_bounds__(256) k_kxk_wgrad(lhn_view x, lhn_view y, lhn_gradview gy, float* __restrict__ dw, int stride,
@@ -288,9 +291,10 @@ __global__ void __launch_bounds__(256) k_kxk_wgrad(lhn_view x, lhn_view y, lhn_g
   constexpr int XC4 = CIN / 4, XRP = 256 / XC4, XPF = 64 / XRP;
   constexpr int YC4 = COP / 4, YRP = 256 / YC4, YPF = 64 / YRP;
   const int xc4 = tid % XC4, xr0 = tid / XC4, xabs = x.coff + 4 * xc4;
-  const int yc4 = tid % YC4, yr0 = tid / YC4, yabs = y.coff + 4 * yc4;
+  const int co0 = blockIdx.z * COP;
+  const int yc4 = tid % YC4, yr0 = tid / YC4, yabs = y.coff + co0 + 4 * yc4;
   const Xf4 xxf = lhn_load_xf(x, xabs);
-  const bool ych_ok = 4 * yc4 < cout;
+  const bool ych_ok = co0 + 4 * yc4 < cout;
   const Xf4 yxf = lhn_load_xf(y, ych_ok ? yabs : y.coff);
   const Gr4 ygr = lhn_load_coef(gy, y.cstride, ych_ok ? yabs : y.coff);
   const int HoWo = y.H * y.W;
@@ -366,6 +370,7 @@ __global__ void __launch_bounds__(256) k_kxk_wgrad(lhn_view x, lhn_view y, lhn_g
     }
     __syncthreads();
   }
+  const bool exclusive = (int)gridDim.x <= nrep;
   dw += (size_t)(blockIdx.x % nrep) * rep_stride;
 #pragma unroll
   for (int t = 0; t < NDW; ++t) {
@@ -374,8 +379,12 @@ __global__ void __launch_bounds__(256) k_kxk_wgrad(lhn_view x, lhn_view y, lhn_g
       const int it = tl / NTI, jt = tl % NTI;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int co = 32 * it + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (co < cout) atomicAdd(dw + ((size_t)co * CIN + 32 * jt + l31) * TAPS + tap, accw[t][r]);
+        const int co = co0 + 32 * it + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (co < cout) {
+          float* o = dw + ((size_t)co * CIN + 32 * jt + l31) * TAPS + tap;
+          if (exclusive) *o += accw[t][r];
+          else atomicAdd(o, accw[t][r]);
+        }
       }
     }
   }
@@ -410,7 +419,7 @@ static int launch_kxk(const lhn_view* x, const float* w, const lhn_view* y, cons
 
 template <int CIN, int NTO, int TAPS, bool PLAIN = false>
 static int launch_kxk_wgrad(const lhn_view* x, const lhn_view* y, const lhn_gradview* gy, float* dw, int stride, int nrep,
-                            int64_t rep_stride, hipStream_t s) {
+                            int64_t rep_stride, hipStream_t s, int cosplit = 1) {
   const int M = y->N * y->H * y->W, ntiles = (M + 63) / 64;
   constexpr int COP = 32 * NTO;
   const size_t lds = (size_t)(64 * (COP + 4) + 64 * (CIN + 4)) * sizeof(float);
@@ -426,9 +435,10 @@ static int launch_kxk_wgrad(const lhn_view* x, const lhn_view* y, const lhn_grad
   static int per_cu = 0;
   if (!per_cu) per_cu = lhn_resident_per_cu(&k_kxk_wgrad<CIN, NTO, TAPS, PLAIN>, lds, 3);
   int grid = TAPS == 1 ? lhn_num_cus() * per_cu : lhn_num_cus() / 4;      // x 9 taps
+  if (cosplit > 1 && nrep > 1) grid = nrep;                               // exclusive replica slices: no atomics in the flush
   if (grid < 1) grid = 1;
   if (grid > ntiles) grid = ntiles;
-  hipLaunchKernelGGL((k_kxk_wgrad<CIN, NTO, TAPS, PLAIN>), dim3(grid, TAPS), dim3(256), lds, s, *x, *y, *gy, dw, stride, y->C, M, ntiles, nrep,
+  hipLaunchKernelGGL((k_kxk_wgrad<CIN, NTO, TAPS, PLAIN>), dim3(grid, TAPS, cosplit), dim3(256), lds, s, *x, *y, *gy, dw, stride, y->C, M, ntiles, nrep,
                      rep_stride);
   return 0;
 }
@@ -483,8 +493,9 @@ extern "C" int lhn_conv_kxk_bwd(const lhn_view* x, const float* w, const lhn_vie
     if (rc) return rc;
   }
   rc = -1;
-  const int nto = (y->C + 31) / 32;
-#define KW(CI, NTV) if (x->C == CI && nto == NTV) rc = plain ? launch_kxk_wgrad<CI, NTV, 9, true>(x, y, gy, dw, stride, nrep, rep_stride, s) : launch_kxk_wgrad<CI, NTV, 9, false>(x, y, gy, dw, stride, nrep, rep_stride, s);
+  // Cout >= 64: one 32-channel group per block (gridDim.z), pixel chunks = gradient replicas -> atomic-free flush
+  const int ntot = (y->C + 31) / 32, cosplit = (ntot == 2 || ntot == 4) && x->C >= 64 && nrep > 1 ? ntot : 1, nto = ntot / cosplit;
+#define KW(CI, NTV) if (x->C == CI && nto == NTV) rc = plain ? launch_kxk_wgrad<CI, NTV, 9, true>(x, y, gy, dw, stride, nrep, rep_stride, s, cosplit) : launch_kxk_wgrad<CI, NTV, 9, false>(x, y, gy, dw, stride, nrep, rep_stride, s, cosplit);
   KW(32, 1) KW(64, 2) KW(128, 4) KW(32, 2) KW(64, 1) KW(64, 4) KW(128, 2) KW(128, 1) KW(32, 4)
 #undef KW
   LHN_CHECK_ARG(rc != -1, "lhn_conv_kxk_bwd: unsupported channels Cin=%d Cout=%d", x->C, y->C);
