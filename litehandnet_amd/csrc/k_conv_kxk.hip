@@ -45,7 +45,7 @@ static void launch_dy_inplace(const lhn_view* y, const lhn_gradview* gy, hipStre
 template <int KD, int NT, int MODE, int TAPS, bool PLAIN = false>
 __global__ void __launch_bounds__(256) k_kxk(lhn_view x, const float* __restrict__ w, lhn_view y, lhn_gradview gy,
                                              double* __restrict__ stats, float* __restrict__ dx, int dx_acc, int stride,
-                                             int nout, int M, int ntiles, lhn_bnfin fin) {
+                                             int nout, int Mhost, int ntiles, lhn_bnfin fin) {
   constexpr int BM = 128, LDA = KD + 4;
   constexpr int C4 = KD / 4, RP = 256 / C4, PF = BM / RP;     // float4 per thread per phase
   constexpr int NW = 32 * NT * KD / 256;                      // weight scalars per thread per tap
@@ -59,7 +59,19 @@ __global__ void __launch_bounds__(256) k_kxk(lhn_view x, const float* __restrict
   const int n0 = blockIdx.y * 32 * NT;        // N split: this block's first output feature (small M: more blocks)
   const lhn_view& av = MODE == 0 ? x : y;
   const lhn_view& ov = MODE == 0 ? y : x;
-  const int OW = ov.W, OHW = ov.H * ov.W;
+  // Stride-2 dgrad by input-pixel PARITY (gridDim.z == 4): an input pixel (ih, iw) only meets the taps with
+  // kh = ih+1 (mod 2), kw = iw+1 (mod 2) -- 1, 2, 2 or 4 of the 9 -- so each parity class is its own small implicit GEMM
+  // over its quarter of the pixels and its own tap list (2.25 taps per pixel on average instead of 9, 3/4 of them zeros).
+  const bool par = (MODE == 1 && TAPS == 9 && gridDim.z == 4);
+  const int ph = par ? (int)(blockIdx.z >> 1) : 0, pw2 = par ? (int)(blockIdx.z & 1) : 0;
+  const int OH2 = par ? (ov.H - ph + 1) / 2 : ov.H, OW = par ? (ov.W - pw2 + 1) / 2 : ov.W, OHW = OH2 * OW;
+  const int M = par ? ov.N * OHW : Mhost;
+  const int nkw = (par && !pw2) ? 1 : (par ? 2 : 3), ntaps = par ? (ph ? 2 : 1) * nkw : TAPS;
+  auto tap_of = [&](int t) -> int {
+    if (!par) return t;
+    const int a = t / nkw, b = t - a * nkw;
+    return (ph ? 2 * a : 1) * 3 + (pw2 ? 2 * b : 1);
+  };
   const int cin_total = MODE == 0 ? KD : nout;
   const int cabs = av.coff + 4 * c4;
   const Xf4 xf = lhn_load_xf(av, cabs);
@@ -86,6 +98,10 @@ __global__ void __launch_bounds__(256) k_kxk(lhn_view x, const float* __restrict
         const int r = m - rn[p] * OHW;
         rh[p] = r / OW;
         rw[p] = r - rh[p] * OW;
+        if (par) {
+          rh[p] = 2 * rh[p] + ph;
+          rw[p] = 2 * rw[p] + pw2;
+        }
       } else {
         rn[p] = -1;
         rh[p] = rw[p] = 0;
@@ -183,9 +199,9 @@ __global__ void __launch_bounds__(256) k_kxk(lhn_view x, const float* __restrict
   int tile = blockIdx.x;
   if (tile < ntiles) {
     geom(tile);
-    issue(0);
-    stage_w(0);
-    commit(0);
+    issue(tap_of(0));
+    stage_w(tap_of(0));
+    commit(tap_of(0));
   }
   __syncthreads();
   for (; tile < ntiles; tile += gridDim.x) {
@@ -195,13 +211,13 @@ __global__ void __launch_bounds__(256) k_kxk(lhn_view x, const float* __restrict
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     const int next_tile = tile + gridDim.x;
-    for (int tap = 0; tap < TAPS; ++tap) {
-      const bool more = (tap + 1 < TAPS) || (next_tile < ntiles);
-      const int ntap = tap + 1 < TAPS ? tap + 1 : 0;
-      if (tap + 1 < TAPS) issue(tap + 1);
+    for (int ti = 0; ti < ntaps; ++ti) {
+      const bool more = (ti + 1 < ntaps) || (next_tile < ntiles);
+      const int ntap = tap_of(ti + 1 < ntaps ? ti + 1 : 0);
+      if (ti + 1 < ntaps) issue(ntap);
       else if (next_tile < ntiles) {
         geom(next_tile);
-        issue(0);
+        issue(ntap);
       }
       const float* arow = As + (wave * 32 + l31) * LDA + 4 * lh;
       const float* brow = Ws + l31 * LDA + 4 * lh;
@@ -240,7 +256,12 @@ __global__ void __launch_bounds__(256) k_kxk(lhn_view x, const float* __restrict
             ssum[j] += v;
             ssq[j] += v * v;
           } else {
-            float* o = dx + (size_t)m * x.cstride + x.coff + ch;
+            size_t pix = (size_t)m;
+            if (par) {
+              const int n = m / OHW, rr = m - n * OHW, i2 = rr / OW, j2 = rr - i2 * OW;
+              pix = ((size_t)n * x.H + 2 * i2 + ph) * x.W + 2 * j2 + pw2;
+            }
+            float* o = dx + pix * x.cstride + x.coff + ch;
             *o = dx_acc ? *o + v : v;
           }
         }
@@ -392,11 +413,11 @@ __global__ void __launch_bounds__(256) k_kxk_wgrad(lhn_view x, lhn_view y, lhn_g
 
 template <int KD, int NT, int MODE, int TAPS, bool PLAIN = false>
 static int launch_kxk(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, double* stats, float* dx,
-                      int dx_acc, int stride, int nout, hipStream_t s, const lhn_bnfin* finp = nullptr, int nsplit = 1) {
+                      int dx_acc, int stride, int nout, hipStream_t s, const lhn_bnfin* finp = nullptr, int nsplit = 1, int parity = 0) {
   lhn_bnfin fin;
   if (finp && stats) fin = *finp; else fin.counter = nullptr;
   const lhn_view* ov = MODE == 0 ? y : x;
-  const int M = ov->N * ov->H * ov->W, ntiles = (M + 127) / 128;
+  const int M = parity ? ov->N * ((ov->H + 1) / 2) * ((ov->W + 1) / 2) : ov->N * ov->H * ov->W, ntiles = (M + 127) / 128;
   const size_t lds = (size_t)((32 * NT + 128) * (KD + 4) + 4 * 32 * NT * 2) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
@@ -413,7 +434,7 @@ static int launch_kxk(const lhn_view* x, const float* w, const lhn_view* y, cons
   if (grid > ntiles) grid = ntiles;
   lhn_gradview g;
   if (gy) g = *gy; else g.dz = g.dpool = g.coef = nullptr;
-  hipLaunchKernelGGL((k_kxk<KD, NT, MODE, TAPS, PLAIN>), dim3(grid, nsplit), dim3(256), lds, s, *x, w, *y, g, stats, dx, dx_acc, stride, nout, M, ntiles, fin);
+  hipLaunchKernelGGL((k_kxk<KD, NT, MODE, TAPS, PLAIN>), dim3(grid, nsplit, parity ? 4 : 1), dim3(256), lds, s, *x, w, *y, g, stats, dx, dx_acc, stride, nout, M, ntiles, fin);
   return 0;
 }
 
@@ -485,8 +506,9 @@ extern "C" int lhn_conv_kxk_bwd(const lhn_view* x, const float* w, const lhn_vie
   if (plain) launch_dy_inplace(y, gy, s);
   if (dx) {
     // GEMM N = Cin, K = Cout
+    const int par = stride == 2 ? 1 : 0;     // stride 2: four parity classes of input pixels (gridDim.z)
     const int ntot = (x->C + 31) / 32, nt = (ntot == 1 || ntot == 2 || ntot == 4) ? kxk_nt_block(x->N * x->H * x->W, ntot) : ntot;
-#define KB(CO, NTV) if (y->C == CO && nt == NTV) rc = plain ? launch_kxk<CO, NTV, 1, 9, true>(x, w, y, gy, nullptr, dx, dx_accumulate, stride, x->C, s, nullptr, ntot / nt) : launch_kxk<CO, NTV, 1, 9, false>(x, w, y, gy, nullptr, dx, dx_accumulate, stride, x->C, s, nullptr, ntot / nt);
+#define KB(CO, NTV) if (y->C == CO && nt == NTV) rc = plain ? launch_kxk<CO, NTV, 1, 9, true>(x, w, y, gy, nullptr, dx, dx_accumulate, stride, x->C, s, nullptr, ntot / nt, par) : launch_kxk<CO, NTV, 1, 9, false>(x, w, y, gy, nullptr, dx, dx_accumulate, stride, x->C, s, nullptr, ntot / nt, par);
     KB(32, 1) KB(64, 2) KB(128, 4) KB(32, 2) KB(64, 1) KB(64, 4) KB(128, 2) KB(128, 1) KB(32, 4)
 #undef KB
     LHN_CHECK_ARG(rc != -1, "lhn_conv_kxk_bwd: unsupported channels Cin=%d Cout=%d", x->C, y->C);
@@ -494,7 +516,9 @@ extern "C" int lhn_conv_kxk_bwd(const lhn_view* x, const float* w, const lhn_vie
   }
   rc = -1;
   // Cout >= 64: one 32-channel group per block (gridDim.z), pixel chunks = gradient replicas -> atomic-free flush
-  const int ntot = (y->C + 31) / 32, cosplit = (ntot == 2 || ntot == 4) && x->C >= 64 && nrep > 1 ? ntot : 1, nto = ntot / cosplit;
+  // (only while a pixel chunk stays short: <= 64 tiles of 64 pixels per block; big maps amortise the atomic flush)
+  const int ntot = (y->C + 31) / 32, wtiles = (y->N * y->H * y->W + 63) / 64;
+  const int cosplit = (ntot == 2 || ntot == 4) && x->C >= 64 && nrep > 1 && wtiles <= 64 * nrep ? ntot : 1, nto = ntot / cosplit;
 #define KW(CI, NTV) if (x->C == CI && nto == NTV) rc = plain ? launch_kxk_wgrad<CI, NTV, 9, true>(x, y, gy, dw, stride, nrep, rep_stride, s, cosplit) : launch_kxk_wgrad<CI, NTV, 9, false>(x, y, gy, dw, stride, nrep, rep_stride, s, cosplit);
   KW(32, 1) KW(64, 2) KW(128, 4) KW(32, 2) KW(64, 1) KW(64, 4) KW(128, 2) KW(128, 1) KW(32, 4)
 #undef KW
