@@ -516,9 +516,9 @@ extern "C" int lhn_conv_kxk_bwd(const lhn_view* x, const float* w, const lhn_vie
   }
   rc = -1;
   // Cout >= 64: one 32-channel group per block (gridDim.z), pixel chunks = gradient replicas -> atomic-free flush
-  // (only while a pixel chunk stays short: <= 64 tiles of 64 pixels per block; big maps amortise the atomic flush)
+  // (only while a pixel chunk stays short: <= 16 tiles of 64 pixels per block; big maps amortise the atomic flush)
   const int ntot = (y->C + 31) / 32, wtiles = (y->N * y->H * y->W + 63) / 64;
-  const int cosplit = (ntot == 2 || ntot == 4) && x->C >= 64 && nrep > 1 && wtiles <= 64 * nrep ? ntot : 1, nto = ntot / cosplit;
+  const int cosplit = (ntot == 2 || ntot == 4) && x->C >= 64 && nrep > 1 && wtiles <= 16 * nrep ? ntot : 1, nto = ntot / cosplit;
 #define KW(CI, NTV) if (x->C == CI && nto == NTV) rc = plain ? launch_kxk_wgrad<CI, NTV, 9, true>(x, y, gy, dw, stride, nrep, rep_stride, s, cosplit) : launch_kxk_wgrad<CI, NTV, 9, false>(x, y, gy, dw, stride, nrep, rep_stride, s, cosplit);
   KW(32, 1) KW(64, 2) KW(128, 4) KW(32, 2) KW(64, 1) KW(64, 4) KW(128, 2) KW(128, 1) KW(32, 4)
 #undef KW
