@@ -422,3 +422,15 @@ def test_hipgraph_replay_matches_plain_launches(dev):
     for (y0, g0), (y1, g1) in zip(res["0"], res["1"]):
         assert y0 == y1
         assert abs(g0 - g1) <= 1e-5 * abs(g0)
+
+
+@pytest.mark.parametrize("variant", ["A", "B", "M"])
+def test_model_224_input(dev, variant):
+    """config/litehandnet/freihand/_1_freihand2d_224x224.py trains at 224x224 (56x56 heatmaps, 7x7 lowest level: odd maps,
+    ceil-mode pooling, widths below the LDS-tile minimum).  Forward + backward vs the float64 oracle, same bar as the blocks."""
+    from litehandnet_amd import get_model
+    cfg = litehandnet_cfg(variant, image_size=224)
+    cfg.MODEL["ca_dropout"] = 0.0
+    ours, ref = get_model(cfg), torch_ref.get_model(cfg, p_drop=0.0)
+    x = synth.synth_images(4, 224, 21)
+    _check_block(ours, ref, x, dev, seed=30, no_dx=True)
