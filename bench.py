@@ -67,6 +67,52 @@ def cpu_baseline(variant, budget_s=20.0):
             "sample": f"{n} steps of batch {bs} at 256x256 (fwd+loss+bwd+Adam), torch CPU fp32 oracle, {el:.1f}s"}
 
 
+def kernel_rooflines(B, dev):
+    """Per-kernel HBM rooflines of the two convolution kernels that carry most of the MSRB hourglass' algorithmic
+    bytes, at their 64x64 shapes, timed live with events around direct C-ABI launches (stream = torch's current)."""
+    import ctypes as C
+    from litehandnet_amd import _lib
+    from litehandnet_amd._lib import View
+    L, st = _lib.lib(), _lib.stream()
+
+    def view(t, table=None):
+        v = View()
+        v.data, v.table, v.gate = t.data_ptr(), (table.data_ptr() if table is not None else None), None
+        v.N, v.H, v.W, v.cstride, v.coff, v.C = t.shape[0], t.shape[1], t.shape[2], t.shape[3], 0, t.shape[3]
+        return v
+
+    def timed(fn, reps=30):
+        for _ in range(5):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e-3
+
+    x = torch.randn(B, 64, 64, 64, device=dev)
+    y = torch.empty_like(x)
+    tb = torch.ones(3, 64, device=dev)
+    stats = torch.zeros(32 * 2 * 64, dtype=torch.float64, device=dev)
+    w3 = torch.randn(64, 1, 3, 3, device=dev)
+    w1 = torch.randn(64, 64, device=dev)
+    vx, vy = view(x, tb), view(y)
+    nbytes = 2 * x.numel() * 4
+    out = []
+    for name, fn in (("k_dwk_fwd_lds<3,1> depthwise 3x3 + BN statistics, 64ch @64x64",
+                      lambda: L.lhn_conv_dw_fwd(C.byref(vx), _lib.ptr(w3), C.byref(vy), _lib.ptr(stats), 3, 1, 1, 1, None, st)),
+                     ("k_pw_fwd<64,2> 1x1 64->64 + BN statistics @64x64",
+                      lambda: L.lhn_conv_pw_fwd(C.byref(vx), _lib.ptr(w1), None, C.byref(vy), _lib.ptr(stats), 1, None, None, st))):
+        t = timed(fn)
+        out.append({"kernel": name, "bound": "hbm", "algorithmic_bytes": nbytes, "launch_us": round(t * 1e6, 2),
+                    "achieved": round(nbytes / t / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(nbytes / t / 1e9 / HBM_PEAK_GBS, 4)})
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -161,6 +207,7 @@ def main():
         "roofline_train_step": {"bound": "hbm", "achieved": round(train_alg / (step_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
                                 "unit": "GB/s", "frac": round(train_alg / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
         "forward_images_per_s": round(B / (fwd_ms * 1e-3), 1),
+        "roofline_kernels": kernel_rooflines(B, dev),
     }
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(args.variant)
