@@ -121,6 +121,7 @@ def main():
     ap.add_argument("--variant", default="B", choices=["A", "B", "M"])
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sync-bn", action="store_true", help="cfg.TRAIN.syncBN: SyncBatchNorm over the process group (N > 1)")
     ap.add_argument("--dropout", type=float, default=0.3, help="Dropout2d p inside channel attention (reference: 0.3)")
     args = ap.parse_args()
 
@@ -136,6 +137,10 @@ def main():
     cfg.MODEL["ca_dropout"] = args.dropout
     torch.manual_seed(0)                       # identical random init on every rank (then broadcast anyway)
     model = get_model(cfg).to(dev).train()
+    if args.sync_bn:
+        from litehandnet_amd.train import prepare_model
+        cfg.TRAIN["syncBN"] = True
+        model = prepare_model(model, cfg)
     crit = get_loss(cfg)
     trainer = Trainer(model, crit, lr=cfg.OPTIMIZER.lr, world_size=world)
 

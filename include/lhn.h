@@ -167,25 +167,31 @@ int lhn_ca_mlp_fwd(const float* pooled /*[N,9,C]*/, const float* w3 /*[C,1,3,3]*
                    const float* beta, float* rmean, float* rvar, int64_t* nbt, const float* w1 /*[C/2,C]*/,
                    const float* b1, const float* w2 /*[C,C/2]*/, const float* b2, const float* dropmask,
                    float* gate, int gate_stride, int gate_coff, float* save /*see DESIGN*/, int N, int C,
-                   float eps, float momentum, int training, void* stream);
+                   float eps, float momentum, int training, int stage, double* gsum, double count_scale,
+                   void* stream);
+/* SyncBatchNorm (train/spawn_dist.py:37-38) support in the attention kernels: stage 0 = the whole op; stage 1 = up to
+ * the local statistics sums, written to gsum[2][C] for the caller to all-reduce; stage 2 = the rest, with statistics
+ * over N*count_scale samples.  Backward: pgrad_scale (1/world) scales d(gamma), d(beta), which come from global sums. */
 
 /* attention of `mynet` (models/pose_hg_ms_att.py:165-174,191-192) on the pooled [N,9,C] tensor:
  * gate = sigmoid(Linear(dropout(dw3x3(relu(BN(pooled))) + b3))); save = floats[3*N*C + 2*C] */
 int lhn_att_mlp_fwd(const float* pooled, const float* gamma, const float* beta, float* rmean, float* rvar,
                     int64_t* nbt, const float* w3 /*[C,1,3,3]*/, const float* b3, const float* wl /*[C,C]*/,
                     const float* bl, const float* dropmask /*[N,C] or NULL*/, float* gate, int gate_stride,
-                    int gate_coff, float* save, int N, int C, float eps, float momentum, int training, void* stream);
+                    int gate_coff, float* save, int N, int C, float eps, float momentum, int training, int stage,
+                    double* gsum, double count_scale, void* stream);
 int lhn_att_mlp_bwd(const float* pooled, const float* gamma, const float* beta, const float* w3, const float* wl,
                     const float* dropmask, float* save, const float* dgate /*[N,C]*/, float* dpool, int cstride,
                     int coff, int H, int W, float* dgamma, float* dbeta, float* dw3, float* db3, float* dwl,
-                    float* dbl, int N, int C, void* stream);
+                    float* dbl, int N, int C, int stage, double* gsum, double count_scale, float pgrad_scale,
+                    void* stream);
 
 /* backward building blocks */
 int lhn_bn_bwd_reduce(const lhn_view* y, const lhn_gradview* g, const float* save_mean_invstd,
                       double* sums /*[R][2][C]: sum du, sum du*xhat*/, const lhn_bnbwdfin* fin /*or NULL*/, void* stream);
 int lhn_bn_bwd_finalize(const double* sums, const float* gamma, const float* save_mean_invstd,
                         float* coef, int cstride, int coff, int C, double count, float* dgamma, float* dbeta,
-                        void* stream);
+                        float pgrad_scale /*1, or 1/world under SyncBatchNorm*/, void* stream);
 int lhn_conv_pw_bwd(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy,
                     float* dx /*grad buffer of x, same geometry, or NULL*/, int dx_accumulate, float* dw,
                     float* dbias, int stride, const float* dy_nchw, int nrep, int64_t rep_stride, void* stream);
@@ -199,6 +205,12 @@ int lhn_conv_stem_bwd(const float* img, const lhn_view* y, const lhn_gradview* g
 int lhn_conv_kxk_bwd(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx,
                      int dx_accumulate, float* dw, int stride, int nrep, int64_t rep_stride, void* stream);
 /* out[i] = sum_r part[r*rep_stride + i]  (folds the replicated weight-gradient partials into the flat gradient) */
+/* SyncBatchNorm (train/spawn_dist.py:37-38): run half-steps [step_begin, step_end) of a phase -- step 2*i = main
+ * launches of op i, step 2*i+1 = the consumer of its statistics.  The caller all-reduces (SUM) the op's statistics
+ * buffer between the two; count_scale = world size, pgrad_scale = 1/world (for d(gamma), d(beta)). */
+int lhn_plan_run_range(void* plan, int phase, int64_t step_begin, int64_t step_end, void* workspace,
+                       void* const* params, void* const* grads, void* const* io, int training, int grad_replicas,
+                       int64_t grad_rep_stride, double count_scale, float pgrad_scale, void* stream);
 int lhn_reduce_replicas(float* out, const float* part, int64_t n, int nrep, int64_t rep_stride, void* stream);
 int lhn_ew_bwd(const lhn_view* srcs, int nsrc, const lhn_view* dst, const float* ddst, float out_slope,
                float* const* dsrcs, const int* accumulate, void* stream);
@@ -213,7 +225,8 @@ int lhn_gate_bwd_reduce(const lhn_view* y, const float* dz, float* dgate /*[N][C
 int lhn_ca_mlp_bwd(const float* pooled, const float* w3, const float* gamma, const float* w1, const float* w2,
                    const float* dropmask, const float* save, const float* dgate, float* dpool /*[N,9,cs]*/,
                    int cstride, int coff, int H, int W, float* dw3, float* dgamma, float* dbeta, float* dw1,
-                   float* db1, float* dw2, float* db2, int N, int C, void* stream);
+                   float* db1, float* dw2, float* db2, int N, int C, int stage, double* gsum, double count_scale,
+                   float pgrad_scale, void* stream);
 
 /* ---------------------------------------------------------------- plan executor
  * A plan is a static list of the calls above over one workspace arena, built by the Python

@@ -11,7 +11,8 @@ __global__ void __launch_bounds__(256) k_att1(const float* __restrict__ pooled, 
                                               float* __restrict__ rvar, int64_t* __restrict__ nbt,
                                               const float* __restrict__ w3, const float* __restrict__ b3,
                                               const float* __restrict__ mask, float* __restrict__ save, int N, int C, float eps,
-                                              float momentum, int training) {
+                                              float momentum, int training, int stage, double* __restrict__ gsum,
+                                              double count_scale) {
   __shared__ double rs[8][32], rq[8][32];
   __shared__ float s_mean[32], s_inv[32];
   float* ad = save;
@@ -20,7 +21,7 @@ __global__ void __launch_bounds__(256) k_att1(const float* __restrict__ pooled, 
   const int cl = threadIdx.x & 31, nl = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
   const bool ok = c < C;
   double s = 0, q = 0;
-  if (ok && training)
+  if (ok && training && stage != 2)
     for (int n = nl; n < N; n += 8)
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
@@ -32,13 +33,23 @@ __global__ void __launch_bounds__(256) k_att1(const float* __restrict__ pooled, 
   rq[nl][cl] = q;
   __syncthreads();
   if (nl == 0 && ok) {
+    for (int j = 1; j < 8; ++j) {
+      s += rs[j][cl];
+      q += rq[j][cl];
+    }
+    if (stage == 1) {
+      gsum[c] = s;
+      gsum[C + c] = q;
+    } else if (stage == 2) {
+      s = gsum[c];
+      q = gsum[C + c];
+    }
+  }
+  if (stage == 1) return;
+  if (nl == 0 && ok) {
     double mean, var;
     if (training) {
-      for (int j = 1; j < 8; ++j) {
-        s += rs[j][cl];
-        q += rq[j][cl];
-      }
-      const double cnt = 9.0 * N;
+      const double cnt = 9.0 * N * count_scale;
       mean = s / cnt;
       var = q / cnt - mean * mean;
       if (var < 0) var = 0;
@@ -123,7 +134,8 @@ __global__ void __launch_bounds__(256) k_att_bwd1(const float* __restrict__ pool
                                                   const float* __restrict__ dad, float* __restrict__ dpool, int cs, int coff,
                                                   int H, int W, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                   float* __restrict__ dw3, float* __restrict__ db3, int N, int C,
-                                                  int training) {
+                                                  int training, int stage, double* __restrict__ gsum, double count_scale,
+                                                  float pgrad_scale) {
   __shared__ double rs[8][32], rq[8][32];
   __shared__ float rw[8][32][10];
   const float* smean = save + (int64_t)N * C * 2;
@@ -169,9 +181,8 @@ __global__ void __launch_bounds__(256) k_att_bwd1(const float* __restrict__ pool
     sd += rs[j][cl];
     sdx += rq[j][cl];
   }
-  if (nl == 0 && ok) {
-    dgamma[c] += (float)sdx;
-    dbeta[c] += (float)sd;
+  // stage 1 (SyncBatchNorm) stops after the local sums; the local parameter gradients of the conv are final already
+  if (nl == 0 && ok && stage != 2) {
     for (int t = 0; t < 10; ++t) {
       float v = 0.f;
       for (int j = 0; j < 8; ++j) v += rw[j][cl][t];
@@ -179,8 +190,23 @@ __global__ void __launch_bounds__(256) k_att_bwd1(const float* __restrict__ pool
       else if (db3) db3[c] += v;
     }
   }
+  if (stage == 1) {
+    if (nl == 0 && ok) {
+      gsum[c] = sd;
+      gsum[C + c] = sdx;
+    }
+    return;
+  }
+  if (stage == 2 && ok) {
+    sd = gsum[c];
+    sdx = gsum[C + c];
+  }
+  if (nl == 0 && ok) {
+    dgamma[c] += (float)sdx * pgrad_scale;
+    dbeta[c] += (float)sd * pgrad_scale;
+  }
   if (ok) {
-    const double cnt = 9.0 * N;
+    const double cnt = 9.0 * N * count_scale;
     const float m1 = (float)(sd / cnt), m2 = (float)(sdx / cnt);
     for (int n = nl; n < N; n += 8) {
       float da = dad[(int64_t)n * C + c];
@@ -202,13 +228,14 @@ __global__ void __launch_bounds__(256) k_att_bwd1(const float* __restrict__ pool
 extern "C" int lhn_att_mlp_fwd(const float* pooled, const float* gamma, const float* beta, float* rmean, float* rvar, int64_t* nbt,
                                const float* w3, const float* b3, const float* wl, const float* bl, const float* dropmask,
                                float* gate, int gate_stride, int gate_coff, float* save, int N, int C, float eps, float momentum,
-                               int training, void* stream) {
+                               int training, int stage, double* gsum, double count_scale, void* stream) {
   LHN_CHECK_ARG(pooled && gamma && beta && rmean && rvar && w3 && wl && bl && gate && save, "lhn_att_mlp_fwd: null pointer");
   LHN_CHECK_ARG(C > 0 && C <= 256 && N > 0, "lhn_att_mlp_fwd: C=%d (<=256)", C);
   hipStream_t s = (hipStream_t)stream;
+  LHN_CHECK_ARG(stage == 0 || (gsum && stage >= 1 && stage <= 2 && count_scale >= 1), "lhn_att_mlp_fwd: stage %d needs gsum", stage);
   hipLaunchKernelGGL(k_att1, dim3((C + 31) / 32), dim3(256), 0, s, pooled, gamma, beta, rmean, rvar, nbt, w3, b3, dropmask, save, N,
-                     C, eps, momentum, training);
-  hipLaunchKernelGGL(k_att2, dim3(N), dim3(128), 0, s, wl, bl, save, gate, gate_stride, gate_coff, N, C);
+                     C, eps, momentum, training, stage, gsum, stage ? count_scale : 1.0);
+  if (stage != 1) hipLaunchKernelGGL(k_att2, dim3(N), dim3(128), 0, s, wl, bl, save, gate, gate_stride, gate_coff, N, C);
   LHN_CHECK_LAUNCH("lhn_att_mlp_fwd");
   return 0;
 }
@@ -216,15 +243,16 @@ extern "C" int lhn_att_mlp_fwd(const float* pooled, const float* gamma, const fl
 extern "C" int lhn_att_mlp_bwd(const float* pooled, const float* gamma, const float* beta, const float* w3, const float* wl,
                                const float* dropmask, float* save, const float* dgate, float* dpool, int cstride, int coff, int H,
                                int W, float* dgamma, float* dbeta, float* dw3, float* db3, float* dwl, float* dbl, int N, int C,
-                               void* stream) {
+                               int stage, double* gsum, double count_scale, float pgrad_scale, void* stream) {
   LHN_CHECK_ARG(pooled && gamma && beta && w3 && wl && save && dgate && dpool && dgamma && dbeta && dw3 && dwl && dbl,
                 "lhn_att_mlp_bwd: null pointer");
   LHN_CHECK_ARG(C > 0 && C <= 256 && N > 0, "lhn_att_mlp_bwd: C=%d (<=256)", C);
   hipStream_t s = (hipStream_t)stream;
   float* dad = save + (int64_t)N * C * 2 + 2 * C;
-  hipLaunchKernelGGL(k_att_bwd2, dim3(N), dim3(256), 0, s, wl, save, dgate, dad, dwl, dbl, N, C);
+  LHN_CHECK_ARG(stage == 0 || (gsum && stage >= 1 && stage <= 2 && count_scale >= 1), "lhn_att_mlp_bwd: stage %d needs gsum", stage);
+  if (stage != 2) hipLaunchKernelGGL(k_att_bwd2, dim3(N), dim3(256), 0, s, wl, save, dgate, dad, dwl, dbl, N, C);
   hipLaunchKernelGGL(k_att_bwd1, dim3((C + 31) / 32), dim3(256), 0, s, pooled, gamma, beta, w3, dropmask, save, dad, dpool, cstride,
-                     coff, H, W, dgamma, dbeta, dw3, db3, N, C, 1);
+                     coff, H, W, dgamma, dbeta, dw3, db3, N, C, 1, stage, gsum, stage ? count_scale : 1.0, stage ? pgrad_scale : 1.f);
   LHN_CHECK_LAUNCH("lhn_att_mlp_bwd");
   return 0;
 }

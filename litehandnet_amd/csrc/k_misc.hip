@@ -324,7 +324,10 @@ __global__ void __launch_bounds__(256) k_ca1(const float* __restrict__ pooled, c
                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                              float* __restrict__ rmean, float* __restrict__ rvar, int64_t* __restrict__ nbt,
                                              const float* __restrict__ mask, float* __restrict__ save, int N, int C,
-                                             float eps, float momentum, int training) {
+                                             float eps, float momentum, int training, int stage, double* __restrict__ gsum,
+                                             double count_scale) {
+  // stage 0: everything; SyncBatchNorm splits the kernel around an all-reduce of gsum[2][C] (stage 1: conv + local sums,
+  // stage 2: statistics over N*count_scale samples + normalisation)
   __shared__ double rs[8][32], rq[8][32];
   __shared__ float s_sc[32], s_sh[32];
   float* a = save;
@@ -337,7 +340,7 @@ __global__ void __launch_bounds__(256) k_ca1(const float* __restrict__ pooled, c
 #pragma unroll
   for (int t = 0; t < 9; ++t) wt[t] = ok ? w3[c * 9 + t] : 0.f;
   double s = 0, q = 0;
-  if (ok)
+  if (ok && stage != 2)
     for (int n = nl; n < N; n += 8) {
       float v = 0.f;
 #pragma unroll
@@ -354,6 +357,17 @@ __global__ void __launch_bounds__(256) k_ca1(const float* __restrict__ pooled, c
       s += rs[j][cl];
       q += rq[j][cl];
     }
+    if (stage == 1) {
+      gsum[c] = s;
+      gsum[C + c] = q;
+    } else if (stage == 2) {
+      s = gsum[c];
+      q = gsum[C + c];
+    }
+  }
+  if (stage == 1) return;
+  const double NT = (double)N * count_scale;
+  if (nl == 0 && ok) {
     double mean, var;
     if (!gamma) {          // deployed attention (common.py:68-90): the BatchNorm is folded, `beta` is the conv bias
       smean[c] = 0.f;
@@ -362,11 +376,11 @@ __global__ void __launch_bounds__(256) k_ca1(const float* __restrict__ pooled, c
       s_sh[cl] = beta ? beta[c] : 0.f;
     } else {
     if (training) {
-      mean = s / N;
-      var = q / N - mean * mean;
+      mean = s / NT;
+      var = q / NT - mean * mean;
       if (var < 0) var = 0;
       rmean[c] = (float)((1.0 - (double)momentum) * rmean[c] + (double)momentum * mean);
-      rvar[c] = (float)((1.0 - (double)momentum) * rvar[c] + (double)momentum * (N > 1 ? var * N / (N - 1.0) : var));
+      rvar[c] = (float)((1.0 - (double)momentum) * rvar[c] + (double)momentum * (NT > 1 ? var * NT / (NT - 1.0) : var));
     } else {
       mean = rmean[c];
       var = rvar[c];
@@ -490,7 +504,9 @@ __global__ void __launch_bounds__(256) k_ca_bwd1(const float* __restrict__ poole
                                                  const float* __restrict__ save, const float* __restrict__ dahat,
                                                  float* __restrict__ dpool, int cs, int coff, int H, int W,
                                                  float* __restrict__ dw3, float* __restrict__ dgamma,
-                                                 float* __restrict__ dbeta, int N, int C, int training) {
+                                                 float* __restrict__ dbeta, int N, int C, int training, int stage,
+                                                 double* __restrict__ gsum, double count_scale, float pgrad_scale) {
+  // stage 0: everything; SyncBatchNorm: stage 1 = local (sum d, sum d*xhat) -> gsum[2][C], all-reduce, stage 2 = the rest
   __shared__ double rs[8][32], rq[8][32];
   __shared__ float rw[8][32][9];
   const float* a = save;
@@ -500,7 +516,7 @@ __global__ void __launch_bounds__(256) k_ca_bwd1(const float* __restrict__ poole
   const bool ok = c < C;
   const float mean = ok ? smean[c] : 0.f, invstd = ok ? sinv[c] : 0.f, gm = ok ? gamma[c] : 0.f;
   double sd = 0, sdx = 0;
-  if (ok)
+  if (ok && stage != 2)
     for (int n = nl; n < N; n += 8) {
       float d = dahat[(int64_t)n * C + c];
       if (mask) d *= mask[(int64_t)n * C + c];
@@ -517,9 +533,21 @@ __global__ void __launch_bounds__(256) k_ca_bwd1(const float* __restrict__ poole
     sd += rs[j][cl];
     sdx += rq[j][cl];
   }
+  if (stage == 1) {
+    if (nl == 0 && ok) {
+      gsum[c] = sd;
+      gsum[C + c] = sdx;
+    }
+    return;
+  }
+  if (stage == 2 && ok) {
+    sd = gsum[c];
+    sdx = gsum[C + c];
+  }
+  const double NT = (double)N * count_scale;
   if (nl == 0 && ok) {
-    dgamma[c] += (float)sdx;
-    dbeta[c] += (float)sd;
+    dgamma[c] += (float)sdx * pgrad_scale;
+    dbeta[c] += (float)sd * pgrad_scale;
   }
   float wt[9], dwt[9], binv[9];
 #pragma unroll
@@ -535,7 +563,7 @@ __global__ void __launch_bounds__(256) k_ca_bwd1(const float* __restrict__ poole
       if (mask) d *= mask[(int64_t)n * C + c];
       const float xh = (a[(int64_t)n * C + c] - mean) * invstd;
       float da = gm * invstd * d;
-      if (training) da = gm * invstd * (d - (float)(sd / N) - xh * (float)(sdx / N));
+      if (training) da = gm * invstd * (d - (float)(sd / NT) - xh * (float)(sdx / NT));
       float dseg[9];
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
@@ -611,7 +639,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_reduce(lhn_view y, lhn_gradview 
 // dy = A*du + B*y + C with  A = s, B = -s*invstd*dgamma/n, C = -s*dbeta/n + s*invstd*mean*dgamma/n, s = gamma*invstd
 __global__ void k_bn_bwd_finalize(const double* __restrict__ sums, const float* __restrict__ gamma,
                                   const float* __restrict__ save, float* __restrict__ coef, int cs, int coff, int C,
-                                  double count, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                  double count, float* __restrict__ dgamma, float* __restrict__ dbeta, float pgrad_scale) {
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     double db = 0, dg = 0;
     for (int r = 0; r < LHN_STAT_REPLICAS; ++r) {
@@ -622,8 +650,8 @@ __global__ void k_bn_bwd_finalize(const double* __restrict__ sums, const float* 
     coef[coff + c] = (float)s;
     coef[cs + coff + c] = (float)(-s * inv * dg / count);
     coef[2 * cs + coff + c] = (float)(-s * db / count + s * inv * mean * dg / count);
-    if (dgamma) dgamma[c] += (float)dg;
-    if (dbeta) dbeta[c] += (float)db;
+    if (dgamma) dgamma[c] += (float)dg * pgrad_scale;
+    if (dbeta) dbeta[c] += (float)db * pgrad_scale;
   }
 }
 
@@ -751,13 +779,14 @@ int lhn_avgpool_bwd(const lhn_view* x, const float* dout, int OH, int OW, float*
 int lhn_ca_mlp_fwd(const float* pooled, const float* w3, const float* gamma, const float* beta, float* rmean, float* rvar,
                    int64_t* nbt, const float* w1, const float* b1, const float* w2, const float* b2, const float* dropmask,
                    float* gate, int gate_stride, int gate_coff, float* save, int N, int C, float eps, float momentum,
-                   int training, void* stream) {
+                   int training, int stage, double* gsum, double count_scale, void* stream) {
   LHN_CHECK_ARG(pooled && w3 && w1 && b1 && w2 && b2 && gate && save, "lhn_ca_mlp_fwd: null pointer");
   LHN_CHECK_ARG(gamma ? (beta && rmean && rvar) : !training, "lhn_ca_mlp_fwd: BatchNorm tensors missing (gamma NULL = deployed form, eval only)");
   LHN_CHECK_ARG(C > 0 && C <= 256 && C % 2 == 0 && N > 0, "lhn_ca_mlp_fwd: C=%d (<=256)", C);
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_ca1, dim3((C + 31) / 32), dim3(256), 0, s, pooled, w3, gamma, beta, rmean, rvar, nbt, dropmask, save, N, C, eps, momentum, training);
-  hipLaunchKernelGGL(k_ca2, dim3(N), dim3(128), 0, s, w1, b1, w2, b2, save, gate, gate_stride, gate_coff, N, C);
+  LHN_CHECK_ARG(stage == 0 || (gsum && stage >= 1 && stage <= 2 && count_scale >= 1), "lhn_ca_mlp_fwd: stage %d needs gsum", stage);
+  hipLaunchKernelGGL(k_ca1, dim3((C + 31) / 32), dim3(256), 0, s, pooled, w3, gamma, beta, rmean, rvar, nbt, dropmask, save, N, C, eps, momentum, training, stage, gsum, stage ? count_scale : 1.0);
+  if (stage != 1) hipLaunchKernelGGL(k_ca2, dim3(N), dim3(128), 0, s, w1, b1, w2, b2, save, gate, gate_stride, gate_coff, N, C);
   LHN_CHECK_LAUNCH("lhn_ca_mlp_fwd");
   return 0;
 }
@@ -782,14 +811,15 @@ int lhn_gate_bwd_reduce(const lhn_view* y, const float* dz, float* dgate, void* 
 int lhn_ca_mlp_bwd(const float* pooled, const float* w3, const float* gamma, const float* w1, const float* w2,
                    const float* dropmask, const float* save, const float* dgate, float* dpool, int cstride, int coff, int H,
                    int W, float* dw3, float* dgamma, float* dbeta, float* dw1, float* db1, float* dw2, float* db2, int N,
-                   int C, void* stream) {
+                   int C, int stage, double* gsum, double count_scale, float pgrad_scale, void* stream) {
   LHN_CHECK_ARG(pooled && w3 && gamma && w1 && w2 && save && dgate && dpool && dw3 && dgamma && dbeta && dw1 && db1 && dw2 && db2,
                 "lhn_ca_mlp_bwd: null pointer");
   LHN_CHECK_ARG(C > 0 && C <= 256 && C % 2 == 0, "lhn_ca_mlp_bwd: C=%d", C);
   hipStream_t s = (hipStream_t)stream;
   float* dahat = const_cast<float*>(save) + (int64_t)N * C * 3 + (int64_t)N * (C / 2) + 2 * C;
-  hipLaunchKernelGGL(k_ca_bwd2, dim3(N), dim3(256), 0, s, w1, w2, save, dgate, dahat, dw1, db1, dw2, db2, N, C);
-  hipLaunchKernelGGL(k_ca_bwd1, dim3((C + 31) / 32), dim3(256), 0, s, pooled, w3, gamma, dropmask, save, dahat, dpool, cstride, coff, H, W, dw3, dgamma, dbeta, N, C, 1);
+  LHN_CHECK_ARG(stage == 0 || (gsum && stage >= 1 && stage <= 2 && count_scale >= 1), "lhn_ca_mlp_bwd: stage %d needs gsum", stage);
+  if (stage != 2) hipLaunchKernelGGL(k_ca_bwd2, dim3(N), dim3(256), 0, s, w1, w2, save, dgate, dahat, dw1, db1, dw2, db2, N, C);
+  hipLaunchKernelGGL(k_ca_bwd1, dim3((C + 31) / 32), dim3(256), 0, s, pooled, w3, gamma, dropmask, save, dahat, dpool, cstride, coff, H, W, dw3, dgamma, dbeta, N, C, 1, stage, gsum, stage ? count_scale : 1.0, stage ? pgrad_scale : 1.f);
   LHN_CHECK_LAUNCH("lhn_ca_mlp_bwd");
   return 0;
 }
@@ -804,9 +834,9 @@ int lhn_bn_bwd_reduce(const lhn_view* y, const lhn_gradview* g, const float* sav
   return 0;
 }
 int lhn_bn_bwd_finalize(const double* sums, const float* gamma, const float* save, float* coef, int cstride, int coff, int C,
-                        double count, float* dgamma, float* dbeta, void* stream) {
+                        double count, float* dgamma, float* dbeta, float pgrad_scale, void* stream) {
   LHN_CHECK_ARG(sums && save && coef && C > 0 && coff + C <= cstride, "lhn_bn_bwd_finalize: bad args");
-  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(1), dim3(C <= 64 ? 64 : (C <= 128 ? 128 : 256)), 0, (hipStream_t)stream, sums, gamma, save, coef, cstride, coff, C, count, dgamma, dbeta);
+  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(1), dim3(C <= 64 ? 64 : (C <= 128 ? 128 : 256)), 0, (hipStream_t)stream, sums, gamma, save, coef, cstride, coff, C, count, dgamma, dbeta, pgrad_scale);
   LHN_CHECK_LAUNCH("lhn_bn_bwd_finalize");
   return 0;
 }

@@ -126,13 +126,25 @@ void lhn_plan_destroy(void* plan) {
   delete p;
 }
 
+// Ops are numbered in HALF-steps: step 2*i = the op's main launches, step 2*i+1 = its statistics consumer (BatchNorm
+// finalize, second half of an attention op).  SyncBatchNorm runs [.., 2*i] / all-reduce / [2*i+1, ..]; a plain run is
+// the whole range.  count_scale = world size (statistics are over N*world samples), pgrad_scale = 1/world for the
+// d(gamma), d(beta) that come out of globally reduced sums.
 static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void* const* grads, void* const* io, int training,
-                   int nrep, int64_t rstr, void* stream) {
+                   int nrep, int64_t rstr, void* stream, size_t sb = 0, size_t se = (size_t)-1, double cscale = 1.0,
+                   float pscale = 1.f) {
   const std::vector<lhn_op>& ops = phase == 0 ? P->fwd : P->bwd;
   hipStream_t s = static_cast<hipStream_t>(stream);
   int rc = 0;
+  const bool whole = (sb == 0 && se >= 2 * ops.size());
   for (size_t oi = 0; oi < ops.size() && rc == 0; ++oi) {
     const lhn_op& o = ops[oi];
+    const bool h0 = 2 * oi >= sb && 2 * oi < se, h1 = 2 * oi + 1 >= sb && 2 * oi + 1 < se;
+    if (!h0 && !h1) continue;
+    const bool two_half = o.kind == OP_STEM || o.kind == OP_PW || o.kind == OP_DW || o.kind == OP_KXK || o.kind == OP_CA_MLP ||
+                          o.kind == OP_ATT_MLP || o.kind == OP_BN_BWD || o.kind == OP_CA_MLP_BWD || o.kind == OP_ATT_MLP_BWD;
+    if (!two_half && !h0) continue;
+    const int stage = (h0 && h1) ? 0 : (h0 ? 1 : 2);
     switch (o.kind) {
       case OP_MEMSET: {
         if (hipMemsetAsync(at(ws, o.ws[0]), 0, (size_t)o.ws[1], s) != hipSuccess) {
@@ -153,11 +165,14 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
         lhn_view y = mkview(P, ws, o.out_buf, o.out_coff, o.out_C);
         const bool bn = conv_has_bn(o);
         lhn_bnfin fin;
-        if (bn) fin = mkfin(P, ws, o, params);
-        rc = lhn_conv_stem_fwd(static_cast<const float*>(io[0]), prm<const float>(params, o.p[0]), &y,
+        if (bn) {
+          fin = mkfin(P, ws, o, params);
+          fin.count *= cscale;
+        }
+        if (h0) rc = lhn_conv_stem_fwd(static_cast<const float*>(io[0]), prm<const float>(params, o.p[0]), &y,
                                (training && o.ws[0] >= 0) ? reinterpret_cast<double*>(at(ws, o.ws[0])) : nullptr, o.i[3], o.i[4], o.i[0], o.i[1],
-                               o.i[2], (bn && training && fuse_finalize()) ? &fin : nullptr, stream);
-        if (!rc && bn && !(training && fuse_finalize())) rc = sep_finalize(fin, reinterpret_cast<const double*>(at(ws, o.ws[0])), training, stream);
+                               o.i[2], (bn && training && fuse_finalize() && whole) ? &fin : nullptr, stream);
+        if (!rc && bn && h1 && !(training && fuse_finalize() && whole)) rc = sep_finalize(fin, reinterpret_cast<const double*>(at(ws, o.ws[0])), training, stream);
         break;
       }
       case OP_PW: {
@@ -174,11 +189,14 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
         }
         const bool bn = !o.i[1] && conv_has_bn(o);
         lhn_bnfin fin;
-        if (bn) fin = mkfin(P, ws, o, params);
-        rc = lhn_conv_pw_fwd(&x, prm<const float>(params, o.p[0]), bn ? nullptr : prm<const float>(params, o.p[1]), &y,
+        if (bn) {
+          fin = mkfin(P, ws, o, params);
+          fin.count *= cscale;
+        }
+        if (h0) rc = lhn_conv_pw_fwd(&x, prm<const float>(params, o.p[0]), bn ? nullptr : prm<const float>(params, o.p[1]), &y,
                              (training && o.ws[0] >= 0) ? reinterpret_cast<double*>(at(ws, o.ws[0])) : nullptr, o.i[0], nchw,
-                             (bn && training && fuse_finalize()) ? &fin : nullptr, stream);
-        if (!rc && bn && !(training && fuse_finalize())) rc = sep_finalize(fin, reinterpret_cast<const double*>(at(ws, o.ws[0])), training, stream);
+                             (bn && training && fuse_finalize() && whole) ? &fin : nullptr, stream);
+        if (!rc && bn && h1 && !(training && fuse_finalize() && whole)) rc = sep_finalize(fin, reinterpret_cast<const double*>(at(ws, o.ws[0])), training, stream);
         break;
       }
       case OP_DW: {
@@ -186,11 +204,14 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
         lhn_view y = mkview(P, ws, o.out_buf, o.out_coff, o.out_C);
         const bool bn = conv_has_bn(o);
         lhn_bnfin fin;
-        if (bn) fin = mkfin(P, ws, o, params);
-        rc = lhn_conv_dw_fwd(&x, prm<const float>(params, o.p[0]), &y,
+        if (bn) {
+          fin = mkfin(P, ws, o, params);
+          fin.count *= cscale;
+        }
+        if (h0) rc = lhn_conv_dw_fwd(&x, prm<const float>(params, o.p[0]), &y,
                              (training && o.ws[0] >= 0) ? reinterpret_cast<double*>(at(ws, o.ws[0])) : nullptr, o.i[0], o.i[1], o.i[2], o.i[3],
-                             (bn && training && fuse_finalize()) ? &fin : nullptr, stream);
-        if (!rc && bn && !(training && fuse_finalize())) rc = sep_finalize(fin, reinterpret_cast<const double*>(at(ws, o.ws[0])), training, stream);
+                             (bn && training && fuse_finalize() && whole) ? &fin : nullptr, stream);
+        if (!rc && bn && h1 && !(training && fuse_finalize() && whole)) rc = sep_finalize(fin, reinterpret_cast<const double*>(at(ws, o.ws[0])), training, stream);
         break;
       }
       case OP_KXK: {
@@ -198,11 +219,14 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
         lhn_view y = mkview(P, ws, o.out_buf, o.out_coff, o.out_C);
         const bool bn = conv_has_bn(o);
         lhn_bnfin fin;
-        if (bn) fin = mkfin(P, ws, o, params);
-        rc = lhn_conv_kxk_fwd(&x, prm<const float>(params, o.p[0]), &y,
+        if (bn) {
+          fin = mkfin(P, ws, o, params);
+          fin.count *= cscale;
+        }
+        if (h0) rc = lhn_conv_kxk_fwd(&x, prm<const float>(params, o.p[0]), &y,
                               (training && o.ws[0] >= 0) ? reinterpret_cast<double*>(at(ws, o.ws[0])) : nullptr, o.i[0],
-                              (bn && training && fuse_finalize()) ? &fin : nullptr, stream);
-        if (!rc && bn && !(training && fuse_finalize())) rc = sep_finalize(fin, reinterpret_cast<const double*>(at(ws, o.ws[0])), training, stream);
+                              (bn && training && fuse_finalize() && whole) ? &fin : nullptr, stream);
+        if (!rc && bn && h1 && !(training && fuse_finalize() && whole)) rc = sep_finalize(fin, reinterpret_cast<const double*>(at(ws, o.ws[0])), training, stream);
         break;
       }
       case OP_FINALIZE: {
@@ -236,24 +260,30 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
       }
       case OP_CA_MLP: {
         const lhn_buf& b = P->bufs[o.out_buf];
+        if ((!training || o.ws[3] < 0) && !h0) break;      // not splittable: runs whole on its first half-step
         rc = lhn_ca_mlp_fwd(reinterpret_cast<const float*>(at(ws, o.ws[0])), prm<const float>(params, o.p[0]),
                             prm<const float>(params, o.p[1]), prm<const float>(params, o.p[2]), prm<float>(params, o.p[3]),
                             prm<float>(params, o.p[4]), prm<int64_t>(params, o.p[5]), prm<const float>(params, o.p[6]),
                             prm<const float>(params, o.p[7]), prm<const float>(params, o.p[8]), prm<const float>(params, o.p[9]),
                             (training && o.ws[2] >= 0) ? reinterpret_cast<const float*>(at(ws, o.ws[2])) : nullptr,
                             reinterpret_cast<float*>(at(ws, b.gate_off)), b.C, o.out_coff,
-                            reinterpret_cast<float*>(at(ws, o.ws[1])), b.N, o.out_C, o.f[0], o.f[1], training, stream);
+                            reinterpret_cast<float*>(at(ws, o.ws[1])), b.N, o.out_C, o.f[0], o.f[1], training,
+                            (training && o.ws[3] >= 0) ? stage : 0, o.ws[3] >= 0 ? reinterpret_cast<double*>(at(ws, o.ws[3])) : nullptr,
+                            cscale, stream);
         break;
       }
       case OP_ATT_MLP: {  // p: gamma, beta, rmean, rvar, nbt, w3, b3, wl, bl; ws: pooled, save, mask
         const lhn_buf& b = P->bufs[o.out_buf];
+        if ((!training || o.ws[3] < 0) && !h0) break;
         rc = lhn_att_mlp_fwd(reinterpret_cast<const float*>(at(ws, o.ws[0])), prm<const float>(params, o.p[0]),
                              prm<const float>(params, o.p[1]), prm<float>(params, o.p[2]), prm<float>(params, o.p[3]),
                              prm<int64_t>(params, o.p[4]), prm<const float>(params, o.p[5]), prm<const float>(params, o.p[6]),
                              prm<const float>(params, o.p[7]), prm<const float>(params, o.p[8]),
                              (training && o.ws[2] >= 0) ? reinterpret_cast<const float*>(at(ws, o.ws[2])) : nullptr,
                              reinterpret_cast<float*>(at(ws, b.gate_off)), b.C, o.out_coff,
-                             reinterpret_cast<float*>(at(ws, o.ws[1])), b.N, o.out_C, o.f[0], o.f[1], training, stream);
+                             reinterpret_cast<float*>(at(ws, o.ws[1])), b.N, o.out_C, o.f[0], o.f[1], training,
+                             (training && o.ws[3] >= 0) ? stage : 0, o.ws[3] >= 0 ? reinterpret_cast<double*>(at(ws, o.ws[3])) : nullptr,
+                             cscale, stream);
         break;
       }
       // ------------------------------------------------------------------ backward
@@ -314,15 +344,15 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
         fin.coef = reinterpret_cast<float*>(at(ws, b.coef_off));
         fin.dgamma = prm<float>(grads, o.p[1]);
         fin.dbeta = prm<float>(grads, o.p[2]);
-        fin.count = (double)b.N * b.H * b.W;
+        fin.count = (double)b.N * b.H * b.W * cscale;
         fin.cstride = b.C; fin.coff = o.out_coff; fin.C = o.out_C;
-        if (fin.counter && fuse_finalize()) {
+        if (fin.counter && fuse_finalize() && whole) {
           rc = lhn_bn_bwd_reduce(&y, &g, save, sums, &fin, stream);
         } else {
-          rc = lhn_bn_bwd_reduce(&y, &g, save, sums, nullptr, stream);
-          if (!rc)
+          if (h0) rc = lhn_bn_bwd_reduce(&y, &g, save, sums, nullptr, stream);
+          if (!rc && h1)
             rc = lhn_bn_bwd_finalize(sums, fin.gamma, save, fin.coef, b.C, o.out_coff, o.out_C, fin.count, fin.dgamma, fin.dbeta,
-                                     stream);
+                                     pscale, stream);
         }
         break;
       }
@@ -356,6 +386,7 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
       }
       case OP_CA_MLP_BWD: {
         const lhn_buf& b = P->bufs[o.out_buf];
+        if (o.ws[4] < 0 && !h0) break;
         rc = lhn_ca_mlp_bwd(reinterpret_cast<const float*>(at(ws, o.ws[0])), prm<const float>(params, o.p[0]),
                             prm<const float>(params, o.p[1]), prm<const float>(params, o.p[2]), prm<const float>(params, o.p[3]),
                             o.ws[2] >= 0 ? reinterpret_cast<const float*>(at(ws, o.ws[2])) : nullptr,
@@ -363,18 +394,22 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
                             reinterpret_cast<float*>(at(ws, b.dpool_off)), b.C, o.out_coff, b.H, b.W, prm<float>(grads, o.p[4]),
                             prm<float>(grads, o.p[5]), prm<float>(grads, o.p[6]), prm<float>(grads, o.p[7]),
                             prm<float>(grads, o.p[8]), prm<float>(grads, o.p[9]), prm<float>(grads, o.p[10]), b.N, o.out_C,
+                            o.ws[4] >= 0 ? stage : 0, o.ws[4] >= 0 ? reinterpret_cast<double*>(at(ws, o.ws[4])) : nullptr, cscale, pscale,
                             stream);
         break;
       }
       case OP_ATT_MLP_BWD: {  // p: gamma, beta, w3, wl (params) | dgamma, dbeta, dw3, db3, dwl, dbl (grads); ws: pooled, save, mask, dgate
         const lhn_buf& b = P->bufs[o.out_buf];
+        if (o.ws[4] < 0 && !h0) break;
         rc = lhn_att_mlp_bwd(reinterpret_cast<const float*>(at(ws, o.ws[0])), prm<const float>(params, o.p[0]),
                              prm<const float>(params, o.p[1]), prm<const float>(params, o.p[2]), prm<const float>(params, o.p[3]),
                              o.ws[2] >= 0 ? reinterpret_cast<const float*>(at(ws, o.ws[2])) : nullptr,
                              reinterpret_cast<float*>(at(ws, o.ws[1])), reinterpret_cast<const float*>(at(ws, o.ws[3])),
                              reinterpret_cast<float*>(at(ws, b.dpool_off)), b.C, o.out_coff, b.H, b.W, prm<float>(grads, o.p[4]),
                              prm<float>(grads, o.p[5]), prm<float>(grads, o.p[6]), prm<float>(grads, o.p[7]),
-                             prm<float>(grads, o.p[8]), prm<float>(grads, o.p[9]), b.N, o.out_C, stream);
+                             prm<float>(grads, o.p[8]), prm<float>(grads, o.p[9]), b.N, o.out_C,
+                             o.ws[4] >= 0 ? stage : 0, o.ws[4] >= 0 ? reinterpret_cast<double*>(at(ws, o.ws[4])) : nullptr, cscale, pscale,
+                             stream);
         break;
       }
       default:
@@ -383,6 +418,17 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
     }
   }
   return rc;
+}
+
+// SyncBatchNorm driver entry: run the half-steps [step_begin, step_end) of a phase (see run_ops).  The caller all-reduces
+// the statistics buffer of op i between step 2*i and step 2*i+1.
+int lhn_plan_run_range(void* plan, int phase, int64_t step_begin, int64_t step_end, void* ws, void* const* params,
+                       void* const* grads, void* const* io, int training, int grad_replicas, int64_t grad_rep_stride,
+                       double count_scale, float pgrad_scale, void* stream) {
+  LHN_CHECK_ARG(plan && ws && params && io && step_begin >= 0 && step_end >= step_begin && count_scale >= 1, "lhn_plan_run_range: bad argument");
+  LHN_CHECK_ARG(phase == 0 || (phase == 1 && grads), "lhn_plan_run_range: phase %d", phase);
+  return run_ops(static_cast<const Plan*>(plan), phase, ws, params, grads, io, training, grad_replicas < 1 ? 1 : grad_replicas,
+                 grad_rep_stride, stream, (size_t)step_begin, (size_t)step_end, count_scale, pgrad_scale);
 }
 
 static bool graphs_enabled() {

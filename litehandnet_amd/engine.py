@@ -45,7 +45,8 @@ class _PlanFn(torch.autograd.Function):
         if plan.nchw_out:
             out = torch.empty((x.shape[0], plan.pb.nchw_out_C, plan.out_hw[0], plan.out_hw[1]), dtype=torch.float32,
                               device=x.device)
-        plan.run(0, xc if eng.full else None, out, training)
+        ctx.sync = eng.sync_config() if training else None
+        plan.run(0, xc if eng.full else None, out, training, sync=ctx.sync)
         if eng.full:
             ctx.save_for_backward(xc)
         if not plan.nchw_out:
@@ -68,7 +69,7 @@ class _PlanFn(torch.autograd.Function):
             dnchw = dout.contiguous()
         else:
             plan.buf_data(plan.pb.out_ref, grad=True).copy_(dout.permute(0, 2, 3, 1))
-        plan.run(1, xc, dnchw, True, eng.GRAD_REPLICAS, eng.grad_stride)
+        plan.run(1, xc, dnchw, True, eng.GRAD_REPLICAS, eng.grad_stride, sync=ctx.sync)
         _lib.check(_lib.lib().lhn_reduce_replicas(_lib.ptr(eng.flat_grads), _lib.ptr(eng.grad_parts),
                                                   C.c_int64(eng.grad_stride), eng.GRAD_REPLICAS, C.c_int64(eng.grad_stride),
                                                   _lib.stream()), "lhn_reduce_replicas")
@@ -91,6 +92,20 @@ class Engine:
         self.flat_grads = None
         self.grads_via_autograd = False     # True: return per-parameter grads through autograd (DDP-hook compatible)
         self.p_drop = p_drop
+        self.sync_override = None           # (world, all_reduce_fn): tests / custom process groups
+
+    def sync_config(self):
+        """SyncBatchNorm (train/spawn_dist.py:37-38, cfg.TRAIN.syncBN): active when the model holds nn.SyncBatchNorm
+        modules (nn.SyncBatchNorm.convert_sync_batchnorm(model) as the reference does) and a process group with
+        more than one rank exists.  Returns (world, all_reduce_fn) or None."""
+        if self.sync_override is not None:
+            return self.sync_override
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return None
+        if not any(isinstance(m, nn.SyncBatchNorm) for m in self.module.modules()):
+            return None
+        return dist.get_world_size(), (lambda t: dist.all_reduce(t))
 
     # -------------------------------------------------------------- state
     def _state(self, device):

@@ -211,8 +211,9 @@ class PlanBuilder:
         pooled = self._ws("misc", self.N * 9 * Cc * 4)
         save = self._ws("misc", (5 * self.N * Cc + self.N * (Cc // 2) + 2 * Cc) * 4)
         mask = self._ws("mask", self.N * Cc * 4) if self.p_drop > 0 else None
-        rec = dict(op=CA_MLP, y=y, ca=ca, pooled=pooled, save=save, mask=mask)
+        rec = dict(op=CA_MLP, y=y, ca=ca, pooled=pooled, save=save, mask=mask, gsum=self._ws("misc", 2 * Cc * 8))
         if self.with_backward:
+            rec["gsum_b"] = self._ws("misc", 2 * Cc * 8)
             rec["dgate"] = self._ws("misc", self.N * Cc * 4)
             b.dpool = True
         self.recs.append(rec)
@@ -227,8 +228,9 @@ class PlanBuilder:
         Cc = y.C
         rec = dict(op=ATT_MLP, y=y, att=att, pooled=self._ws("misc", self.N * 9 * Cc * 4),
                    save=self._ws("misc", (3 * self.N * Cc + 2 * Cc) * 4),
-                   mask=self._ws("mask", self.N * Cc * 4) if self.p_drop > 0 else None)
+                   mask=self._ws("mask", self.N * Cc * 4) if self.p_drop > 0 else None, gsum=self._ws("misc", 2 * Cc * 8))
         if self.with_backward:
+            rec["gsum_b"] = self._ws("misc", 2 * Cc * 8)
             rec["dgate"] = self._ws("misc", self.N * Cc * 4)
             b.dpool = True
         self.recs.append(rec)
@@ -379,7 +381,7 @@ class PlanBuilder:
                               p=(self._p(bn.weight), self._p(bn.bias), self._p(bn.running_mean), self._p(bn.running_var),
                                  self._p(bn.num_batches_tracked), self._p(dw.weight), self._p(dw.bias),
                                  self._p(lin.weight), self._p(lin.bias)),
-                              ws=(self._abs(r["pooled"]), self._abs(r["save"]), self._abs(r["mask"])),
+                              ws=(self._abs(r["pooled"]), self._abs(r["save"]), self._abs(r["mask"]), self._abs(r["gsum"])),
                               f=(bn.eps, bn.momentum)))
             elif k == CA_MLP:
                 y, ca = r["y"], r["ca"]
@@ -390,7 +392,7 @@ class PlanBuilder:
                                  self._p(bn.running_mean), self._p(bn.running_var), self._p(bn.num_batches_tracked),
                                  self._p(ca.conv1x1[1].weight), self._p(ca.conv1x1[1].bias),
                                  self._p(ca.conv1x1[3].weight), self._p(ca.conv1x1[3].bias)),
-                              ws=(self._abs(r["pooled"]), self._abs(r["save"]), self._abs(r["mask"])),
+                              ws=(self._abs(r["pooled"]), self._abs(r["save"]), self._abs(r["mask"]), self._abs(r["gsum"])),
                               f=(bn.eps, bn.momentum)))
             else:
                 raise AssertionError(k)
@@ -474,7 +476,7 @@ class PlanBuilder:
                                       self._p(bn.weight), self._p(bn.bias), self._p(dw.weight), self._p(dw.bias),
                                       self._p(lin.weight), self._p(lin.bias)),
                                    ws=(self._abs(r["pooled"]), self._abs(r["save"]), self._abs(r["mask"]),
-                                       self._abs(r["dgate"]))))
+                                       self._abs(r["dgate"]), self._abs(r["gsum_b"]))))
                 elif k == CA_MLP:
                     y, ca = r["y"], r["ca"]
                     bn = ca.conv3x3.bn
@@ -486,7 +488,7 @@ class PlanBuilder:
                                       self._p(ca.conv1x1[1].weight), self._p(ca.conv1x1[1].bias),
                                       self._p(ca.conv1x1[3].weight), self._p(ca.conv1x1[3].bias)),
                                    ws=(self._abs(r["pooled"]), self._abs(r["save"]), self._abs(r["mask"]),
-                                       self._abs(r["dgate"]))))
+                                       self._abs(r["dgate"]), self._abs(r["gsum_b"]))))
             if self.ar["zb"].size:
                 bwd.append(mk(MEMSET, ws=(self.arena_base["zb"], self.ar["zb"].size)))
             for b in sorted(self._needs_zero_grad):
@@ -504,6 +506,19 @@ class PlanBuilder:
                     elif o.kind == AVGPOOL_BWD and o.in_buf[0] in self._needs_zero_grad:
                         o.i[2] = 1
             bwd += body
+        # ---------------- SyncBatchNorm: (op index, byte offset, number of doubles) of every statistics buffer that has
+        # to be all-reduced between half-step 2*i and 2*i+1 of lhn_plan_run_range
+        self.sync_points = {0: [], 1: []}
+        for phase, lst in ((0, fwd), (1, bwd)):
+            for i, o in enumerate(lst):
+                if o.kind in (STEM, PW, DW, KXK) and o.p[2] >= 0 and o.ws[0] >= 0:
+                    self.sync_points[0].append((i, o.ws[0], STAT_REPLICAS * 2 * o.out_C))
+                elif o.kind in (CA_MLP, ATT_MLP) and o.ws[3] >= 0:
+                    self.sync_points[0].append((i, o.ws[3], 2 * o.out_C))
+                elif o.kind == BN_BWD:
+                    self.sync_points[1].append((i, o.ws[0], STAT_REPLICAS * 2 * o.out_C))
+                elif o.kind in (CA_MLP_BWD, ATT_MLP_BWD) and o.ws[4] >= 0:
+                    self.sync_points[1].append((i, o.ws[4], 2 * o.out_C))
         # ---------------- C arrays
         cb = (Buf * len(self.bufs))()
         for j, b in enumerate(self.bufs):
@@ -564,13 +579,32 @@ class CompiledPlan:
         for j, g in enumerate(grad_tensors):
             self._grads[j] = 0 if g is None else g.data_ptr()
 
-    def run(self, phase, io0, io1, training, grad_replicas=1, grad_rep_stride=0):
+    def run(self, phase, io0, io1, training, grad_replicas=1, grad_rep_stride=0, sync=None):
+        """sync = (world, all_reduce_fn) runs the phase in SyncBatchNorm mode: the launch sequence is cut at every
+        statistics buffer, `all_reduce_fn(float64 view)` sums it over the ranks, statistics count N*world samples."""
         self._io[0] = 0 if io0 is None else io0.data_ptr()
         self._io[1] = 0 if io1 is None else io1.data_ptr()
         if phase == 0 and training and self.mask_view is not None:
             keep = 1.0 - self.pb.p_drop
             self.mask_view.bernoulli_(keep).mul_(1.0 / keep)
         L = _lib.lib()
+        if sync is not None and training and sync[0] > 1:
+            world, allreduce = sync
+            nsteps = 2 * (self.n_fwd if phase == 0 else self.n_bwd)
+
+            def run_range(b, e):
+                rc = L.lhn_plan_run_range(C.c_void_p(self.handle), phase, C.c_int64(b), C.c_int64(e), _lib.ptr(self.ws),
+                                          self._params, self._grads, self._io, 1, int(grad_replicas),
+                                          C.c_int64(int(grad_rep_stride)), C.c_double(float(world)), C.c_float(1.0 / world),
+                                          _lib.stream())
+                _lib.check(rc, "lhn_plan_run_range")
+            begin = 0
+            for oi, off, n in self.pb.sync_points[phase]:
+                run_range(begin, 2 * oi + 1)
+                allreduce(self.ws[off:off + 8 * n].view(torch.float64))
+                begin = 2 * oi + 1
+            run_range(begin, nsteps)
+            return
         rc = L.lhn_plan_run(C.c_void_p(self.handle), phase, _lib.ptr(self.ws), self._params, self._grads, self._io,
                             1 if training else 0, int(grad_replicas), C.c_int64(int(grad_rep_stride)), _lib.stream())
         _lib.check(rc, "lhn_plan_run")

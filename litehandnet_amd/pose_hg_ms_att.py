@@ -26,7 +26,7 @@ def emit_conv_bn_act(pb, x, seq, out=None):
     groups, i = [], 0
     while i < len(mods):
         conv, bn = mods[i], mods[i + 1]
-        assert isinstance(conv, nn.Conv2d) and isinstance(bn, nn.BatchNorm2d), (type(conv), type(bn))
+        assert isinstance(conv, nn.Conv2d) and isinstance(bn, nn.modules.batchnorm._BatchNorm), (type(conv), type(bn))
         i += 2
         slope = 1.0
         if i < len(mods) and not isinstance(mods[i], nn.Conv2d):

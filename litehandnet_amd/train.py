@@ -29,6 +29,15 @@ def init_distributed(backend=None):
     return rank, local, world
 
 
+def prepare_model(model, cfg):
+    """train/spawn_dist.py:37-38: `cfg.TRAIN.syncBN` converts every BatchNorm to nn.SyncBatchNorm (parameter containers
+    here; the engine sees them and runs the plan in SyncBatchNorm mode: statistics all-reduced over the process group
+    between every convolution and its finalize -- `Engine.sync_config`)."""
+    if cfg.TRAIN.get("syncBN", False) and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        model = nn.SyncBatchNorm.convert_sync_batchnorm(model)
+    return model
+
+
 class FlatParams:
     """Re-homes every parameter of `model` into one flat buffer (views stay valid nn.Parameters, so state_dict
     keys / shapes are untouched) and exposes a single leaf whose .grad is the engine's flat gradient."""

@@ -434,3 +434,77 @@ def test_model_224_input(dev, variant):
     ours, ref = get_model(cfg), torch_ref.get_model(cfg, p_drop=0.0)
     x = synth.synth_images(4, 224, 21)
     _check_block(ours, ref, x, dev, seed=30, no_dx=True)
+
+
+# ---------------------------------------------------------------- SyncBatchNorm (section 8f rank 3)
+@pytest.mark.parametrize("variant", ["B", "M"])
+def test_sync_batchnorm_two_emulated_ranks(dev, variant):
+    """cfg.TRAIN.syncBN (train/spawn_dist.py:37-38): two replicas, each with half of a batch of 8, run in lockstep on one
+    GPU (two host threads; the all-reduce of every statistics buffer is emulated by summing the two replicas' buffers).
+    SyncBatchNorm over the halves must reproduce plain BatchNorm over the whole batch: outputs, running statistics, and
+    the SUM of the two ranks' parameter gradients (DDP would average them)."""
+    import threading
+    from litehandnet_amd import get_model
+    cfg = litehandnet_cfg(variant)
+    cfg.MODEL["ca_dropout"] = 0.0
+    full = get_model(cfg)
+    sd = synth.synth_state_dict(full, 17)
+    full.load_state_dict(sd)
+    full.to(dev).train()
+    x = synth.synth_images(8, 64, 5).to(dev)
+    g = torch.from_numpy(np.random.Generator(np.random.PCG64(9)).standard_normal((8, 21, 16, 16)).astype(np.float32)).to(dev)
+    yf = full(x)
+    yf.backward(g)
+    gf = {k: p.grad.clone() for k, p in full.named_parameters()}
+
+    world = 2
+    reps = []
+    for r in range(world):
+        m = torch.nn.SyncBatchNorm.convert_sync_batchnorm(get_model(cfg))
+        m.load_state_dict(sd)
+        m.to(dev).train()
+        reps.append(m)
+    barrier, slots, errors, outs = threading.Barrier(world), [None] * world, [], [None] * world
+
+    def make_allreduce(rank):
+        def allreduce(t):
+            slots[rank] = t
+            barrier.wait()
+            total = slots[0] + slots[1]          # same stream: ordered after both ranks' producer kernels
+            barrier.wait()
+            t.copy_(total)
+            barrier.wait()
+        return allreduce
+
+    def worker(rank):
+        try:
+            with torch.autograd.set_multithreading_enabled(False):
+                m = reps[rank]
+                from litehandnet_amd.engine import Engine
+                eng = Engine(m)
+                m.__dict__["_engine"] = eng
+                eng.sync_override = (world, make_allreduce(rank))
+                y = m(x[4 * rank:4 * rank + 4])
+                y.backward(g[4 * rank:4 * rank + 4])
+                outs[rank] = y.detach()
+        except Exception as e:          # noqa: BLE001 -- surfaced below
+            errors.append(repr(e))
+            barrier.abort()
+
+    ths = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=240)
+    assert not errors, errors
+    y2 = torch.cat(outs)
+    assert _rel(y2, yf) < 2e-4, _rel(y2, yf)
+    pa, pb2 = dict(reps[0].named_parameters()), dict(reps[1].named_parameters())
+    floor = 1e-3 * max(float(v.double().norm()) for v in gf.values())
+    for k, v in gf.items():
+        tot = pa[k].grad.double() + pb2[k].grad.double()
+        e = float((tot - v.double()).norm() / (v.double().norm() + floor))
+        assert e < 2e-3, (k, e)
+    for (k, a), (_, b) in zip(reps[0].state_dict().items(), full.state_dict().items()):
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            assert torch.allclose(a, b, rtol=1e-4, atol=1e-6), k
