@@ -507,7 +507,7 @@ __global__ void __launch_bounds__(256) k_dwk_fwd_lds(lhn_view x, const float* __
   // are all in flight together) into registers one tile AHEAD; commit() transforms, zeroes the padding and writes LDS
   constexpr int NIT = (T::PIX + 31) / 32;
   f4 raw[NIT];
-  auto issue = [&](int t) {
+  auto issue = [&](int t) __attribute__((always_inline)) {
     int r = t / cgroups;
     const int tw = r % tiles_w;
     r /= tiles_w;

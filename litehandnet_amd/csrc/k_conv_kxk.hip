@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(256) k_kxk(lhn_view x, const float* __restrict
   const int OH2 = par ? (ov.H - ph + 1) / 2 : ov.H, OW = par ? (ov.W - pw2 + 1) / 2 : ov.W, OHW = OH2 * OW;
   const int M = par ? ov.N * OHW : Mhost;
   const int nkw = (par && !pw2) ? 1 : (par ? 2 : 3), ntaps = par ? (ph ? 2 : 1) * nkw : TAPS;
-  auto tap_of = [&](int t) -> int {
+  auto tap_of = [&](int t) __attribute__((always_inline)) -> int {
     if (!par) return t;
     const int a = t / nkw, b = t - a * nkw;
     return (ph ? 2 * a : 1) * 3 + (pw2 ? 2 * b : 1);
@@ -87,28 +87,20 @@ __global__ void __launch_bounds__(256) k_kxk(lhn_view x, const float* __restrict
   bool pv[PF];
   int cur_tile = 0;
 
-  auto geom = [&](int tile) {
+  auto geom = [&](int tile) __attribute__((always_inline)) {
     cur_tile = tile;
     if (LIN) return;
 #pragma unroll
     for (int p = 0; p < PF; ++p) {
-      const int m = tile * BM + row0 + p * RP;
-      if (m < M) {
-        rn[p] = m / OHW;
-        const int r = m - rn[p] * OHW;
-        rh[p] = r / OW;
-        rw[p] = r - rh[p] * OW;
-        if (par) {
-          rh[p] = 2 * rh[p] + ph;
-          rw[p] = 2 * rw[p] + pw2;
-        }
-      } else {
-        rn[p] = -1;
-        rh[p] = rw[p] = 0;
-      }
+      // branch-free (an if/else over these small arrays made the compiler keep them in scratch memory)
+      const int m = tile * BM + row0 + p * RP, mc = min(m, M - 1);
+      const int n = mc / OHW, r = mc - n * OHW, i2 = r / OW, j2 = r - i2 * OW;
+      rn[p] = m < M ? n : -1;
+      rh[p] = par ? 2 * i2 + ph : i2;
+      rw[p] = par ? 2 * j2 + pw2 : j2;
     }
   };
-  auto issue = [&](int tap) {
+  auto issue = [&](int tap) __attribute__((always_inline)) {
     const int kh = TAPS == 1 ? 1 : tap / 3, kw = TAPS == 1 ? 1 : tap - (tap / 3) * 3;
     if (LIN) {
 #pragma unroll
@@ -145,7 +137,7 @@ __global__ void __launch_bounds__(256) k_kxk(lhn_view x, const float* __restrict
       }
     }
   };
-  auto stage_w = [&](int tap) {
+  auto stage_w = [&](int tap) __attribute__((always_inline)) {
 #pragma unroll 1
     for (int j0 = 0; j0 < NW; j0 += WCH) {
       float t[WCH];
@@ -175,7 +167,7 @@ __global__ void __launch_bounds__(256) k_kxk(lhn_view x, const float* __restrict
       }
     }
   };
-  auto commit = [&](int tap) {
+  auto commit = [&](int tap) __attribute__((always_inline)) {
     const int kh = TAPS == 1 ? 1 : tap / 3, kw = TAPS == 1 ? 1 : tap - (tap / 3) * 3;
     const f4 one = (f4){1.f, 1.f, 1.f, 1.f}, zero = (f4){0.f, 0.f, 0.f, 0.f};
     if (MODE == 1 && PLAIN) {
@@ -330,7 +322,7 @@ __global__ void __launch_bounds__(256) k_kxk_wgrad(lhn_view x, lhn_view y, lhn_g
   bool xok[XPF], yok[YPF];
   int xn[XPF], yn[YPF];
   // raw global loads of one 64-pixel tile into registers (clamped addresses, validity kept as predicates)
-  auto issue = [&](int tile) {
+  auto issue = [&](int tile) __attribute__((always_inline)) {
 #pragma unroll
     for (int p = 0; p < XPF; ++p) {
       const int m = min(tile * 64 + xr0 + p * XRP, M - 1);
@@ -352,7 +344,7 @@ __global__ void __launch_bounds__(256) k_kxk_wgrad(lhn_view x, lhn_view y, lhn_g
     }
   };
   // transform and park them in LDS
-  auto commit = [&]() {
+  auto commit = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int p = 0; p < XPF; ++p) {
       const f4 gate = x.gate ? *reinterpret_cast<const f4*>(x.gate + (size_t)xn[p] * x.cstride + xabs) : one;

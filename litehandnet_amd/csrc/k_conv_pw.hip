@@ -36,13 +36,13 @@ __global__ void __launch_bounds__(256) k_pw_fwd(lhn_view x, const float* __restr
   const int HoWo = y.H * y.W;
 
   f4 pre[PF];
-  auto in_pix = [&](int m) -> int64_t {
+  auto in_pix = [&](int m) __attribute__((always_inline)) -> int64_t {
     if (stride == 1) return m;
     const int n = m / HoWo, r = m - n * HoWo;
     const int ho = r / y.W, wo = r - ho * y.W;
     return ((int64_t)n * x.H + ho * stride) * x.W + wo * stride;
   };
-  auto issue = [&](int tile) {
+  auto issue = [&](int tile) __attribute__((always_inline)) {
 #pragma unroll
     for (int p = 0; p < PF; ++p) {
       const int m = tile * 128 + row0 + p * RP;
@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(256) k_pw_fwd(lhn_view x, const float* __restr
       if (m < M) pre[p] = *reinterpret_cast<const f4*>(x.data + in_pix(m) * x.cstride + cabs);
     }
   };
-  auto commit = [&](int tile) {
+  auto commit = [&](int tile) __attribute__((always_inline)) {
 #pragma unroll
     for (int p = 0; p < PF; ++p) {
       const int row = row0 + p * RP, m = tile * 128 + row;
@@ -280,7 +280,7 @@ __global__ void __launch_bounds__(256) k_pw_bwd(lhn_view x, const float* __restr
 #pragma unroll
     for (int r = 0; r < 16; ++r) accw[t][r] = 0.f;
 
-  auto in_pix = [&](int m) -> int64_t {
+  auto in_pix = [&](int m) __attribute__((always_inline)) -> int64_t {
     if (stride == 1) return m;
     const int n = m / HoWo, r = m - n * HoWo;
     const int ho = r / y.W, wo = r - ho * y.W;
@@ -290,7 +290,7 @@ __global__ void __launch_bounds__(256) k_pw_bwd(lhn_view x, const float* __restr
   // global loads of a tile go to registers (issue) one iteration ahead of their transform + LDS store (commit), so the
   // next tile's HBM latency overlaps this tile's MFMA work
   f4 xraw[XPF], yraw[YPF], ydz[YPF];
-  auto issue = [&](int tile) {
+  auto issue = [&](int tile) __attribute__((always_inline)) {
 #pragma unroll
     for (int p = 0; p < XPF; ++p) {
       const int m = min(tile * 64 + xr0 + p * XRP, M - 1);      // clamped (branch-free); commit() zeroes rows >= M
@@ -305,7 +305,7 @@ __global__ void __launch_bounds__(256) k_pw_bwd(lhn_view x, const float* __restr
       }
     }
   };
-  auto commit = [&](int tile) {
+  auto commit = [&](int tile) __attribute__((always_inline)) {
 #pragma unroll
     for (int p = 0; p < XPF; ++p) {
       const int row = xr0 + p * XRP, m = tile * 64 + row;
