@@ -132,8 +132,10 @@ int lhn_conv_dw_fwd(const lhn_view* x, const float* w /*[C,1,k,k]*/, const lhn_v
                     int k, int stride, int pad, int dil, const lhn_bnfin* fin, void* stream);
 int lhn_conv_stem_fwd(const float* img /*[N,3,Hi,Wi]*/, const float* w /*[Cout,3,k,k]*/, const lhn_view* y,
                       double* stats, int Hi, int Wi, int k, int stride, int pad, const lhn_bnfin* fin, void* stream);
+/* wt_scratch: optional 9*Cout*Cin floats of caller-owned scratch; the call re-lays the OIHW weights tap-major into it
+ * (16-byte weight loads per tap instead of 36-byte-strided gathers).  NULL = read the OIHW tensor directly. */
 int lhn_conv_kxk_fwd(const lhn_view* x, const float* w /*[Cout,Cin,3,3]*/, const lhn_view* y, double* stats,
-                     int stride, const lhn_bnfin* fin, void* stream);
+                     int stride, const lhn_bnfin* fin, float* wt_scratch, void* stream);
 /* conv_bias: a biased convolution followed by BatchNorm (models/pose_hg_ms_att.py:27-35,46-56) stores its output
  * WITHOUT the bias -- BatchNorm cancels it -- and the bias only enters the running mean (training) or the shift
  * (eval: beta - (running_mean - bias) * scale).  d(bias) is identically zero in training mode. */
@@ -203,7 +205,8 @@ int lhn_conv_stem_bwd(const float* img, const lhn_view* y, const lhn_gradview* g
 /* NOTE: lhn_conv_kxk_bwd and the large-channel path of lhn_conv_pw_bwd CONSUME gy->dz (it is overwritten in place
  * with dy before the MFMA kernels stream it). */
 int lhn_conv_kxk_bwd(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx,
-                     int dx_accumulate, float* dw, int stride, int nrep, int64_t rep_stride, void* stream);
+                     int dx_accumulate, float* dw, int stride, int nrep, int64_t rep_stride,
+                     float* wt_scratch /*9*Cout*Cin floats or NULL, as above (dgrad layout)*/, void* stream);
 /* out[i] = sum_r part[r*rep_stride + i]  (folds the replicated weight-gradient partials into the flat gradient) */
 /* SyncBatchNorm (train/spawn_dist.py:37-38): run half-steps [step_begin, step_end) of a phase -- step 2*i = main
  * launches of op i, step 2*i+1 = the consumer of its statistics.  The caller all-reduces (SUM) the op's statistics

@@ -45,7 +45,7 @@ static void launch_dy_inplace(const lhn_view* y, const lhn_gradview* gy, hipStre
 template <int KD, int NT, int MODE, int TAPS, bool PLAIN = false>
 __global__ void __launch_bounds__(256) k_kxk(lhn_view x, const float* __restrict__ w, lhn_view y, lhn_gradview gy,
                                              double* __restrict__ stats, float* __restrict__ dx, int dx_acc, int stride,
-                                             int nout, int Mhost, int ntiles, lhn_bnfin fin) {
+                                             int nout, int Mhost, int ntiles, lhn_bnfin fin, const float* __restrict__ wt) {
   constexpr int BM = 128, LDA = KD + 4;
   constexpr int C4 = KD / 4, RP = 256 / C4, PF = BM / RP;     // float4 per thread per phase
   constexpr int NW = 32 * NT * KD / 256;                      // weight scalars per thread per tap
@@ -138,6 +138,26 @@ __global__ void __launch_bounds__(256) k_kxk(lhn_view x, const float* __restrict
     }
   };
   auto stage_w = [&](int tap) __attribute__((always_inline)) {
+    if (TAPS > 1 && wt) {
+      // tap-major copy of the weights (k_w_tapmajor): row = output feature of this GEMM, KD contiguous floats per row ->
+      // 16-byte loads/stores instead of 4-byte gathers with a 36-byte stride (which cost more than the MFMAs of a phase)
+      constexpr int NWV = 32 * NT * KD / 4 / 256, K4 = KD / 4;
+#pragma unroll
+      for (int j0 = 0; j0 < NWV; j0 += 4) {
+        f4 t[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int i = tid + 256 * (j0 + j), nn = i / K4, k4 = i - nn * K4;
+          t[j] = *reinterpret_cast<const f4*>(wt + ((size_t)tap * nout + min(n0 + nn, nout - 1)) * KD + 4 * k4);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int i = tid + 256 * (j0 + j), nn = i / K4, k4 = i - nn * K4;
+          *reinterpret_cast<f4*>(Ws + nn * LDA + 4 * k4) = n0 + nn < nout ? t[j] : (f4){0.f, 0.f, 0.f, 0.f};
+        }
+      }
+      return;
+    }
 #pragma unroll 1
     for (int j0 = 0; j0 < NW; j0 += WCH) {
       float t[WCH];
@@ -403,9 +423,24 @@ __global__ void __launch_bounds__(256) k_kxk_wgrad(lhn_view x, lhn_view y, lhn_g
   }
 }
 
+// wt[tap][r][k]: mode 0 (forward GEMM, rows = Cout, K = Cin)  wt = w[r][k][tap];  mode 1 (dgrad, rows = Cin, K = Cout)
+// wt = w[k][r][tap].  147,456 floats for 128 -> 128: a ~3 us launch per conv and direction.
+__global__ void __launch_bounds__(256) k_w_tapmajor(const float* __restrict__ w, float* __restrict__ wt, int Cout, int Cin, int mode) {
+  const int R = mode ? Cin : Cout, K = mode ? Cout : Cin, total = 9 * R * K;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int k = i % K, r = (i / K) % R, tap = i / (K * R);
+    wt[i] = mode ? w[((size_t)k * Cin + r) * 9 + tap] : w[((size_t)r * Cin + k) * 9 + tap];
+  }
+}
+static void launch_w_tapmajor(const float* w, float* wt, int Cout, int Cin, int mode, hipStream_t s) {
+  const int total = 9 * Cout * Cin;
+  hipLaunchKernelGGL(k_w_tapmajor, dim3((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024), dim3(256), 0, s, w, wt, Cout, Cin, mode);
+}
+
 template <int KD, int NT, int MODE, int TAPS, bool PLAIN = false>
 static int launch_kxk(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, double* stats, float* dx,
-                      int dx_acc, int stride, int nout, hipStream_t s, const lhn_bnfin* finp = nullptr, int nsplit = 1, int parity = 0) {
+                      int dx_acc, int stride, int nout, hipStream_t s, const lhn_bnfin* finp = nullptr, int nsplit = 1, int parity = 0,
+                      const float* wt = nullptr) {
   lhn_bnfin fin;
   if (finp && stats) fin = *finp; else fin.counter = nullptr;
   const lhn_view* ov = MODE == 0 ? y : x;
@@ -426,7 +461,7 @@ static int launch_kxk(const lhn_view* x, const float* w, const lhn_view* y, cons
   if (grid > ntiles) grid = ntiles;
   lhn_gradview g;
   if (gy) g = *gy; else g.dz = g.dpool = g.coef = nullptr;
-  hipLaunchKernelGGL((k_kxk<KD, NT, MODE, TAPS, PLAIN>), dim3(grid, nsplit, parity ? 4 : 1), dim3(256), lds, s, *x, w, *y, g, stats, dx, dx_acc, stride, nout, M, ntiles, fin);
+  hipLaunchKernelGGL((k_kxk<KD, NT, MODE, TAPS, PLAIN>), dim3(grid, nsplit, parity ? 4 : 1), dim3(256), lds, s, *x, w, *y, g, stats, dx, dx_acc, stride, nout, M, ntiles, fin, wt);
   return 0;
 }
 
@@ -470,13 +505,14 @@ static int kxk_nt_block(int M, int nt) {
 }
 
 extern "C" int lhn_conv_kxk_fwd(const lhn_view* x, const float* w, const lhn_view* y, double* stats, int stride,
-                                const lhn_bnfin* fin, void* stream) {
+                                const lhn_bnfin* fin, float* wt_scratch, void* stream) {
   LHN_CHECK_ARG(lhn_view_ok(x) && lhn_view_ok(y) && w, "lhn_conv_kxk_fwd: bad view / null pointer");
   LHN_CHECK_ARG((stride == 1 || stride == 2) && kxk_geometry_ok(x, y, stride), "lhn_conv_kxk_fwd: geometry / stride %d", stride);
   const int ntot = (y->C + 31) / 32, nt = (ntot == 1 || ntot == 2 || ntot == 4) ? kxk_nt_block(y->N * y->H * y->W, ntot) : ntot;
   hipStream_t s = (hipStream_t)stream;
   int rc = -1;
-#define KF(CI, NTV) if (x->C == CI && nt == NTV) rc = launch_kxk<CI, NTV, 0, 9>(x, w, y, nullptr, stats, nullptr, 0, stride, y->C, s, fin, ntot / nt);
+  if (wt_scratch) launch_w_tapmajor(w, wt_scratch, y->C, x->C, 0, s);
+#define KF(CI, NTV) if (x->C == CI && nt == NTV) rc = launch_kxk<CI, NTV, 0, 9>(x, w, y, nullptr, stats, nullptr, 0, stride, y->C, s, fin, ntot / nt, 0, wt_scratch);
   KF(32, 1) KF(64, 2) KF(128, 4) KF(32, 2) KF(64, 1) KF(64, 4) KF(128, 2) KF(128, 1) KF(32, 4)
 #undef KF
   LHN_CHECK_ARG(rc != -1, "lhn_conv_kxk_fwd: unsupported channels Cin=%d Cout=%d", x->C, y->C);
@@ -486,7 +522,8 @@ extern "C" int lhn_conv_kxk_fwd(const lhn_view* x, const float* w, const lhn_vie
 }
 
 extern "C" int lhn_conv_kxk_bwd(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx,
-                                int dx_accumulate, float* dw, int stride, int nrep, int64_t rep_stride, void* stream) {
+                                int dx_accumulate, float* dw, int stride, int nrep, int64_t rep_stride, float* wt_scratch,
+                                void* stream) {
   LHN_CHECK_ARG(lhn_view_ok(x) && lhn_view_ok(y) && w && gy && gy->dz && dw, "lhn_conv_kxk_bwd: bad view / null pointer");
   LHN_CHECK_ARG((stride == 1 || stride == 2) && kxk_geometry_ok(x, y, stride), "lhn_conv_kxk_bwd: geometry / stride %d", stride);
   if (nrep < 1) nrep = 1;
@@ -499,8 +536,9 @@ extern "C" int lhn_conv_kxk_bwd(const lhn_view* x, const float* w, const lhn_vie
   if (dx) {
     // GEMM N = Cin, K = Cout
     const int par = stride == 2 ? 1 : 0;     // stride 2: four parity classes of input pixels (gridDim.z)
+    if (wt_scratch) launch_w_tapmajor(w, wt_scratch, y->C, x->C, 1, s);
     const int ntot = (x->C + 31) / 32, nt = (ntot == 1 || ntot == 2 || ntot == 4) ? kxk_nt_block(x->N * x->H * x->W, ntot) : ntot;
-#define KB(CO, NTV) if (y->C == CO && nt == NTV) rc = plain ? launch_kxk<CO, NTV, 1, 9, true>(x, w, y, gy, nullptr, dx, dx_accumulate, stride, x->C, s, nullptr, ntot / nt, par) : launch_kxk<CO, NTV, 1, 9, false>(x, w, y, gy, nullptr, dx, dx_accumulate, stride, x->C, s, nullptr, ntot / nt, par);
+#define KB(CO, NTV) if (y->C == CO && nt == NTV) rc = plain ? launch_kxk<CO, NTV, 1, 9, true>(x, w, y, gy, nullptr, dx, dx_accumulate, stride, x->C, s, nullptr, ntot / nt, par, wt_scratch) : launch_kxk<CO, NTV, 1, 9, false>(x, w, y, gy, nullptr, dx, dx_accumulate, stride, x->C, s, nullptr, ntot / nt, par, wt_scratch);
     KB(32, 1) KB(64, 2) KB(128, 4) KB(32, 2) KB(64, 1) KB(64, 4) KB(128, 2) KB(128, 1) KB(32, 4)
 #undef KB
     LHN_CHECK_ARG(rc != -1, "lhn_conv_kxk_bwd: unsupported channels Cin=%d Cout=%d", x->C, y->C);

@@ -225,7 +225,8 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
         }
         if (h0) rc = lhn_conv_kxk_fwd(&x, prm<const float>(params, o.p[0]), &y,
                               (training && o.ws[0] >= 0) ? reinterpret_cast<double*>(at(ws, o.ws[0])) : nullptr, o.i[0],
-                              (bn && training && fuse_finalize() && whole) ? &fin : nullptr, stream);
+                              (bn && training && fuse_finalize() && whole) ? &fin : nullptr,
+                              o.ws[3] >= 0 ? reinterpret_cast<float*>(at(ws, o.ws[3])) : nullptr, stream);
         if (!rc && bn && h1 && !(training && fuse_finalize() && whole)) rc = sep_finalize(fin, reinterpret_cast<const double*>(at(ws, o.ws[0])), training, stream);
         break;
       }
@@ -329,7 +330,7 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
         lhn_gradview g = mkgrad(P, ws, o.out_buf, o.i[5] != 0);
         float* dx = o.i[2] ? reinterpret_cast<float*>(at(ws, P->bufs[o.in_buf[0]].grad_off)) : nullptr;
         rc = lhn_conv_kxk_bwd(&x, prm<const float>(params, o.p[0]), &y, &g, dx, o.i[2] == 2, prm<float>(grads, o.p[1]), o.i[0],
-                              nrep, rstr, stream);
+                              nrep, rstr, o.ws[3] >= 0 ? reinterpret_cast<float*>(at(ws, o.ws[3])) : nullptr, stream);
         break;
       }
       case OP_BN_BWD: {

@@ -144,6 +144,8 @@ class PlanBuilder:
         assert (out.H, out.W, out.C) == (Ho, Wo, cout), (out, Ho, Wo, cout)
         rec = dict(op=kind, x=x, out=out, conv=conv, bn=bn, slope=float(slope), k=kh, stride=s, pad=p, dil=d,
                    nchw=nchw_out)
+        if kind == KXK:
+            rec["wt"] = self._ws("misc", 9 * cout * cin_g * 4)      # tap-major weight scratch (lhn_conv_kxk_*: wt_scratch)
         if bn is not None:
             rec["stats"] = self._ws("zf", STAT_REPLICAS * 2 * cout * 8)
             rec["cnt"] = self._ws("zf", 4)
@@ -353,7 +355,8 @@ class PlanBuilder:
                 elif k == DW:
                     fwd.append(mk(DW, ins=(x,), out=out, p=(pw, cb) + pbn, ws=wsl, i=(r["k"], r["stride"], r["pad"], r["dil"]), f=fl))
                 else:
-                    fwd.append(mk(KXK, ins=(x,), out=out, p=(pw, cb) + pbn, ws=wsl, i=(r["stride"],), f=fl))
+                    fwd.append(mk(KXK, ins=(x,), out=out, p=(pw, cb) + pbn, ws=(tuple(wsl) + (-1, -1, -1))[:3] + (self._abs(r["wt"]),),
+                                  i=(r["stride"],), f=fl))
             elif k == EW:
                 fwd.append(mk(EW, ins=r["srcs"], out=r["out"], i=(len(r["srcs"]),), f=(r["slope"],)))
             elif k == MAXPOOL:
@@ -453,7 +456,8 @@ class PlanBuilder:
                         body.append(mk(DW_BWD, ins=(x,), out=out, p=(pw, pw),
                                        i=(r["k"], r["stride"], r["pad"], r["dil"], mode, use_coef)))
                     else:
-                        body.append(mk(KXK_BWD, ins=(x,), out=out, p=(pw, pw), i=(r["stride"], 0, mode, 0, 0, use_coef)))
+                        body.append(mk(KXK_BWD, ins=(x,), out=out, p=(pw, pw), ws=(-1, -1, -1, self._abs(r["wt"])),
+                                       i=(r["stride"], 0, mode, 0, 0, use_coef)))
                 elif k == EW:
                     for s in r["srcs"]:
                         if s.buf == self._no_grad_buf or (s.buf in aliased and self.bufs[s.buf].off["grad"] == self.bufs[r["out"].buf].off["grad"]):
