@@ -188,6 +188,15 @@ int lhn_att_mlp_bwd(const float* pooled, const float* gamma, const float* beta, 
                     float* dbl, int N, int C, int stage, double* gsum, double count_scale, float pgrad_scale,
                     void* stream);
 
+/* squeeze-and-excitation gate (models/pose_estimation/liteHandNet/common.py:23-37; ca_type / msrb_ca / rbu_ca = 'se'):
+ * gate = sigmoid(up(relu(down(pooled)))), pooled = lhn_avgpool_fwd(y, 1, 1) [N,C]; J = internal neurons; save = floats[N*J + N*C] */
+int lhn_se_mlp_fwd(const float* pooled, const float* w1 /*[J,C]*/, const float* b1, const float* w2 /*[C,J]*/,
+                   const float* b2, float* gate, int gate_stride, int gate_coff, float* save, int N, int C, int J,
+                   void* stream);
+int lhn_se_mlp_bwd(const float* pooled, const float* w1, const float* w2, const float* save, const float* dgate /*[N,C]*/,
+                   float* dpool /*[N,25,cstride]*/, int cstride, int coff, int H, int W, float* dw1, float* db1, float* dw2,
+                   float* db2, int N, int C, int J, void* stream);
+
 /* backward building blocks */
 int lhn_bn_bwd_reduce(const lhn_view* y, const lhn_gradview* g, const float* save_mean_invstd,
                       double* sums /*[R][2][C]: sum du, sum du*xhat*/, const lhn_bnbwdfin* fin /*or NULL*/, void* stream);

@@ -1,7 +1,23 @@
-"""HIP-backed mirror of models/pose_estimation/liteHandNet/common.py:40-66 (ChannelAttension)."""
+"""HIP-backed mirror of models/pose_estimation/liteHandNet/common.py:23-66 (SEBlock, ChannelAttension)."""
 from torch import nn
 
 from .engine import PlanModule
+
+
+class SEBlock(PlanModule):
+    """x * sigmoid(up(relu(down(global_avg_pool(x)))))  -- common.py:23-37."""
+
+    def __init__(self, input_channels, internal_neurons):
+        super().__init__()
+        self.down = nn.Conv2d(input_channels, internal_neurons, kernel_size=1, stride=1, bias=True)
+        self.up = nn.Conv2d(internal_neurons, input_channels, kernel_size=1, stride=1, bias=True)
+        self.input_channels = input_channels
+
+    def emit(self, pb, x, out=None):
+        b = pb.bufs[x.buf]
+        if x.coff != 0 or x.C != b.C or b.gate or (pb.in_ref is not None and x.buf == pb.in_ref.buf):
+            x = pb.ew([x])          # a gate needs a buffer of its own whose producer turns (gate, dz, dpool) into d(raw)
+        return pb.se_attention(x, self)
 
 
 class ChannelAttension(PlanModule):
@@ -32,6 +48,6 @@ class ChannelAttension(PlanModule):
     def emit(self, pb, x, out=None):
         # the gate attaches to the buffer behind x; a view that does not own its buffer is materialised first
         b = pb.bufs[x.buf]
-        if x.coff != 0 or x.C != b.C or b.gate:
+        if x.coff != 0 or x.C != b.C or b.gate or (pb.in_ref is not None and x.buf == pb.in_ref.buf):
             x = pb.ew([x])
         return pb.channel_attention(x, self)

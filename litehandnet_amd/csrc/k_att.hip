@@ -256,3 +256,88 @@ extern "C" int lhn_att_mlp_bwd(const float* pooled, const float* gamma, const fl
   LHN_CHECK_LAUNCH("lhn_att_mlp_bwd");
   return 0;
 }
+
+// ------------------------------------------------------------------ squeeze-and-excitation (reference common.py:23-37)
+//   gate = sigmoid(up(relu(down(global_avg_pool(y)))))   -- 1x1 convs with bias, J = internal neurons (C/16)
+// pooled = lhn_avgpool_fwd(y, 1, 1) -> [N][C].  save layout (floats): h[N*J] | g[N*C]
+__global__ void __launch_bounds__(256) k_se_fwd(const float* __restrict__ pooled, const float* __restrict__ w1,
+                                                const float* __restrict__ b1, const float* __restrict__ w2,
+                                                const float* __restrict__ b2, float* __restrict__ save, float* __restrict__ gate,
+                                                int gs, int gcoff, int N, int C, int J) {
+  __shared__ float sp[256], sh[64];
+  const int n = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) sp[c] = pooled[(int64_t)n * C + c];
+  __syncthreads();
+  for (int j = threadIdx.x; j < J; j += blockDim.x) {
+    float v = b1[j];
+    for (int c = 0; c < C; ++c) v += w1[j * C + c] * sp[c];
+    v = fmaxf(v, 0.f);
+    sh[j] = v;
+    save[(int64_t)n * J + j] = v;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float v = b2[c];
+    for (int j = 0; j < J; ++j) v += w2[c * J + j] * sh[j];
+    const float g = 1.f / (1.f + expf(-v));
+    save[(int64_t)N * J + (int64_t)n * C + c] = g;
+    gate[(int64_t)n * gs + gcoff + c] = g;
+  }
+}
+
+// backward: parameter gradients (atomics over the N blocks) and the pooled gradient, written to all 25 segment slots
+// (one global bin: every pixel receives d(loss)/d(pooled) / (H*W))
+__global__ void __launch_bounds__(256) k_se_bwd(const float* __restrict__ pooled, const float* __restrict__ w1,
+                                                const float* __restrict__ w2, const float* __restrict__ save,
+                                                const float* __restrict__ dgate, float* __restrict__ dpool, int cs, int coff,
+                                                float inv_hw, float* __restrict__ dw1, float* __restrict__ db1,
+                                                float* __restrict__ dw2, float* __restrict__ db2, int N, int C, int J) {
+  __shared__ float sp[256], sh[64], sdz[256], sdh[64];
+  const int n = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    sp[c] = pooled[(int64_t)n * C + c];
+    const float g = save[(int64_t)N * J + (int64_t)n * C + c];
+    const float dz = dgate[(int64_t)n * C + c] * g * (1.f - g);
+    sdz[c] = dz;
+    atomicAdd(db2 + c, dz);
+  }
+  for (int j = threadIdx.x; j < J; j += blockDim.x) sh[j] = save[(int64_t)n * J + j];
+  __syncthreads();
+  for (int i = threadIdx.x; i < C * J; i += blockDim.x) atomicAdd(dw2 + i, sdz[i / J] * sh[i % J]);
+  for (int j = threadIdx.x; j < J; j += blockDim.x) {
+    float d = 0.f;
+    for (int c = 0; c < C; ++c) d += w2[c * J + j] * sdz[c];
+    d = sh[j] > 0.f ? d : 0.f;
+    sdh[j] = d;
+    atomicAdd(db1 + j, d);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < J * C; i += blockDim.x) atomicAdd(dw1 + i, sdh[i / C] * sp[i % C]);
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float d = 0.f;
+    for (int j = 0; j < J; ++j) d += w1[j * C + c] * sdh[j];
+    d *= inv_hw;
+    for (int s = 0; s < LHN_DPOOL_SLOTS; ++s) dpool[((int64_t)n * LHN_DPOOL_SLOTS + s) * cs + coff + c] = d;
+  }
+}
+
+extern "C" int lhn_se_mlp_fwd(const float* pooled, const float* w1, const float* b1, const float* w2, const float* b2, float* gate,
+                              int gate_stride, int gate_coff, float* save, int N, int C, int J, void* stream) {
+  LHN_CHECK_ARG(pooled && w1 && b1 && w2 && b2 && gate && save, "lhn_se_mlp_fwd: null pointer");
+  LHN_CHECK_ARG(C > 0 && C <= 256 && J > 0 && J <= 64 && N > 0, "lhn_se_mlp_fwd: C=%d J=%d (C <= 256, J <= 64)", C, J);
+  hipLaunchKernelGGL(k_se_fwd, dim3(N), dim3(128), 0, (hipStream_t)stream, pooled, w1, b1, w2, b2, save, gate, gate_stride, gate_coff,
+                     N, C, J);
+  LHN_CHECK_LAUNCH("lhn_se_mlp_fwd");
+  return 0;
+}
+
+extern "C" int lhn_se_mlp_bwd(const float* pooled, const float* w1, const float* w2, const float* save, const float* dgate,
+                              float* dpool, int cstride, int coff, int H, int W, float* dw1, float* db1, float* dw2, float* db2,
+                              int N, int C, int J, void* stream) {
+  LHN_CHECK_ARG(pooled && w1 && w2 && save && dgate && dpool && dw1 && db1 && dw2 && db2, "lhn_se_mlp_bwd: null pointer");
+  LHN_CHECK_ARG(C > 0 && C <= 256 && J > 0 && J <= 64 && N > 0 && H > 0 && W > 0, "lhn_se_mlp_bwd: C=%d J=%d", C, J);
+  hipLaunchKernelGGL(k_se_bwd, dim3(N), dim3(256), 0, (hipStream_t)stream, pooled, w1, w2, save, dgate, dpool, cstride, coff,
+                     1.f / (float)(H * W), dw1, db1, dw2, db2, N, C, J);
+  LHN_CHECK_LAUNCH("lhn_se_mlp_bwd");
+  return 0;
+}

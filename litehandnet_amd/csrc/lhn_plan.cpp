@@ -11,9 +11,9 @@ extern "C" int lhn_ew_bwd2(const lhn_view* src, const lhn_view* dst, const float
 
 enum {
   OP_STEM = 1, OP_PW = 2, OP_DW = 3, OP_KXK = 4, OP_FINALIZE = 5, OP_EW = 6, OP_MAXPOOL = 7, OP_AVGPOOL = 8,
-  OP_CA_MLP = 9, OP_TABLE_FILL = 10, OP_MEMSET = 11, OP_ATT_MLP = 12,
+  OP_CA_MLP = 9, OP_TABLE_FILL = 10, OP_MEMSET = 11, OP_ATT_MLP = 12, OP_SE_MLP = 13,
   OP_STEM_BWD = 101, OP_PW_BWD = 102, OP_DW_BWD = 103, OP_KXK_BWD = 104, OP_BN_BWD = 105, OP_EW_BWD = 106,
-  OP_MAXPOOL_BWD = 107, OP_AVGPOOL_BWD = 108, OP_GATE_REDUCE = 109, OP_CA_MLP_BWD = 110, OP_ATT_MLP_BWD = 111,
+  OP_MAXPOOL_BWD = 107, OP_AVGPOOL_BWD = 108, OP_GATE_REDUCE = 109, OP_CA_MLP_BWD = 110, OP_ATT_MLP_BWD = 111, OP_SE_MLP_BWD = 112,
 };
 
 // One captured launch sequence (hipGraph) of a phase for one set of pointers.
@@ -287,6 +287,14 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
                              cscale, stream);
         break;
       }
+      case OP_SE_MLP: {  // p: w1, b1, w2, b2; ws: pooled, save; i[0] = J
+        const lhn_buf& b = P->bufs[o.out_buf];
+        rc = lhn_se_mlp_fwd(reinterpret_cast<const float*>(at(ws, o.ws[0])), prm<const float>(params, o.p[0]),
+                            prm<const float>(params, o.p[1]), prm<const float>(params, o.p[2]), prm<const float>(params, o.p[3]),
+                            reinterpret_cast<float*>(at(ws, b.gate_off)), b.C, o.out_coff, reinterpret_cast<float*>(at(ws, o.ws[1])),
+                            b.N, o.out_C, o.i[0], stream);
+        break;
+      }
       // ------------------------------------------------------------------ backward
       case OP_STEM_BWD: {
         lhn_view y = mkview(P, ws, o.out_buf, o.out_coff, o.out_C);
@@ -411,6 +419,15 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
                              prm<float>(grads, o.p[8]), prm<float>(grads, o.p[9]), b.N, o.out_C,
                              o.ws[4] >= 0 ? stage : 0, o.ws[4] >= 0 ? reinterpret_cast<double*>(at(ws, o.ws[4])) : nullptr, cscale, pscale,
                              stream);
+        break;
+      }
+      case OP_SE_MLP_BWD: {  // p: w1, w2 (params) | dw1, db1, dw2, db2 (grads); ws: pooled, save, -, dgate; i[0] = J
+        const lhn_buf& b = P->bufs[o.out_buf];
+        rc = lhn_se_mlp_bwd(reinterpret_cast<const float*>(at(ws, o.ws[0])), prm<const float>(params, o.p[0]),
+                            prm<const float>(params, o.p[1]), reinterpret_cast<const float*>(at(ws, o.ws[1])),
+                            reinterpret_cast<const float*>(at(ws, o.ws[3])), reinterpret_cast<float*>(at(ws, b.dpool_off)), b.C,
+                            o.out_coff, b.H, b.W, prm<float>(grads, o.p[2]), prm<float>(grads, o.p[3]), prm<float>(grads, o.p[4]),
+                            prm<float>(grads, o.p[5]), b.N, o.out_C, o.i[0], stream);
         break;
       }
       default:

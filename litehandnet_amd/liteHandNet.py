@@ -4,7 +4,7 @@ attribute names and state_dict keys as the reference."""
 from torch import nn
 
 from . import _lib
-from .common import ChannelAttension
+from .common import ChannelAttension, SEBlock
 from .engine import PlanModule
 from .repblocks import RepBlock, RepConv, act_slope
 
@@ -96,7 +96,7 @@ class MSAB(PlanModule):
         elif ca_type == "none":
             self.ca = nn.Identity()
         elif ca_type == "se":
-            raise _lib.LhnError("SEBlock attention is outside the built hot path ('ca' | 'none')")
+            self.ca = SEBlock(out_c, internal_neurons=out_c // 16)      # liteHandNet.py:147-148
         else:
             raise ValueError(f"<ca_type={ca_type!r}> not in se|ca|none")
         self.mid_c = m
@@ -111,7 +111,7 @@ class MSAB(PlanModule):
                 branch[1].emit(pb, t, out=pb.slice(cat, j * half, half))
             m = cat
         y = self.conv2.emit(pb, pb.ew([m, x]))
-        if isinstance(self.ca, ChannelAttension):
+        if isinstance(self.ca, (ChannelAttension, SEBlock)):
             y = self.ca.emit(pb, y)
         return y
 

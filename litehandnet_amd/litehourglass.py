@@ -4,7 +4,7 @@ import torch
 from torch import nn
 
 from . import _lib
-from .common import ChannelAttension
+from .common import ChannelAttension, SEBlock
 from .engine import Engine, PlanModule
 from .repblocks import RepConv
 
@@ -13,7 +13,7 @@ def _make_ca(ca_type, channels, p_drop):
     if ca_type == "ca":
         return ChannelAttension(channels, p_drop=p_drop)
     if ca_type == "se":
-        raise _lib.LhnError("SEBlock attention is outside the built hot path ('ca' | 'none')")
+        return SEBlock(channels, internal_neurons=channels // 16)       # litehourglass.py:33-35, 64-66
     return nn.Identity()
 
 
@@ -35,7 +35,7 @@ class MSRB(PlanModule):
             lr = pb.new(acc.H, acc.W, 2 * h)
             b1.emit(pb, pb.slice(acc, 0, h), out=pb.slice(lr, 0, h))
             b2.emit(pb, pb.slice(acc, h, h), out=pb.slice(lr, h, h))
-            if isinstance(ca, ChannelAttension):
+            if isinstance(ca, (ChannelAttension, SEBlock)):
                 lr = ca.emit(pb, lr)
             acc = pb.ew([acc, lr] + ([x] if r == 1 else []))     # the last add also folds `out + x`
         return self.conv.emit(pb, acc, out=out)
@@ -58,7 +58,7 @@ class RepBasicUnit(PlanModule):
 
     def emit(self, pb, x, out=None):
         L = self.left_part
-        gated = isinstance(self.ca, ChannelAttension)
+        gated = isinstance(self.ca, (ChannelAttension, SEBlock))
         y = out if (out is not None and not gated) else pb.new(x.H, x.W, L + self.right_part_out)
         pb.ew([pb.slice(x, 0, L)], out=pb.slice(y, 0, L))                       # left half passes through
         t = self.conv[0].emit(pb, pb.slice(x, L, self.right_part_in))

@@ -23,8 +23,8 @@ from . import _lib
 from ._lib import Buf, Op
 
 # op kinds (must match csrc/lhn_plan.cpp)
-STEM, PW, DW, KXK, FINALIZE, EW, MAXPOOL, AVGPOOL, CA_MLP, TABLE_FILL, MEMSET, ATT_MLP = range(1, 13)
-STEM_BWD, PW_BWD, DW_BWD, KXK_BWD, BN_BWD, EW_BWD, MAXPOOL_BWD, AVGPOOL_BWD, GATE_REDUCE, CA_MLP_BWD, ATT_MLP_BWD = range(101, 112)
+STEM, PW, DW, KXK, FINALIZE, EW, MAXPOOL, AVGPOOL, CA_MLP, TABLE_FILL, MEMSET, ATT_MLP, SE_MLP = range(1, 14)
+STEM_BWD, PW_BWD, DW_BWD, KXK_BWD, BN_BWD, EW_BWD, MAXPOOL_BWD, AVGPOOL_BWD, GATE_REDUCE, CA_MLP_BWD, ATT_MLP_BWD, SE_MLP_BWD = range(101, 113)
 SLOPE_SILU = 2.0       # LHN_SLOPE_SILU in include/lhn.h: the combine applies SiLU instead of a leaky ReLU
 
 ALIGN = 256
@@ -239,6 +239,22 @@ class PlanBuilder:
         b.gate = True
         return y
 
+    def se_attention(self, y, se):
+        """SEBlock (common.py:23-37) on the WHOLE buffer behind `y` (square maps: avg_pool2d(kernel=W) is global)."""
+        b = self.bufs[y.buf]
+        assert y.coff == 0 and y.C == b.C and not b.gate, "attention gates a whole, ungated buffer"
+        if y.H != y.W:
+            raise _lib.LhnError("SEBlock pools with kernel_size = width: only square maps are built")
+        Cc, J = y.C, se.down.weight.shape[0]
+        rec = dict(op=SE_MLP, y=y, se=se, J=J, pooled=self._ws("misc", self.N * Cc * 4),
+                   save=self._ws("misc", self.N * (J + Cc) * 4))
+        if self.with_backward:
+            rec["dgate"] = self._ws("misc", self.N * Cc * 4)
+            b.dpool = True
+        self.recs.append(rec)
+        b.gate = True
+        return y
+
     def set_output(self, y):
         """Generic (block-level) output: materialise the consumed value into a plain buffer."""
         self.out_ref = self.ew([y])
@@ -376,6 +392,12 @@ class PlanBuilder:
                                  self._p(ca.conv1x1[3].weight), self._p(ca.conv1x1[3].bias)),
                               ws=(self._abs(r["pooled"]), self._abs(r["save"]), self._abs(r["mask"])),
                               f=(1e-5, 0.1)))
+            elif k == SE_MLP:
+                y, se = r["y"], r["se"]
+                fwd.append(mk(AVGPOOL, ins=(y,), ws=(self._abs(r["pooled"]),), i=(1, 1, 1)))
+                fwd.append(mk(SE_MLP, out=y, p=(self._p(se.down.weight), self._p(se.down.bias), self._p(se.up.weight),
+                                               self._p(se.up.bias)),
+                              ws=(self._abs(r["pooled"]), self._abs(r["save"])), i=(r["J"],)))
             elif k == ATT_MLP:
                 y, att = r["y"], r["att"]
                 bn, dw, lin = att[1], att[3], att[6]
@@ -471,6 +493,13 @@ class PlanBuilder:
                     mode = self._grad_mode(written, r["x"])
                     body.append(mk(AVGPOOL_BWD, ins=(r["x"],), ws=(self.bufs[r["out"].buf].off["grad"],),
                                    i=(r["OH"], r["OW"], 1 if mode == 2 else 0)))
+                elif k == SE_MLP:
+                    y, se = r["y"], r["se"]
+                    body.append(mk(GATE_REDUCE, out=y, ws=(-1, -1, -1, self._abs(r["dgate"]))))
+                    body.append(mk(SE_MLP_BWD, out=y,
+                                   p=(self._p(se.down.weight), self._p(se.up.weight), self._p(se.down.weight),
+                                      self._p(se.down.bias), self._p(se.up.weight), self._p(se.up.bias)),
+                                   ws=(self._abs(r["pooled"]), self._abs(r["save"]), -1, self._abs(r["dgate"])), i=(r["J"],)))
                 elif k == ATT_MLP:
                     y, att = r["y"], r["att"]
                     bn, dw, lin = att[1], att[3], att[6]

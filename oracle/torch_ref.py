@@ -186,9 +186,25 @@ class ChannelAttension(nn.Module):
         _swap_in(self, "rbr_reparam", self.conv3x3.conv, k, b, ("conv3x3",))
 
 
+class SEBlock(nn.Module):
+    """common.py:23-37: x * sigmoid(up(relu(down(avg_pool2d(x, kernel = width)))))."""
+
+    def __init__(self, c, internal):
+        super().__init__()
+        self.down = nn.Conv2d(c, internal, 1)
+        self.up = nn.Conv2d(internal, c, 1)
+        self.input_channels = c
+
+    def forward(self, x):
+        g = torch.sigmoid(self.up(F.relu(self.down(F.avg_pool2d(x, kernel_size=x.size(3))))))
+        return x * g.view(-1, self.input_channels, 1, 1)
+
+
 def _make_ca(kind, c, p_drop):
     if kind == "ca":
         return ChannelAttension(c, p_drop)
+    if kind == "se":
+        return SEBlock(c, c // 16)
     if kind == "none":
         return nn.Identity()
     raise ValueError(f"ca_type {kind!r}: the hot path covers 'ca' and 'none' only")
@@ -203,7 +219,7 @@ class MSRB(nn.Module):
         h = cin // 2
         self.branch1 = nn.ModuleList([RepConv(h, h, 3, 1, 1, groups=h, activation=None) for _ in range(2)])
         self.branch2 = nn.ModuleList([RepConv(h, h, 3, 1, 2, 2, groups=h, activation=None) for _ in range(2)])
-        self.ca = nn.ModuleList([_make_ca(ca_type if ca_type == "ca" else "none", cout, p_drop) for _ in range(2)])
+        self.ca = nn.ModuleList([_make_ca(ca_type, cout, p_drop) for _ in range(2)])
         self.conv = RepConv(cin, cout, 1, 1, 0)
 
     def forward(self, x):

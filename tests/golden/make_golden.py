@@ -150,6 +150,12 @@ def main():
     assert np.array_equal(yr, yo)
     np.savez_compressed(os.path.join(HERE, "model_M_64_eval.npz"), seed=11, heatmap=yr, weights_seed=10)
 
+    # ---- variant B with squeeze-and-excitation gates (msrb_ca = rbu_ca = 'se': config/litehandnet/*_h4_se_none.py)
+    cfgS = litehandnet_cfg("B", msrb_ca="se", rbu_ca="se")
+    rS, oS = ref_b.LiteHandNet(cfgS), torch_ref.get_model(cfgS)
+    assert list(rS.state_dict()) == list(oS.state_dict())
+    _model_case(rS, oS, 8, 64, 12, "Bse_64", out)
+
     # ---- variant B with CA everywhere + rbu_ca='ca' (exercise gates in the hourglass), eval-mode BN too
     cfgB2 = litehandnet_cfg("B", rbu_ca="ca")
     rB2, oB2 = ref_b.LiteHandNet(cfgB2), torch_ref.get_model(cfgB2)

@@ -508,3 +508,17 @@ def test_sync_batchnorm_two_emulated_ranks(dev, variant):
     for (k, a), (_, b) in zip(reps[0].state_dict().items(), full.state_dict().items()):
         if k.endswith("running_mean") or k.endswith("running_var"):
             assert torch.allclose(a, b, rtol=1e-4, atol=1e-6), k
+
+
+# ---------------------------------------------------------------- squeeze-and-excitation gates ('se')
+def test_se_blocks_and_model(dev, golden_dir):
+    """ca_type / msrb_ca / rbu_ca = 'se' (common.py:23-37; config/litehandnet/*_h4_se_none.py): the blocks against the
+    float64 oracle, the whole variant-B model against the reference-generated fixture."""
+    from litehandnet_amd import litehourglass as lh, liteHandNet as la
+    from litehandnet_amd.common import ChannelAttension, SEBlock
+    _check_block(SEBlock(64, 4), torch_ref.SEBlock(64, 4), _x(4, 64, 12, 12), dev, seed=60)
+    _check_block(ChannelAttension(64, p_drop=0.0), torch_ref.ChannelAttension(64, 0.0), _x(8, 64, 12, 12), dev, seed=64)
+    _check_block(lh.MSRB(64, 64, "se", p_drop=0.0), torch_ref.MSRB(64, 64, "se", 0.0), _x(4, 64, 16, 16), dev, seed=61)
+    _check_block(lh.RepBasicUnit(64, 64, "se", p_drop=0.0), torch_ref.RepBasicUnit(64, 64, "se", 0.0), _x(4, 64, 12, 12), dev, seed=62)
+    _check_block(la.MSAB(128, 128, "se", p_drop=0.0), torch_ref.MSAB(128, 128, "se", p_drop=0.0), _x(4, 128, 16, 16), dev, seed=63)
+    _model_case(dev, golden_dir, "Bse_64", variant="B", msrb_ca="se", rbu_ca="se")

@@ -77,6 +77,10 @@ def test_model_M_128(golden_dir):
     assert np.abs(y - g["heatmap"]).max() <= 1e-5 * np.abs(g["heatmap"]).max()
 
 
+def test_model_Bse_64(golden_dir):
+    _run_case(golden_dir, "Bse_64", "B", msrb_ca="se", rbu_ca="se")
+
+
 def test_eval_mode(golden_dir):
     for tag, variant, wseed in (("B", "B", 5), ("A", "A", 6)):
         g = np.load(os.path.join(golden_dir, f"model_{tag}_64_eval.npz"))
