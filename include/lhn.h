@@ -97,6 +97,17 @@ int lhn_transform_preds(const float* coords /*[N,K,2]*/, const float* center /*[
 int lhn_heatmap_decode(const float* hm, const float* center, const float* scale, float* hm_preds,
                        float* preds, float* maxvals, int N, int K, int H, int W, int post_process,
                        void* stream);
+/* SimDR (cfg.PIPELINE.simdr_split_ratio = k > 0): 1-D Gaussian target vectors (generate_simder.py:9-31) and the
+ * auxiliary loss on the decoded vectors (centernet_simdr_loss.py:6-71: per joint, SmoothL1 'mean' over [N, L] times the
+ * MEAN of that joint's weights, x and y, averaged over joints).  The two shared Linear decoders are plain library
+ * GEMMs on the caller's side; decoding the vectors is lhn_heatmap_argmax on [N,K,1,L] + lhn_transform_preds.
+ * sums = double[3*K] scratch shared by fwd and bwd. */
+int lhn_simdr_encode(const float* joints /*[N,K,3]*/, const float* visible, int vis_stride, float* target_x /*[N,K,Wd]*/,
+                     float* target_y /*[N,K,Hd]*/, int N, int K, int Wd, int Hd, float k, float sigma, void* stream);
+int lhn_simdr_loss_fwd(const float* px, const float* py, const float* tx, const float* ty, const float* weight /*[N,K]*/,
+                       double* sums, float* loss, int N, int K, int Wd, int Hd, void* stream);
+int lhn_simdr_loss_bwd(const float* px, const float* py, const float* tx, const float* ty, const double* sums,
+                       const float* gout, float* dpx, float* dpy, int N, int K, int Wd, int Hd, void* stream);
 /* DARK 'unbiased' decode: k x k Gaussian modulation + log + Taylor step (top_down_eval.py:233-272,338-372,433-439;
  * twin utils/heatmap_post_processing.py:35-91), fused with argmax and transform_preds */
 int lhn_heatmap_decode_dark(const float* hm, const float* center, const float* scale, float* hm_preds,

@@ -543,3 +543,110 @@ extern "C" int lhn_heatmap_decode_dark(const float* hm, const float* center, con
   LHN_CHECK_LAUNCH("lhn_heatmap_decode_dark");
   return 0;
 }
+
+// ------------------------------------------------------------------ SimDR (1-D coordinate classification vectors)
+// targets: datasets/data_pipeline/generate_simder.py:9-31; loss: loss/centernet_simdr_loss.py:6-71 (KLDiscretLoss with
+// SmoothL1 'mean' + the per-joint weight quirk); decode reuses lhn_heatmap_argmax / lhn_transform_preds.
+__global__ void __launch_bounds__(256) k_simdr_encode(const float* __restrict__ joints, const float* __restrict__ vis, int vis_stride,
+                                                      float* __restrict__ tx, float* __restrict__ ty, int Wd, int Hd, float k,
+                                                      float sigma) {
+  const int nk = blockIdx.x;
+  const bool on = vis[(size_t)nk * vis_stride] > 0.f;
+  const float mux = mul_rn(joints[(size_t)nk * 3 + 0], k), muy = mul_rn(joints[(size_t)nk * 3 + 1], k);
+  const float den = 2.f * sigma * sigma;
+  for (int i = threadIdx.x; i < Wd; i += blockDim.x) {
+    const float d = sub_rn((float)i, mux);
+    tx[(size_t)nk * Wd + i] = on ? expf(-mul_rn(d, d) / den) : 0.f;
+  }
+  for (int i = threadIdx.x; i < Hd; i += blockDim.x) {
+    const float d = sub_rn((float)i, muy);
+    ty[(size_t)nk * Hd + i] = on ? expf(-mul_rn(d, d) / den) : 0.f;
+  }
+}
+
+__device__ __forceinline__ float smooth_l1(float d) {
+  const float a = fabsf(d);
+  return a < 1.f ? 0.5f * d * d : a - 0.5f;
+}
+// one block per joint index: sums[idx] = sum_{b,i} smoothl1(px - tx), sums[K + idx] = same for y, sums[2K + idx] = sum_b w
+__global__ void __launch_bounds__(256) k_simdr_loss_sums(const float* __restrict__ px, const float* __restrict__ py,
+                                                         const float* __restrict__ tx, const float* __restrict__ ty,
+                                                         const float* __restrict__ w, double* __restrict__ sums, int N, int K,
+                                                         int Wd, int Hd) {
+  __shared__ double rs[256], rq[256];
+  const int idx = blockIdx.x;
+  double sx = 0, sy = 0;
+  for (int b = 0; b < N; ++b) {
+    const size_t ox = ((size_t)b * K + idx) * Wd, oy = ((size_t)b * K + idx) * Hd;
+    for (int i = threadIdx.x; i < Wd; i += blockDim.x) sx += smooth_l1(px[ox + i] - tx[ox + i]);
+    for (int i = threadIdx.x; i < Hd; i += blockDim.x) sy += smooth_l1(py[oy + i] - ty[oy + i]);
+  }
+  rs[threadIdx.x] = sx;
+  rq[threadIdx.x] = sy;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      rs[threadIdx.x] += rs[threadIdx.x + o];
+      rq[threadIdx.x] += rq[threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    double sw = 0;
+    for (int b = 0; b < N; ++b) sw += w[(size_t)b * K + idx];
+    sums[idx] = rs[0];
+    sums[K + idx] = rq[0];
+    sums[2 * K + idx] = sw;
+  }
+}
+__global__ void k_simdr_loss_final(const double* __restrict__ sums, float* __restrict__ loss, int N, int K, int Wd, int Hd) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double l = 0;
+    for (int idx = 0; idx < K; ++idx) {
+      const double mw = sums[2 * K + idx] / N;
+      l += (sums[idx] / ((double)N * Wd) + sums[K + idx] / ((double)N * Hd)) * mw;
+    }
+    loss[0] = (float)(l / K);
+  }
+}
+// d loss / d px = gout * mean_w[idx] / (K * N * Wd) * smoothl1'(px - tx)
+__global__ void __launch_bounds__(256) k_simdr_loss_bwd(const float* __restrict__ p, const float* __restrict__ t,
+                                                        const double* __restrict__ sums, const float* __restrict__ gout,
+                                                        float* __restrict__ dp, int N, int K, int L) {
+  const size_t total = (size_t)N * K * L;
+  const float g = gout[0];
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int idx = (int)((i / L) % K);
+    const float c = g * (float)(sums[2 * K + idx] / N / ((double)K * N * L));
+    const float d = p[i] - t[i];
+    dp[i] = c * (fabsf(d) < 1.f ? d : (d > 0.f ? 1.f : -1.f));
+  }
+}
+
+extern "C" int lhn_simdr_encode(const float* joints, const float* visible, int vis_stride, float* target_x, float* target_y, int N,
+                                int K, int Wd, int Hd, float k, float sigma, void* stream) {
+  LHN_CHECK_ARG(joints && visible && target_x && target_y && N > 0 && K > 0 && Wd > 0 && Hd > 0 && k > 0 && sigma > 0,
+                "lhn_simdr_encode: bad argument");
+  hipLaunchKernelGGL(k_simdr_encode, dim3(N * K), dim3(256), 0, (hipStream_t)stream, joints, visible, vis_stride, target_x, target_y,
+                     Wd, Hd, k, sigma);
+  LHN_CHECK_LAUNCH("lhn_simdr_encode");
+  return 0;
+}
+extern "C" int lhn_simdr_loss_fwd(const float* px, const float* py, const float* tx, const float* ty, const float* weight,
+                                  double* sums, float* loss, int N, int K, int Wd, int Hd, void* stream) {
+  LHN_CHECK_ARG(px && py && tx && ty && weight && sums && loss && N > 0 && K > 0 && Wd > 0 && Hd > 0, "lhn_simdr_loss_fwd: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_simdr_loss_sums, dim3(K), dim3(256), 0, s, px, py, tx, ty, weight, sums, N, K, Wd, Hd);
+  hipLaunchKernelGGL(k_simdr_loss_final, dim3(1), dim3(64), 0, s, sums, loss, N, K, Wd, Hd);
+  LHN_CHECK_LAUNCH("lhn_simdr_loss_fwd");
+  return 0;
+}
+extern "C" int lhn_simdr_loss_bwd(const float* px, const float* py, const float* tx, const float* ty, const double* sums,
+                                  const float* gout, float* dpx, float* dpy, int N, int K, int Wd, int Hd, void* stream) {
+  LHN_CHECK_ARG(px && py && tx && ty && sums && gout && dpx && dpy, "lhn_simdr_loss_bwd: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_simdr_loss_bwd, dim3(512), dim3(256), 0, s, px, tx, sums, gout, dpx, N, K, Wd);
+  hipLaunchKernelGGL(k_simdr_loss_bwd, dim3(512), dim3(256), 0, s, py, ty, sums, gout, dpy, N, K, Hd);
+  LHN_CHECK_LAUNCH("lhn_simdr_loss_bwd");
+  return 0;
+}

@@ -149,6 +149,62 @@ def keypoint_pck_accuracy(pred, gt, mask, thr, normalize):
     return acc, float(a[0]), int(a[1])
 
 
+def generate_simdr_batch(joints, visible, image_size, k=2, sigma=2):
+    """GenerateSimDR._generate_sa_simdr (generate_simder.py:9-31) for a whole batch on the device:
+    joints [N,K,3], visible [N,K,1|3] -> (simdr_x [N,K,W*k], simdr_y [N,K,H*k])."""
+    j = _lib.f32c(_dev(joints))
+    v = _lib.f32c(_dev(visible, j.device))
+    N, K = j.shape[0], j.shape[1]
+    Wd, Hd = int(image_size[0] * int(k)), int(image_size[1] * int(k))
+    tx = torch.empty((N, K, Wd), dtype=torch.float32, device=j.device)
+    ty = torch.empty((N, K, Hd), dtype=torch.float32, device=j.device)
+    _lib.check(_lib.lib().lhn_simdr_encode(_lib.ptr(j), _lib.ptr(v), v.shape[-1], _lib.ptr(tx), _lib.ptr(ty), N, K, Wd, Hd,
+                                           _lib.C.c_float(float(int(k))), _lib.C.c_float(float(sigma)), _lib.stream()),
+               "lhn_simdr_encode")
+    return tx, ty
+
+
+class GenerateSimDR:
+    """generate_simder.py:3-42 -- per-sample `results` dict contract kept; `.batch()` is the device-resident form."""
+
+    def __init__(self, sigma=2, k=2):
+        self.sigma = sigma
+        self.k = int(k)
+        self.with_simdr = k > 0 and not isinstance(sigma, (list, tuple))
+
+    def batch(self, joints, visible, image_size):
+        return generate_simdr_batch(joints, visible, image_size, self.k, self.sigma)
+
+    def __call__(self, results):
+        if self.with_simdr:
+            tx, ty = generate_simdr_batch(torch.as_tensor(results["joints_3d"])[None], torch.as_tensor(results["joints_3d_visible"])[None],
+                                          results["ann_info"]["image_size"], self.k, self.sigma)
+            results["simdr_x"], results["simdr_y"] = tx[0], ty[0]
+        return results
+
+
+def keypoints_from_simdr(x_vectors, y_vectors, center, scale, k=2):
+    """top_down_eval.py:466-500: argmax of each 1-D vector / k, score = mean of the two maxima, back-transform with the
+    un-scaled map size.  Returns [N,K,3] on the device."""
+    assert k > 0
+    xv = _lib.f32c(_dev(x_vectors))
+    yv = _lib.f32c(_dev(y_vectors, xv.device))
+    N, K, Wd = xv.shape
+    Hd = yv.shape[2]
+    def argmax1d(v, L):
+        idx = torch.empty((N, K), dtype=torch.int32, device=v.device)
+        mv = torch.empty((N, K, 1), dtype=torch.float32, device=v.device)
+        scratch = torch.empty((N, K, 2), dtype=torch.float32, device=v.device)
+        _lib.check(_lib.lib().lhn_heatmap_argmax(_lib.ptr(v), _lib.ptr(scratch), _lib.ptr(mv), _lib.ptr(idx), N, K, 1, L,
+                                                 _lib.stream()), "lhn_heatmap_argmax")
+        return idx.to(torch.float32).unsqueeze(2), mv      # plain first-maximum index (no "-1 where max <= 0" masking)
+    ix, mx = argmax1d(xv, Wd)
+    iy, my = argmax1d(yv, Hd)
+    preds = torch.cat([ix, iy], dim=2) / float(k)
+    out = transform_preds(preds, center, scale, [Wd // k, Hd // k])
+    return torch.cat([out, (mx + my) / 2], dim=2)
+
+
 class TopDownDecoder:
     """utils/post_processing/decoder.py:9-71."""
 

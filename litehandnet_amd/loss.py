@@ -77,6 +77,56 @@ class DistanceLoss(nn.Module):
         return _BalancedMSE.apply(output, target, target_weight, loss_weight, self.balance)
 
 
+class _SimDRSmoothL1(torch.autograd.Function):
+    """KLDiscretLoss (centernet_simdr_loss.py:6-39) on the decoded vectors: lhn_simdr_loss_fwd / _bwd."""
+
+    @staticmethod
+    def forward(ctx, px, py, tx, ty, w):
+        N, K, Wd = px.shape
+        Hd = py.shape[2]
+        px, py, tx, ty, w = (_lib.f32c(t) for t in (px, py, tx, ty, w.reshape(N, K)))
+        sums = torch.empty(3 * K, dtype=torch.float64, device=px.device)
+        loss = torch.empty(1, dtype=torch.float32, device=px.device)
+        _lib.check(_lib.lib().lhn_simdr_loss_fwd(_lib.ptr(px), _lib.ptr(py), _lib.ptr(tx), _lib.ptr(ty), _lib.ptr(w),
+                                                 _lib.ptr(sums), _lib.ptr(loss), N, K, Wd, Hd, _lib.stream()),
+                   "lhn_simdr_loss_fwd")
+        ctx.save_for_backward(px, py, tx, ty, sums)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        px, py, tx, ty, sums = ctx.saved_tensors
+        N, K, Wd = px.shape
+        dpx, dpy = torch.empty_like(px), torch.empty_like(py)
+        g = _lib.f32c(gout.reshape(1))
+        _lib.check(_lib.lib().lhn_simdr_loss_bwd(_lib.ptr(px), _lib.ptr(py), _lib.ptr(tx), _lib.ptr(ty), _lib.ptr(sums),
+                                                 _lib.ptr(g), _lib.ptr(dpx), _lib.ptr(dpy), N, K, Wd, py.shape[2],
+                                                 _lib.stream()), "lhn_simdr_loss_bwd")
+        return dpx, dpy, None, None, None
+
+
+class SimDRLoss(nn.Module):
+    """centernet_simdr_loss.py:42-71: two shared Linear decoders heatmap[H*W] -> 1-D x / y vectors (plain library GEMMs:
+    torch -> rocBLAS) and the SmoothL1 loss above.  Same attribute names / state_dict keys as the reference."""
+
+    def __init__(self, cfg=None):
+        super().__init__()
+        k = cfg.PIPELINE.simdr_split_ratio
+        self.simdr_width = int(k * cfg.DATASET.image_size[0])
+        self.simdr_height = int(k * cfg.DATASET.image_size[1])
+        in_features = int(cfg.DATASET.heatmap_size[0] * cfg.DATASET.heatmap_size[1])
+        self.x_shared_decoder = nn.Linear(in_features, self.simdr_width)
+        self.y_shared_decoder = nn.Linear(in_features, self.simdr_height)
+
+    def decode(self, heatmap):
+        flat = heatmap.flatten(start_dim=2)
+        return self.x_shared_decoder(flat), self.y_shared_decoder(flat)
+
+    def forward(self, heatmap, simdr_x, simdr_y, target_weight):
+        px, py = self.decode(heatmap)
+        return _SimDRSmoothL1.apply(px, py, simdr_x, simdr_y, target_weight)
+
+
 class TopdownHeatmapLoss(nn.Module):
     """loss.py:69-114.  meta['target'] [N,K,H,W], meta['target_weight'] [N,K,1] may live on CPU or device."""
 
@@ -84,8 +134,7 @@ class TopdownHeatmapLoss(nn.Module):
         super().__init__()
         self.heatmap_loss = DistanceLoss(loss_type=cfg.LOSS.get("dl_type", "L2"), reduction="mean",
                                          balance=cfg.MODEL.name != "atthandnet")
-        if cfg.PIPELINE.simdr_split_ratio > 0:
-            raise _lib.LhnError("SimDR loss is outside the hot path (simdr_split_ratio must be 0)")
+        self.simdr_loss = SimDRLoss(cfg) if cfg.PIPELINE.simdr_split_ratio > 0 else None      # loss.py:81-85
         self.loss_weight = cfg.LOSS.loss_weight
         if cfg.LOSS.auto_weight:
             raise _lib.LhnError("LOSS.auto_weight is outside the hot path")
@@ -95,7 +144,13 @@ class TopdownHeatmapLoss(nn.Module):
         target = meta["target"].to(device, non_blocking=True)
         weight = meta["target_weight"].to(device, non_blocking=True)
         loss = self.heatmap_loss(output, target, weight, float(self.loss_weight[0]))
-        return loss, {"heatmap": DeviceScalar(loss)}
+        loss_dict = {"heatmap": DeviceScalar(loss)}
+        if self.simdr_loss is not None:                                                        # loss.py:102-106
+            ls = float(self.loss_weight[1]) * self.simdr_loss(output, meta["simdr_x"].to(device, non_blocking=True),
+                                                              meta["simdr_y"].to(device, non_blocking=True), weight)
+            loss_dict["simdr"] = DeviceScalar(ls)
+            loss = loss + ls
+        return loss, loss_dict
 
 
 topdownheatmaploss = TopdownHeatmapLoss

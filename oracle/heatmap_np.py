@@ -232,3 +232,34 @@ def keypoint_epe(pred, gt, mask):
     d = _calc_distances(pred, gt, mask, np.ones((pred.shape[0], pred.shape[2]), np.float32))
     v = d[d != -1]
     return v.sum() / max(1, len(v))
+
+
+def generate_sa_simdr(joints, target_weight, image_size, k=2, sigma=2):
+    """datasets/data_pipeline/generate_simder.py:9-31 for one sample: joints [K,3], target_weight [K,1|3]."""
+    k = int(k)
+    K = joints.shape[0]
+    tx = np.zeros((K, int(image_size[0] * k)), np.float32)
+    ty = np.zeros((K, int(image_size[1] * k)), np.float32)
+    for j in range(K):
+        if target_weight[j][0] > 0:
+            mu_x, mu_y = joints[j, :2] * k
+            x = np.arange(0, int(image_size[0] * k), 1, np.float32)
+            y = np.arange(0, int(image_size[1] * k), 1, np.float32)
+            tx[j] = np.exp(-((x - mu_x) ** 2) / (2 * sigma ** 2))
+            ty[j] = np.exp(-((y - mu_y) ** 2) / (2 * sigma ** 2))
+    return tx, ty
+
+
+def keypoints_from_simdr(x_vectors, y_vectors, center, scale, k=2):
+    """utils/post_processing/evaluation/top_down_eval.py:466-500."""
+    B, K, W = x_vectors.shape
+    H = y_vectors.shape[2]
+    preds = np.zeros((B, K, 2), np.float32)
+    scores = np.zeros((B, K, 1), np.float32)
+    for i in range(B):
+        xi, yi = x_vectors[i].argmax(1).reshape(-1, 1), y_vectors[i].argmax(1).reshape(-1, 1)
+        preds[i] = np.concatenate([xi, yi], 1) / k
+        scores[i] = (x_vectors[i].max(1).reshape(-1, 1) + y_vectors[i].max(1).reshape(-1, 1)) / 2
+    for i in range(B):
+        preds[i] = transform_preds(preds[i], center[i], scale[i], [W // k, H // k], use_udp=False)
+    return np.concatenate([preds, scores], 2)

@@ -659,16 +659,45 @@ def distance_loss(output, target, target_weight, balance=True, thr=0.5):
     return l.mean()
 
 
+class SimDRLoss(nn.Module):
+    """loss/centernet_simdr_loss.py:6-71.  Per joint: SmoothL1 (mean over [N, L]) times the MEAN of that joint's weights
+    (the reference multiplies a scalar by the weight vector and takes the mean), x and y, averaged over the joints."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        k = cfg.PIPELINE.simdr_split_ratio
+        self.simdr_width, self.simdr_height = int(k * cfg.DATASET.image_size[0]), int(k * cfg.DATASET.image_size[1])
+        feat = int(cfg.DATASET.heatmap_size[0] * cfg.DATASET.heatmap_size[1])
+        self.x_shared_decoder = nn.Linear(feat, self.simdr_width)
+        self.y_shared_decoder = nn.Linear(feat, self.simdr_height)
+
+    def forward(self, heatmap, simdr_x, simdr_y, target_weight):
+        flat = heatmap.flatten(start_dim=2)
+        px, py = self.x_shared_decoder(flat), self.y_shared_decoder(flat)
+        K = px.size(1)
+        total = 0
+        for j in range(K):
+            mw = target_weight[:, j].reshape(-1).mean()
+            total = total + F.smooth_l1_loss(px[:, j], simdr_x[:, j]) * mw + F.smooth_l1_loss(py[:, j], simdr_y[:, j]) * mw
+        return total / K
+
+
 class TopdownHeatmapLoss(nn.Module):
-    """loss/loss.py:69-114 with simdr_split_ratio == 0 and auto_weight False."""
+    """loss/loss.py:69-114 with auto_weight False (SimDR auxiliary loss when simdr_split_ratio > 0)."""
 
     def __init__(self, cfg):
         super().__init__()
         self.balance = cfg.MODEL.name != "atthandnet"
         self.loss_weight = cfg.LOSS.loss_weight
+        self.simdr_loss = SimDRLoss(cfg) if cfg.PIPELINE.simdr_split_ratio > 0 else None
 
     def forward(self, output, meta):
         t = meta["target"].to(output.device)
         w = meta["target_weight"].to(output.device)
         loss = self.loss_weight[0] * distance_loss(output, t, w, self.balance)
-        return loss, {"heatmap": loss.item()}
+        d = {"heatmap": loss.item()}
+        if self.simdr_loss is not None:
+            ls = self.loss_weight[1] * self.simdr_loss(output, meta["simdr_x"], meta["simdr_y"], w)
+            d["simdr"] = ls.item()
+            loss = loss + ls
+        return loss, d

@@ -53,6 +53,14 @@ def _load_reference():
     return ref_models, ref_b, RefLoss, pt, gt, ev
 
 
+def by_path_ref(dotted, rel):
+    spec = importlib.util.spec_from_file_location(dotted, os.path.join(REF, rel))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[dotted] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
 def _no_dropout(model):
     for m in model.modules():
         if isinstance(m, (torch.nn.Dropout2d, torch.nn.Dropout)):
@@ -185,6 +193,42 @@ def main():
                             weights_seed={"B": 5, "A": 6}[tag], n_params=sum(p.numel() for p in rm.parameters()),
                             n_keys=len(sr), keys=np.array(list(sr)), abs_sums=np.array([float(v.double().abs().sum()) for v in sr.values()]),
                             **{"t_" + k: sr[k].numpy() for k in pick})
+
+    # ---- SimDR (cfg.PIPELINE.simdr_split_ratio = 2): targets, loss through the shared decoders, decode
+    from loss.centernet_simdr_loss import SimDRLoss as RefSimDR
+    gs = by_path_ref("ref_generate_simder", "datasets/data_pipeline/generate_simder.py")
+    cfgS2 = litehandnet_cfg("B")
+    cfgS2.PIPELINE["simdr_split_ratio"] = 2
+    js = synth.synth_joints(4, 21, 256, 31, margin=0.05)
+    vs = np.ones_like(js); vs[1, 4] = 0; vs[2, :] = 0
+    G = gs.GenerateSimDR(sigma=2, k=2)
+    sx, sy = zip(*[G._generate_sa_simdr(a, v, [256, 256]) for a, v in zip(js, vs)])
+    sx, sy = np.stack(sx), np.stack(sy)
+    ox, oy = zip(*[onp.generate_sa_simdr(a, v, [256, 256], 2, 2) for a, v in zip(js, vs)])
+    assert np.array_equal(sx, np.stack(ox)) and np.array_equal(sy, np.stack(oy))
+    torch.manual_seed(5)
+    rs, os_ = RefSimDR(cfgS2), torch_ref.SimDRLoss(cfgS2)
+    sdl = synth.synth_state_dict(rs, 33)
+    rs.load_state_dict(sdl); os_.load_state_dict(sdl)
+    hm = torch.from_numpy(np.random.Generator(np.random.PCG64(34)).standard_normal((4, 21, 64, 64)).astype(np.float32) * 0.1)
+    tw = torch.from_numpy(vs[..., :1].copy())
+    res = {}
+    for tag, mod in (("ref", rs), ("ora", os_)):
+        h = hm.clone().requires_grad_()
+        l = mod(h, torch.from_numpy(sx), torch.from_numpy(sy), tw)
+        l.backward()
+        res[tag] = (float(l), h.grad.numpy().copy(), mod.x_shared_decoder.weight.grad.numpy().copy())
+    assert abs(res["ref"][0] - res["ora"][0]) <= 1e-6 * abs(res["ref"][0]), (res["ref"][0], res["ora"][0])
+    assert np.abs(res["ref"][1] - res["ora"][1]).max() <= 1e-6 * np.abs(res["ref"][1]).max()
+    cs = np.stack([[128.0, 120.0], [100.0, 90.0], [64.0, 200.0], [30.0, 31.0]]).astype(np.float32)
+    ss = np.stack([[1.1, 1.1], [0.8, 0.8], [1.5, 1.5], [0.6, 0.6]]).astype(np.float32)
+    kp = ev.keypoints_from_simdr(sx, sy, cs, ss, 2)
+    assert np.array_equal(kp, onp.keypoints_from_simdr(sx, sy, cs, ss, 2))
+    np.savez_compressed(os.path.join(HERE, "simdr.npz"), joints=js, visible=vs, weights_seed=33, hm_seed=34,
+                        loss=np.float64(res["ref"][0]), dheatmap_abs_sum=np.float64(np.abs(res["ref"][1]).sum()),
+                        dheatmap_sample=res["ref"][1][:, ::5, ::16, ::16].copy(),
+                        dwx_abs_sum=np.float64(np.abs(res["ref"][2]).sum()),
+                        tx_sum=sx.sum(2), ty_sum=sy.sum(2), tx_argmax=sx.argmax(2), center=cs, scale=ss, keypoints=kp)
 
     # ---- loss alone (reference loss/heatmapLoss.py:242-265 through loss/loss.py:93-114)
     r = np.random.Generator(np.random.PCG64(21))

@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 import torch
 
+from litehandnet_amd.config import litehandnet_cfg
 from oracle import heatmap_np as onp
 from oracle import synth, torch_ref
 
@@ -148,3 +149,39 @@ def test_decode_dark_unbiased(dev, golden_dir):
     # the Taylor step itself is pinned by the reference's _taylor on the golden log-map (oracle == reference exactly)
     d = heatmap.TopDownDecoder
     assert d is not None
+
+
+def test_simdr_targets_loss_decode(dev, golden_dir):
+    """SimDR (simdr_split_ratio = 2) on the GPU against the reference-generated fixture: target vectors within 2 ulp of
+    numpy's float32 exp (argmax exact), loss <= 2e-6 relative, d(heatmap) 1e-5, decode of the target vectors exact."""
+    from litehandnet_amd import heatmap
+    from litehandnet_amd.loss import SimDRLoss, TopdownHeatmapLoss
+    g = np.load(os.path.join(golden_dir, "simdr.npz"))
+    js, vs = g["joints"], g["visible"]
+    tx, ty = heatmap.generate_simdr_batch(js, vs, [256, 256], 2, 2)
+    ox, oy = zip(*[onp.generate_sa_simdr(a, v, [256, 256], 2, 2) for a, v in zip(js, vs)])
+    ox, oy = np.stack(ox), np.stack(oy)
+    assert np.abs(tx.cpu().numpy() - ox).max() <= 2.5e-7 and np.abs(ty.cpu().numpy() - oy).max() <= 2.5e-7
+    assert np.array_equal(tx.cpu().numpy().argmax(2), g["tx_argmax"])
+    cfg = litehandnet_cfg("B")
+    cfg.PIPELINE["simdr_split_ratio"] = 2
+    m = SimDRLoss(cfg)
+    m.load_state_dict(synth.synth_state_dict(m, int(g["weights_seed"])))
+    m.to(dev)
+    hm = torch.from_numpy(np.random.Generator(np.random.PCG64(int(g["hm_seed"]))).standard_normal((4, 21, 64, 64)).astype(np.float32) * 0.1)
+    hm = hm.to(dev).requires_grad_()
+    w = torch.from_numpy(vs[..., :1].copy()).to(dev)
+    loss = m(hm, torch.from_numpy(ox).to(dev), torch.from_numpy(oy).to(dev), w)
+    loss.backward()
+    assert abs(float(loss) - float(g["loss"])) <= 2e-6 * abs(float(g["loss"]))
+    assert np.abs(hm.grad.cpu().numpy()[:, ::5, ::16, ::16] - g["dheatmap_sample"]).max() <= 1e-5 * np.abs(g["dheatmap_sample"]).max()
+    assert abs(float(m.x_shared_decoder.weight.grad.abs().sum()) - float(g["dwx_abs_sum"])) <= 1e-4 * float(g["dwx_abs_sum"])
+    kp = heatmap.keypoints_from_simdr(ox, oy, g["center"], g["scale"], 2)
+    assert np.array_equal(kp.cpu().numpy(), g["keypoints"])
+    # the combined criterion (loss.py:93-114 with simdr_split_ratio > 0) adds loss_weight[1] * simdr
+    crit = TopdownHeatmapLoss(cfg).to(dev)
+    crit.simdr_loss.load_state_dict(m.state_dict())
+    t = torch.zeros(4, 21, 64, 64, device=dev)
+    tot, d = crit(hm.detach(), {"target": t, "target_weight": w, "simdr_x": torch.from_numpy(ox), "simdr_y": torch.from_numpy(oy)})
+    assert abs(float(d["simdr"]) - 0.1 * float(g["loss"])) <= 1e-5 * float(g["loss"])
+    assert abs(float(tot) - float(d["heatmap"]) - float(d["simdr"])) <= 1e-6 * abs(float(tot))

@@ -153,3 +153,23 @@ def test_loss(golden_dir):
     assert abs(float(l) - float(g["loss"])) < 1e-6 * abs(float(g["loss"]))
     l.backward()
     assert np.allclose(o.grad.numpy()[:, ::5, ::16, ::16], g["grad_sample"], rtol=1e-5, atol=1e-9)
+
+
+def test_simdr(golden_dir):
+    """SimDR targets / loss / decode of the oracle against the reference-generated fixture."""
+    g = np.load(os.path.join(golden_dir, "simdr.npz"))
+    js, vs = g["joints"], g["visible"]
+    sx, sy = zip(*[onp.generate_sa_simdr(a, v, [256, 256], 2, 2) for a, v in zip(js, vs)])
+    sx, sy = np.stack(sx), np.stack(sy)
+    assert np.allclose(sx.sum(2), g["tx_sum"], rtol=1e-6) and np.array_equal(sx.argmax(2), g["tx_argmax"])
+    cfg = litehandnet_cfg("B")
+    cfg.PIPELINE["simdr_split_ratio"] = 2
+    m = torch_ref.SimDRLoss(cfg)
+    m.load_state_dict(synth.synth_state_dict(m, int(g["weights_seed"])))
+    hm = torch.from_numpy(np.random.Generator(np.random.PCG64(int(g["hm_seed"]))).standard_normal((4, 21, 64, 64)).astype(np.float32) * 0.1)
+    hm.requires_grad_()
+    l = m(hm, torch.from_numpy(sx), torch.from_numpy(sy), torch.from_numpy(vs[..., :1].copy()))
+    l.backward()
+    assert abs(float(l) - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
+    assert abs(float(hm.grad.abs().sum()) - float(g["dheatmap_abs_sum"])) <= 1e-4 * float(g["dheatmap_abs_sum"])
+    assert np.array_equal(onp.keypoints_from_simdr(sx, sy, g["center"], g["scale"], 2), g["keypoints"])
