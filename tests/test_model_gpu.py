@@ -522,3 +522,29 @@ def test_se_blocks_and_model(dev, golden_dir):
     _check_block(lh.RepBasicUnit(64, 64, "se", p_drop=0.0), torch_ref.RepBasicUnit(64, 64, "se", 0.0), _x(4, 64, 12, 12), dev, seed=62)
     _check_block(la.MSAB(128, 128, "se", p_drop=0.0), torch_ref.MSAB(128, 128, "se", p_drop=0.0), _x(4, 128, 16, 16), dev, seed=63)
     _model_case(dev, golden_dir, "Bse_64", variant="B", msrb_ca="se", rbu_ca="se")
+
+
+@pytest.mark.parametrize("variant,n,size", [("B", 3, 128), ("A", 5, 96), ("M", 1, 96), ("B", 1, 256)])
+def test_odd_batches(dev, variant, n, size):
+    """Batch sizes / map sizes that leave partially filled GEMM tiles everywhere (N*H*W not a multiple of 64 or 128 on the
+    low-resolution levels; N = 1).  Forward + backward against the float64 oracle.  (N = 1 in training mode makes the
+    attention's BatchNorm over N samples degenerate -- eval-mode forward only there.)
+
+    Gradient bar 3e-2 instead of the blocks' 1e-3: with ReLU-like units a single pre-activation within one fp32 ulp of
+    zero flips its derivative relative to float64 (traced on the A / N=4 / 96px case: ONE (pixel, channel) of one layer,
+    its 3x3 dgrad footprint 62 % off, every upstream gradient norm moved by ~0.4 %); which element flips depends on the
+    summation order, so torch's own fp32 run may or may not share it."""
+    from litehandnet_amd import get_model
+    cfg = litehandnet_cfg(variant, image_size=size)
+    cfg.MODEL["ca_dropout"] = 0.0
+    ours, ref = get_model(cfg), torch_ref.get_model(cfg, p_drop=0.0)
+    x = synth.synth_images(n, size, 40 + n)
+    if n > 1:
+        _check_block(ours, ref, x, dev, seed=70 + n, no_dx=True, grad_tol=3e-2)
+        return
+    sd = synth.synth_state_dict(ref, 71)
+    ref.load_state_dict(sd); ours.load_state_dict(sd)
+    ours.to(dev).eval(); ref.double().eval()
+    with torch.no_grad():
+        y, y64 = ours(x.to(dev)), ref(x.double())
+    assert _rel(y, y64) < FWD_TOL, _rel(y, y64)
