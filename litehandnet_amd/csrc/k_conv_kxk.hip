@@ -315,7 +315,10 @@ template <int CIN, int NTO, int TAPS, bool PLAIN = false>
 __global__ void __launch_bounds__(256) k_kxk_wgrad(lhn_view x, lhn_view y, lhn_gradview gy, float* __restrict__ dw, int stride,
                                                    int cout, int M, int ntiles, int nrep, int64_t rep_stride) {
   constexpr int NTI = CIN / 32, COP = 32 * NTO, LDY = COP + 4, LDX = CIN + 4;
-  constexpr int NDW = (NTO * NTI + 3) / 4;
+  // fewer dW tiles than waves (32 -> 32: one tile): split the 64-pixel K range of a tile over the idle waves; the partial
+  // tiles meet in LDS before the flush
+  constexpr int T = NTO * NTI, KS = T < 4 ? 4 / T : 1;
+  constexpr int NDW = (T * KS + 3) / 4;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* dYs = smem;               // [64][LDY]
   float* Xs = dYs + 64 * LDY;      // [64][LDX]
@@ -388,14 +391,15 @@ __global__ void __launch_bounds__(256) k_kxk_wgrad(lhn_view x, lhn_view y, lhn_g
     issue(tile);
     commit();
     __syncthreads();
+    const int kpart = KS > 1 ? wave % KS : 0;
 #pragma unroll 4
-    for (int ks = 0; ks < 32; ++ks) {
+    for (int ks = kpart * (32 / KS); ks < (kpart + 1) * (32 / KS); ++ks) {
       const float* dyr = dYs + (2 * ks + lh) * LDY + l31;
       const float* xr = Xs + (2 * ks + lh) * LDX + l31;
 #pragma unroll
       for (int t = 0; t < NDW; ++t) {
-        const int tl = wave + 4 * t;
-        if (tl < NTO * NTI) {
+        const int tl = (wave + 4 * t) / KS;
+        if (tl < T) {
           const int it = tl / NTI, jt = tl % NTI;
           accw[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(dyr[32 * it], xr[32 * jt], accw[t], 0, 0, 0);
         }
@@ -405,10 +409,28 @@ __global__ void __launch_bounds__(256) k_kxk_wgrad(lhn_view x, lhn_view y, lhn_g
   }
   const bool exclusive = (int)gridDim.x <= nrep;
   dw += (size_t)(blockIdx.x % nrep) * rep_stride;
+  if (KS > 1) {
+    // K-split: NDW == 1; waves of a tile (wave / KS equal) add their partials through LDS (dYs/Xs are dead), the first
+    // wave of each tile keeps the sum
+    float* part = dYs;                        // [4 waves][16 regs][64 lanes]
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[(wave * 16 + r) * 64 + lane] = accw[0][r];
+    __syncthreads();
+    if (wave % KS == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) v += part[((wave + k) * 16 + r) * 64 + lane];
+        accw[0][r] = v;
+      }
+    }
+  }
 #pragma unroll
   for (int t = 0; t < NDW; ++t) {
-    const int tl = wave + 4 * t;
-    if (tl < NTO * NTI) {
+    const int tl = (wave + 4 * t) / KS;
+    if (tl < T && (KS == 1 || wave % KS == 0)) {
       const int it = tl / NTI, jt = tl % NTI;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
