@@ -486,7 +486,7 @@ struct DwTile {
 template <int K, int DIL>
 __global__ void __launch_bounds__(256) k_dwk_fwd_lds(lhn_view x, const float* __restrict__ w, lhn_view y,
                                                      double* __restrict__ stats, int tiles_h, int tiles_w, int cgroups,
-                                                     lhn_bnfin fin) {
+                                                     lhn_bnfin fin, int ps) {
   constexpr int TH = 8, TW = 32, KK = K * K;
   using T = DwTile<K, DIL, TH, TW>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -494,7 +494,10 @@ __global__ void __launch_bounds__(256) k_dwk_fwd_lds(lhn_view x, const float* __
   f4* red = tile + T::PIX * 8;                             // [256][2]
   f4* wl = red + 512;                                      // [KK][8] weights of this block's channel group
   const int tid = threadIdx.x, c4 = tid & 7, pl = tid >> 3;   // pl = output column 0..31
-  const int ntile = y.N * tiles_h * tiles_w * cgroups;
+  // ps = pixel stride of the lattice a tile lives on.  ps == 2 runs a dilation-2 convolution as FOUR independent
+  // dilation-1 convolutions on the parity sub-lattices (pixels (2i+a, 2j+b) only meet pixels of the same parity): the halo
+  // shrinks from (TH+4)(TW+4) to (TH+2)(TW+2) and every pixel still is one contiguous 128-byte channel group.
+  const int ntile = y.N * ps * ps * tiles_h * tiles_w * cgroups;
   const int cg = blockIdx.x % cgroups;                     // grid % cgroups == 0 (host): fixed per block
   const int cin = x.coff + cg * 32 + 4 * c4, cout = y.coff + cg * 32 + 4 * c4;
   const Xf4 xf = lhn_load_xf(x, cin);
@@ -511,15 +514,18 @@ __global__ void __launch_bounds__(256) k_dwk_fwd_lds(lhn_view x, const float* __
     int r = t / cgroups;
     const int tw = r % tiles_w;
     r /= tiles_w;
-    const int th = r % tiles_h, n = r / tiles_h;
+    const int th = r % tiles_h;
+    r /= tiles_h;
+    const int par = r % (ps * ps), n = r / (ps * ps), pa = par / ps, pb = par % ps;
+    const int SH = (x.H - pa + ps - 1) / ps, SW = (x.W - pb + ps - 1) / ps;     // sub-lattice extent
     const int h0 = th * TH - T::P, w0 = tw * TW - T::P;
     const float* xin = x.data + (size_t)n * x.H * x.W * x.cstride + cin;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int i = min(pl + 32 * it, T::PIX - 1);
       const int ph = i / T::WW, pw = i - ph * T::WW;
-      const int ih = min(max(h0 + ph, 0), x.H - 1), iw = min(max(w0 + pw, 0), x.W - 1);
-      raw[it] = *reinterpret_cast<const f4*>(xin + ((size_t)ih * x.W + iw) * x.cstride);
+      const int ih = pa + ps * min(max(h0 + ph, 0), max(SH - 1, 0)), iw = pb + ps * min(max(w0 + pw, 0), max(SW - 1, 0));
+      raw[it] = *reinterpret_cast<const f4*>(xin + ((size_t)min(ih, x.H - 1) * x.W + min(iw, x.W - 1)) * x.cstride);
     }
   };
   int t = blockIdx.x;
@@ -528,7 +534,10 @@ __global__ void __launch_bounds__(256) k_dwk_fwd_lds(lhn_view x, const float* __
     int r = t / cgroups;
     const int tw = r % tiles_w;
     r /= tiles_w;
-    const int th = r % tiles_h, n = r / tiles_h;
+    const int th = r % tiles_h;
+    r /= tiles_h;
+    const int par = r % (ps * ps), n = r / (ps * ps), pa = par / ps, pb = par % ps;
+    const int SH = (x.H - pa + ps - 1) / ps, SW = (x.W - pb + ps - 1) / ps;
     const f4 gate = x.gate ? *reinterpret_cast<const f4*>(x.gate + (size_t)n * x.cstride + cin) : (f4){1.f, 1.f, 1.f, 1.f};
     const int h0 = th * TH - T::P, w0 = tw * TW - T::P;
     __syncthreads();   // previous tile fully consumed (and wl visible)
@@ -538,7 +547,7 @@ __global__ void __launch_bounds__(256) k_dwk_fwd_lds(lhn_view x, const float* __
       if (i < T::PIX) {
         const int ph = i / T::WW, pw = i - ph * T::WW;
         const int ih = h0 + ph, iw = w0 + pw;
-        const bool inb = ih >= 0 && ih < x.H && iw >= 0 && iw < x.W;
+        const bool inb = ih >= 0 && ih < SH && iw >= 0 && iw < SW;
         const f4 v = lhn_apply_xf(raw[it], xf) * gate;
         tile[i * 8 + c4] = inb ? v : (f4){0.f, 0.f, 0.f, 0.f};
       }
@@ -546,9 +555,9 @@ __global__ void __launch_bounds__(256) k_dwk_fwd_lds(lhn_view x, const float* __
     __syncthreads();
     if (t + (int)gridDim.x < ntile) issue(t + gridDim.x);
     const int wo = tw * TW + pl;
-    if (wo < y.W) {
+    if (wo < SW) {
       const f4* col = tile + (pl + T::P) * 8 + c4;    // centre column of this thread, tile row 0
-      float* yout = y.data + ((size_t)(n * y.H + th * TH) * y.W + wo) * y.cstride + cout;
+      float* yout = y.data + ((size_t)(n * y.H + pa + ps * th * TH) * y.W + pb + ps * wo) * y.cstride + cout;
       if (K == 3 && DIL == 1) {
         f4 wt[9];
 #pragma unroll
@@ -566,27 +575,27 @@ __global__ void __launch_bounds__(256) k_dwk_fwd_lds(lhn_view x, const float* __
             win[1][b] = win[2][b];
             win[2][b] = col[((rr + 2) * T::WW + (b - 1)) * 8];
           }
-          if (th * TH + rr < y.H) {
+          if (th * TH + rr < SH) {
             f4 acc = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int a = 0; a < 3; ++a)
 #pragma unroll
               for (int b = 0; b < 3; ++b) acc += win[a][b] * wt[a * 3 + b];
-            *reinterpret_cast<f4*>(yout + (size_t)rr * y.W * y.cstride) = acc;
+            *reinterpret_cast<f4*>(yout + (size_t)rr * ps * y.W * y.cstride) = acc;
             s += acc;
             q += acc * acc;
           }
         }
       } else {
         for (int rr = 0; rr < TH; ++rr) {
-          if (th * TH + rr >= y.H) break;
+          if (th * TH + rr >= SH) break;
           f4 acc = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int a = 0; a < K; ++a)
 #pragma unroll
             for (int b = 0; b < K; ++b)
               acc += col[((rr + a * DIL) * T::WW + (b * DIL - T::P)) * 8] * wl[(a * K + b) * 8 + c4];
-          *reinterpret_cast<f4*>(yout + (size_t)rr * y.W * y.cstride) = acc;
+          *reinterpret_cast<f4*>(yout + (size_t)rr * ps * y.W * y.cstride) = acc;
           s += acc;
           q += acc * acc;
         }
@@ -609,7 +618,7 @@ __global__ void __launch_bounds__(256) k_dwk_fwd_lds(lhn_view x, const float* __
 template <int K, int DIL>
 __global__ void __launch_bounds__(256) k_dwk_bwd_lds(lhn_view x, const float* __restrict__ w, lhn_view y, lhn_gradview gy,
                                                      float* __restrict__ dx, int dx_acc, float* __restrict__ dw, int tiles_h,
-                                                     int tiles_w, int cgroups, int nrep, int64_t rep_stride) {
+                                                     int tiles_w, int cgroups, int nrep, int64_t rep_stride, int ps) {
   constexpr int TH = 8, TW = 16, KK = K * K;
   constexpr bool REGACC = (K == 3);
   using T = DwTile<K, DIL, TH, TW>;
@@ -621,7 +630,7 @@ __global__ void __launch_bounds__(256) k_dwk_bwd_lds(lhn_view x, const float* __
   f4* dws = wl + KK * 8;                        // [KK][8]  (K = 7 only) block-level dW partials
   const int tid = threadIdx.x, c4 = tid & 7, pl = tid >> 3;
   const int colw = pl & 15, rpar = pl >> 4;
-  const int ntile = y.N * tiles_h * tiles_w * cgroups;
+  const int ntile = y.N * ps * ps * tiles_h * tiles_w * cgroups;      // ps: see k_dwk_fwd_lds
   const int cg = blockIdx.x % cgroups;
   const int cx = x.coff + cg * 32 + 4 * c4, cy = y.coff + cg * 32 + 4 * c4;
   const Xf4 xxf = lhn_load_xf(x, cx), yxf = lhn_load_xf(y, cy);
@@ -638,7 +647,10 @@ __global__ void __launch_bounds__(256) k_dwk_bwd_lds(lhn_view x, const float* __
     int r = t / cgroups;
     const int tw = r % tiles_w;
     r /= tiles_w;
-    const int th = r % tiles_h, n = r / tiles_h;
+    const int th = r % tiles_h;
+    r /= tiles_h;
+    const int par = r % (ps * ps), n = r / (ps * ps), pa = par / ps, pb = par % ps;
+    const int SH = (x.H - pa + ps - 1) / ps, SW = (x.W - pb + ps - 1) / ps;
     const f4 xgate = x.gate ? *reinterpret_cast<const f4*>(x.gate + (size_t)n * x.cstride + cx) : (f4){1.f, 1.f, 1.f, 1.f};
     const f4 ygate = y.gate ? *reinterpret_cast<const f4*>(y.gate + (size_t)n * y.cstride + cy) : (f4){1.f, 1.f, 1.f, 1.f};
     const int h0 = th * TH - T::P, w0 = tw * TW - T::P;
@@ -651,7 +663,8 @@ __global__ void __launch_bounds__(256) k_dwk_bwd_lds(lhn_view x, const float* __
       for (int it = 0; it < NIT; ++it) {
         const int i = min(pl + 32 * it, T::PIX - 1);
         const int ph = i / T::WW, pw = i - ph * T::WW;
-        const int ih = min(max(h0 + ph, 0), x.H - 1), iw = min(max(w0 + pw, 0), x.W - 1);
+        const int ih = min(pa + ps * min(max(h0 + ph, 0), max(SH - 1, 0)), x.H - 1);
+        const int iw = min(pb + ps * min(max(w0 + pw, 0), max(SW - 1, 0)), x.W - 1);
         const size_t pix = (size_t)(n * x.H + ih) * x.W + iw;
         rx[it] = *reinterpret_cast<const f4*>(x.data + pix * x.cstride + cx);
         ry[it] = *reinterpret_cast<const f4*>(y.data + pix * y.cstride + cy);
@@ -663,13 +676,13 @@ __global__ void __launch_bounds__(256) k_dwk_bwd_lds(lhn_view x, const float* __
         if (i < T::PIX) {
           const int ph = i / T::WW, pw = i - ph * T::WW;
           const int ih = h0 + ph, iw = w0 + pw;
-          const bool inb = ih >= 0 && ih < x.H && iw >= 0 && iw < x.W;   // stride 1, "same" padding: x and y share geometry
+          const bool inb = ih >= 0 && ih < SH && iw >= 0 && iw < SW;     // stride 1, "same" padding: x and y share geometry
           const f4 vx = lhn_apply_xf(rx[it], xxf) * xgate;
           f4 e = rz[it] * ygate;
           const f4 u = ry[it] * yxf.sc + yxf.sh;
           const f4 dl = (f4){u.x > 0.f ? 1.f : yxf.sl.x, u.y > 0.f ? 1.f : yxf.sl.y, u.z > 0.f ? 1.f : yxf.sl.z,
                              u.w > 0.f ? 1.f : yxf.sl.w};
-          if (gy.dpool && inb) e += lhn_dpool_sum(gy, y, n, ih, iw, cy);
+          if (gy.dpool && inb) e += lhn_dpool_sum(gy, y, n, pa + ps * ih, pb + ps * iw, cy);
           const f4 vy = ygr.A * (e * dl) + ygr.B * ry[it] + ygr.Cc;
           const f4 z = (f4){0.f, 0.f, 0.f, 0.f};
           tx[i * 8 + c4] = inb ? vx : z;
@@ -683,7 +696,7 @@ __global__ void __launch_bounds__(256) k_dwk_bwd_lds(lhn_view x, const float* __
 #pragma unroll
       for (int j = 0; j < TH / 2; ++j) {
         const int rr = 2 * j + rpar, hh = th * TH + rr;
-        if (wcol < x.W && hh < x.H) {
+        if (wcol < SW && hh < SH) {
           const int centre = ((rr + T::P) * T::WW + colw + T::P) * 8 + c4;
           const f4 dyc = tdy[centre];
           f4 accx = (f4){0.f, 0.f, 0.f, 0.f};
@@ -696,7 +709,7 @@ __global__ void __launch_bounds__(256) k_dwk_bwd_lds(lhn_view x, const float* __
               accw[REGACC ? a * K + b : 0] += dyc * tx[centre + off];
             }
           if (dx) {
-            float* o = dx + ((size_t)(n * x.H + hh) * x.W + wcol) * x.cstride + cx;
+            float* o = dx + ((size_t)(n * x.H + pa + ps * hh) * x.W + pb + ps * wcol) * x.cstride + cx;
             if (dx_acc) accx += *reinterpret_cast<const f4*>(o);
             *reinterpret_cast<f4*>(o) = accx;
           }
@@ -707,14 +720,14 @@ __global__ void __launch_bounds__(256) k_dwk_bwd_lds(lhn_view x, const float* __
       if (dx)
         for (int j = 0; j < TH / 2; ++j) {
           const int rr = 2 * j + rpar, hh = th * TH + rr;
-          if (wcol < x.W && hh < x.H) {
+          if (wcol < SW && hh < SH) {
             const int centre = ((rr + T::P) * T::WW + colw + T::P) * 8 + c4;
             f4 accx = (f4){0.f, 0.f, 0.f, 0.f};
             for (int a = 0; a < K; ++a)
 #pragma unroll
               for (int b = 0; b < K; ++b)
                 accx += tdy[centre - ((a * DIL - T::P) * T::WW + (b * DIL - T::P)) * 8] * wl[(a * K + b) * 8 + c4];
-            float* o = dx + ((size_t)(n * x.H + hh) * x.W + wcol) * x.cstride + cx;
+            float* o = dx + ((size_t)(n * x.H + pa + ps * hh) * x.W + pb + ps * wcol) * x.cstride + cx;
             if (dx_acc) accx += *reinterpret_cast<const f4*>(o);
             *reinterpret_cast<f4*>(o) = accx;
           }
@@ -726,7 +739,7 @@ __global__ void __launch_bounds__(256) k_dwk_bwd_lds(lhn_view x, const float* __
         for (int b = 0; b < K; ++b) ar[b] = (f4){0.f, 0.f, 0.f, 0.f};
         for (int j = 0; j < TH / 2; ++j) {
           const int rr = 2 * j + rpar, hh = th * TH + rr;
-          if (wcol < x.W && hh < x.H) {
+          if (wcol < SW && hh < SH) {
             const int centre = ((rr + T::P) * T::WW + colw + T::P) * 8 + c4;
             const f4 dyc = tdy[centre];
 #pragma unroll
@@ -805,10 +818,11 @@ static int dw3_grid(int ntile, int cgroups, int per_cu) {
 }
 
 template <int K, int DIL>
-static void launch_dwk_fwd(const lhn_view* x, const float* w, const lhn_view* y, double* stats, lhn_bnfin fin, hipStream_t s) {
+static void launch_dwk_fwd(const lhn_view* x, const float* w, const lhn_view* y, double* stats, lhn_bnfin fin, hipStream_t s, int ps = 1) {
   constexpr int TH = 8, TW = 32, P = DIL * (K - 1) / 2;
   const int cg = x->C / 32;
-  const int th = (y->H + TH - 1) / TH, tw = (y->W + TW - 1) / TW, ntile = y->N * th * tw * cg;
+  const int sh = (y->H + ps - 1) / ps, sw = (y->W + ps - 1) / ps;       // largest parity sub-lattice
+  const int th = (sh + TH - 1) / TH, tw = (sw + TW - 1) / TW, ntile = y->N * ps * ps * th * tw * cg;
   const size_t lds = (size_t)((TH + 2 * P) * (TW + 2 * P) * 8 + 512 + K * K * 8) * 16;
   const int per_cu = lds > 80 * 1024 ? 1 : (lds > 52 * 1024 ? 2 : 3);
   static bool done = false;
@@ -816,14 +830,15 @@ static void launch_dwk_fwd(const lhn_view* x, const float* w, const lhn_view* y,
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwk_fwd_lds<K, DIL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     done = true;
   }
-  hipLaunchKernelGGL((k_dwk_fwd_lds<K, DIL>), dim3(dw3_grid(ntile, cg, per_cu * 2)), dim3(256), lds, s, *x, w, *y, stats, th, tw, cg, fin);
+  hipLaunchKernelGGL((k_dwk_fwd_lds<K, DIL>), dim3(dw3_grid(ntile, cg, per_cu * 2)), dim3(256), lds, s, *x, w, *y, stats, th, tw, cg, fin, ps);
 }
 template <int K, int DIL>
 static void launch_dwk_bwd(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx, int dx_acc,
-                           float* dw, int nrep, int64_t rep_stride, hipStream_t s) {
+                           float* dw, int nrep, int64_t rep_stride, hipStream_t s, int ps = 1) {
   constexpr int TH = 8, TW = 16, P = DIL * (K - 1) / 2;
   const int cg = x->C / 32;
-  const int th = (x->H + TH - 1) / TH, tw = (x->W + TW - 1) / TW, ntile = x->N * th * tw * cg;
+  const int sh = (x->H + ps - 1) / ps, sw = (x->W + ps - 1) / ps;
+  const int th = (sh + TH - 1) / TH, tw = (sw + TW - 1) / TW, ntile = x->N * ps * ps * th * tw * cg;
   const size_t lds = (size_t)((TH + 2 * P) * (TW + 2 * P) * 16 + 256 + 2 * K * K * 8) * 16;
   static bool done = false;
   if (!done) {
@@ -831,13 +846,14 @@ static void launch_dwk_bwd(const lhn_view* x, const float* w, const lhn_view* y,
     done = true;
   }
   hipLaunchKernelGGL((k_dwk_bwd_lds<K, DIL>), dim3(dw3_grid(ntile, cg, 4)), dim3(256), lds, s, *x, w, *y, *gy, dx, dx_acc, dw, th, tw,
-                     cg, nrep, rep_stride);
+                     cg, nrep, rep_stride, ps);
 }
 
 // returns 1 if an LDS-tiled kernel was launched
 int lhn_dwk_fwd_lds(const lhn_view* x, const float* w, const lhn_view* y, double* stats, int k, int dil, lhn_bnfin fin,
                     hipStream_t s) {
   if (k == 3 && dil == 1) launch_dwk_fwd<3, 1>(x, w, y, stats, fin, s);
+  else if (k == 3 && dil == 2 && y->W >= 16) launch_dwk_fwd<3, 1>(x, w, y, stats, fin, s, 2);    // parity sub-lattices
   else if (k == 3 && dil == 2) launch_dwk_fwd<3, 2>(x, w, y, stats, fin, s);
   else if (k == 7 && dil == 1) launch_dwk_fwd<7, 1>(x, w, y, stats, fin, s);
   else return 0;
@@ -846,6 +862,7 @@ int lhn_dwk_fwd_lds(const lhn_view* x, const float* w, const lhn_view* y, double
 int lhn_dwk_bwd_lds(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx, int dx_acc,
                     float* dw, int k, int dil, int nrep, int64_t rep_stride, hipStream_t s) {
   if (k == 3 && dil == 1) launch_dwk_bwd<3, 1>(x, w, y, gy, dx, dx_acc, dw, nrep, rep_stride, s);
+  else if (k == 3 && dil == 2 && x->W >= 16) launch_dwk_bwd<3, 1>(x, w, y, gy, dx, dx_acc, dw, nrep, rep_stride, s, 2);
   else if (k == 3 && dil == 2) launch_dwk_bwd<3, 2>(x, w, y, gy, dx, dx_acc, dw, nrep, rep_stride, s);
   else if (k == 7 && dil == 1) launch_dwk_bwd<7, 1>(x, w, y, gy, dx, dx_acc, dw, nrep, rep_stride, s);
   else return 0;

@@ -433,7 +433,7 @@ def test_model_224_input(dev, variant):
     cfg.MODEL["ca_dropout"] = 0.0
     ours, ref = get_model(cfg), torch_ref.get_model(cfg, p_drop=0.0)
     x = synth.synth_images(4, 224, 21)
-    _check_block(ours, ref, x, dev, seed=30, no_dx=True)
+    _check_block(ours, ref, x, dev, seed=30, no_dx=True, grad_tol=2e-2)      # N=4 attention BatchNorms: see test_odd_batches
 
 
 # ---------------------------------------------------------------- SyncBatchNorm (section 8f rank 3)
