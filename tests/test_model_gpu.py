@@ -551,3 +551,12 @@ def test_odd_batches(dev, variant, n, size):
     with torch.no_grad():
         y, y64 = ours(x.to(dev)), ref(x.double())
     assert _rel(y, y64) < FWD_TOL, _rel(y, y64)
+
+
+def test_unsupported_width_fails_loudly(dev):
+    """input_channel = 256 (the *_w256 configs) needs 1x1 GEMMs with K or N = 256, which are not built: the first forward
+    must raise LhnError naming the shape -- never fall back to anything else."""
+    from litehandnet_amd import _lib, get_model
+    m = get_model(litehandnet_cfg("B", channels=256)).to(dev).train()
+    with pytest.raises(_lib.LhnError, match="unsupported channels|C="):
+        m(torch.zeros(2, 3, 64, 64, device=dev))
