@@ -97,6 +97,14 @@ int lhn_transform_preds(const float* coords /*[N,K,2]*/, const float* center /*[
 int lhn_heatmap_decode(const float* hm, const float* center, const float* scale, float* hm_preds,
                        float* preds, float* maxvals, int N, int K, int H, int W, int post_process,
                        void* stream);
+/* GPU input path: TopDownAffine (datasets/data_pipeline/topdown_affine.py:47-114, non-UDP) +
+ * ToTensor + NormalizeTensor (shared_transform.py:3-44) in one launch: uint8 HWC source images [N,Hs,Ws,3] -> normalised
+ * float CHW crops [N,3,Ho,Wo]; optionally maps joints [N,K,3] (visible ones) with the same transform.  mean3/std3 are
+ * HOST pointers to 3 floats.  cv2.warpAffine parity is unpinned (cv2 absent): exact-float bilinear, uint8 rounding. */
+int lhn_affine_warp_normalize(const unsigned char* img, int N, int Hs, int Ws, const float* center /*[N,2]*/,
+                              const float* scale /*[N,2]*/, const float* rot_deg /*[N]*/, const float* mean3,
+                              const float* std3, float* out, int Ho, int Wo, float* joints /*or NULL*/,
+                              const float* visible, int vis_stride, int K, void* stream);
 /* SimDR (cfg.PIPELINE.simdr_split_ratio = k > 0): 1-D Gaussian target vectors (generate_simder.py:9-31) and the
  * auxiliary loss on the decoded vectors (centernet_simdr_loss.py:6-71: per joint, SmoothL1 'mean' over [N, L] times the
  * MEAN of that joint's weights, x and y, averaged over joints).  The two shared Linear decoders are plain library

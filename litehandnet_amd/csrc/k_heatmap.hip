@@ -650,3 +650,84 @@ extern "C" int lhn_simdr_loss_bwd(const float* px, const float* py, const float*
   LHN_CHECK_LAUNCH("lhn_simdr_loss_bwd");
   return 0;
 }
+
+// ------------------------------------------------------------------ GPU input path: TopDownAffine + ToTensor + Normalize
+// datasets/data_pipeline/topdown_affine.py:47-114 (non-UDP branch) + shared_transform.py:3-44, fused:
+//   trans = get_affine_transform(center, scale, rot, out_size)  (post_transforms.py:101-156: a similarity transform
+//           dst = s * R(-rot) * (src - center) + out_size/2 with s = out_w / (scale_x * 200))
+//   img   = warpAffine(img_u8, trans, INTER_LINEAR, constant 0 border) -> /255 -> (v - mean) / std, CHW
+//   joints[:, :2] = trans * [x, y, 1] for visible joints
+// cv2 is absent from the build container: the bilinear sample is exact float arithmetic rounded to the nearest uint8
+// level like cv2's output type (cv2 itself interpolates with 5-bit fixed-point weights) -- "parity unpinned".
+__global__ void __launch_bounds__(256) k_affine_warp_norm(const unsigned char* __restrict__ img, int Hs, int Ws,
+                                                          const float* __restrict__ center, const float* __restrict__ scale,
+                                                          const float* __restrict__ rot, float m0, float m1, float m2, float s0,
+                                                          float s1, float s2, float* __restrict__ out, int Ho, int Wo) {
+  const int n = blockIdx.y;
+  const float cx = center[n * 2], cy = center[n * 2 + 1];
+  const float src_w = scale[n * 2] * 200.f;
+  const float inv_s = src_w / (float)Wo;                          // 1 / s
+  const float r = rot[n] * 3.14159265358979323846f / 180.f;
+  const float cr = cosf(r), sr = sinf(r);
+  const unsigned char* src = img + (size_t)n * Hs * Ws * 3;
+  const float mean[3] = {m0, m1, m2}, istd[3] = {1.f / s0, 1.f / s1, 1.f / s2};
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < Ho * Wo; p += gridDim.x * blockDim.x) {
+    const int y = p / Wo, x = p - y * Wo;
+    const float dx = (float)x - 0.5f * Wo, dy = (float)y - 0.5f * Ho;
+    // src = center + (1/s) * R(rot) * (dst - out/2)
+    const float sx = cx + inv_s * (cr * dx - sr * dy), sy = cy + inv_s * (sr * dx + cr * dy);
+    const float fx = floorf(sx), fy = floorf(sy);
+    const int x0 = (int)fx, y0 = (int)fy;
+    const float ax = sx - fx, ay = sy - fy;
+    float v[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int xx = x0 + i, yy = y0 + j;
+        if (xx >= 0 && xx < Ws && yy >= 0 && yy < Hs) {
+          const float wgt = (i ? ax : 1.f - ax) * (j ? ay : 1.f - ay);
+          const unsigned char* q = src + ((size_t)yy * Ws + xx) * 3;
+          v[0] += wgt * q[0];
+          v[1] += wgt * q[1];
+          v[2] += wgt * q[2];
+        }
+      }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float u8 = fminf(fmaxf(rintf(v[c]), 0.f), 255.f);     // cv2.warpAffine returns uint8
+      out[((size_t)n * 3 + c) * Ho * Wo + p] = (u8 / 255.f - mean[c]) * istd[c];
+    }
+  }
+}
+__global__ void k_affine_joints(float* __restrict__ joints, const float* __restrict__ visible, int vis_stride,
+                                const float* __restrict__ center, const float* __restrict__ scale, const float* __restrict__ rot,
+                                int K, int Ho, int Wo, int total) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int n = i / K;
+  if (!(visible[(size_t)i * vis_stride] > 0.f)) return;
+  const float s = (float)Wo / (scale[n * 2] * 200.f);
+  const float r = rot[n] * 3.14159265358979323846f / 180.f, cr = cosf(r), sr = sinf(r);
+  const float dx = joints[(size_t)i * 3] - center[n * 2], dy = joints[(size_t)i * 3 + 1] - center[n * 2 + 1];
+  joints[(size_t)i * 3] = s * (cr * dx + sr * dy) + 0.5f * Wo;            // dst = s * R(-rot) * (src - center) + out/2
+  joints[(size_t)i * 3 + 1] = s * (-sr * dx + cr * dy) + 0.5f * Ho;
+}
+
+extern "C" int lhn_affine_warp_normalize(const unsigned char* img, int N, int Hs, int Ws, const float* center, const float* scale,
+                                         const float* rot, const float* mean3, const float* std3, float* out, int Ho, int Wo,
+                                         float* joints, const float* visible, int vis_stride, int K, void* stream) {
+  LHN_CHECK_ARG(img && center && scale && rot && mean3 && std3 && out && N > 0 && Hs > 0 && Ws > 0 && Ho > 0 && Wo > 0,
+                "lhn_affine_warp_normalize: bad argument");
+  LHN_CHECK_ARG(!joints || (visible && K > 0), "lhn_affine_warp_normalize: joints need visibility flags");
+  hipStream_t s = (hipStream_t)stream;
+  int gx = (Ho * Wo + 255) / 256;
+  if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(k_affine_warp_norm, dim3(gx, N), dim3(256), 0, s, img, Hs, Ws, center, scale, rot, mean3[0], mean3[1], mean3[2],
+                     std3[0], std3[1], std3[2], out, Ho, Wo);
+  if (joints)
+    hipLaunchKernelGGL(k_affine_joints, dim3((N * K + 255) / 256), dim3(256), 0, s, joints, visible, vis_stride, center, scale, rot, K,
+                       Ho, Wo, N * K);
+  LHN_CHECK_LAUNCH("lhn_affine_warp_normalize");
+  return 0;
+}

@@ -1,0 +1,64 @@
+"""GPU input path: the per-sample CPU transforms of datasets/build_dataset.py:111-132 that feed
+the network -- TopDownAffine (topdown_affine.py:47-114, non-UDP) + ToTensor + NormalizeTensor (shared_transform.py:3-44)
+-- as ONE launch over a batch, followed by the device-resident target encoders in `heatmap` (TopDownGenerateTarget,
+GenerateSimDR).  Source images of one batch share their size (uint8, HWC)."""
+import ctypes as C
+
+import torch
+
+from . import _lib, heatmap
+
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+def affine_warp_normalize(images_u8, center, scale, rotation, image_size, joints=None, visible=None, mean=IMAGENET_MEAN,
+                          std=IMAGENET_STD):
+    """images_u8 [N,Hs,Ws,3] uint8, center/scale [N,2], rotation [N] degrees -> float32 [N,3,H,W] normalised crops
+    (+ joints [N,K,3] mapped into the crop, visible ones only, when given)."""
+    _lib.require_device()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    img = torch.as_tensor(images_u8).to(dev)
+    if img.dtype != torch.uint8 or img.dim() != 4 or img.shape[3] != 3:
+        raise _lib.LhnError("affine_warp_normalize: images must be uint8 [N,Hs,Ws,3]")
+    img = img.contiguous()
+    N, Hs, Ws, _ = img.shape
+    ce = _lib.f32c(torch.as_tensor(center, dtype=torch.float32).to(dev)).reshape(N, 2)
+    sc = _lib.f32c(torch.as_tensor(scale, dtype=torch.float32).to(dev)).reshape(N, 2)
+    ro = _lib.f32c(torch.as_tensor(rotation, dtype=torch.float32).to(dev)).reshape(N)
+    Wo, Ho = int(image_size[0]), int(image_size[1])
+    out = torch.empty((N, 3, Ho, Wo), dtype=torch.float32, device=dev)
+    m3, s3 = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
+    j = v = None
+    K = 0
+    if joints is not None:
+        j = _lib.f32c(torch.as_tensor(joints, dtype=torch.float32).to(dev)).clone()
+        v = _lib.f32c(torch.as_tensor(visible, dtype=torch.float32).to(dev))
+        K = j.shape[1]
+    _lib.check(_lib.lib().lhn_affine_warp_normalize(_lib.ptr(img), N, Hs, Ws, _lib.ptr(ce), _lib.ptr(sc), _lib.ptr(ro), m3, s3,
+                                                    _lib.ptr(out), Ho, Wo, _lib.ptr(j), _lib.ptr(v),
+                                                    0 if v is None else v.shape[-1], K, _lib.stream()),
+               "lhn_affine_warp_normalize")
+    return (out, j) if joints is not None else out
+
+
+class TopDownBatchPipeline:
+    """The evaluation pipeline of build_dataset.py:124-131 for a batch already resident on the GPU: affine crop +
+    normalise, then targets (and SimDR vectors when simdr_split_ratio > 0) from the transformed joints."""
+
+    def __init__(self, cfg):
+        P = cfg.PIPELINE
+        if P.use_udp:
+            raise _lib.LhnError("TopDownBatchPipeline: the UDP variant of TopDownAffine is not built")
+        self.image_size = list(cfg.DATASET.image_size)
+        self.heatmap_size = list(cfg.DATASET.heatmap_size)
+        self.sigma, self.unbiased, self.k = P.sigma, bool(P.unbiased_encoding), int(P.get("simdr_split_ratio", 0))
+
+    def __call__(self, images_u8, center, scale, rotation, joints, visible):
+        img, j = affine_warp_normalize(images_u8, center, scale, rotation, self.image_size, joints, visible)
+        vis = torch.as_tensor(visible, dtype=torch.float32).to(img.device)
+        target, weight = heatmap.generate_target_batch(j, vis, self.image_size, self.heatmap_size, self.sigma, self.unbiased)
+        meta = {"target": target, "target_weight": weight, "joints_3d": j}
+        if self.k > 0:
+            meta["simdr_x"], meta["simdr_y"] = heatmap.generate_simdr_batch(j, vis, self.image_size, self.k, self.sigma)
+        return img, meta

@@ -263,3 +263,37 @@ def keypoints_from_simdr(x_vectors, y_vectors, center, scale, k=2):
     for i in range(B):
         preds[i] = transform_preds(preds[i], center[i], scale[i], [W // k, H // k], use_udp=False)
     return np.concatenate([preds, scores], 2)
+
+
+def affine_matrix(center, scale, rot, output_size):
+    """Closed form of post_transforms.get_affine_transform (:101-156; the reference solves three point pairs with
+    cv2.getAffineTransform): dst = s * R(-rot) * (src - center) + output_size / 2, s = out_w / (scale_x * 200)."""
+    s = output_size[0] / (scale[0] * 200.0)
+    r = np.pi * rot / 180.0
+    c, sn = np.cos(r), np.sin(r)
+    A = s * np.array([[c, sn], [-sn, c]], np.float64)
+    t = np.array([output_size[0] * 0.5, output_size[1] * 0.5]) - A @ np.asarray(center, np.float64)
+    return np.concatenate([A, t[:, None]], 1)
+
+
+def warp_affine_normalize(img_u8, center, scale, rot, output_size, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)):
+    """TopDownAffine (topdown_affine.py:95-107) + ToTensor + NormalizeTensor for one HWC uint8 image, with exact bilinear
+    interpolation (cv2 interpolates with 5-bit fixed-point weights -- parity unpinned, cv2 absent) and uint8 rounding."""
+    M = affine_matrix(center, scale, rot, output_size)
+    Ai = np.linalg.inv(M[:, :2])
+    W, H = int(output_size[0]), int(output_size[1])
+    ys, xs = np.mgrid[0:H, 0:W].astype(np.float64)
+    d = np.stack([xs - M[0, 2], ys - M[1, 2]], -1) @ Ai.T
+    sx, sy = d[..., 0], d[..., 1]
+    x0, y0 = np.floor(sx).astype(int), np.floor(sy).astype(int)
+    ax, ay = sx - x0, sy - y0
+    Hs, Ws = img_u8.shape[:2]
+    out = np.zeros((H, W, 3), np.float64)
+    for j in (0, 1):
+        for i in (0, 1):
+            xx, yy = x0 + i, y0 + j
+            ok = (xx >= 0) & (xx < Ws) & (yy >= 0) & (yy < Hs)
+            wgt = (ax if i else 1 - ax) * (ay if j else 1 - ay)
+            out += (wgt * ok)[..., None] * img_u8[np.clip(yy, 0, Hs - 1), np.clip(xx, 0, Ws - 1)].astype(np.float64)
+    u8 = np.clip(np.rint(out), 0, 255)
+    return (((u8 / 255.0) - np.asarray(mean)) / np.asarray(std)).transpose(2, 0, 1).astype(np.float32), M

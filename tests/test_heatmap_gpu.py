@@ -185,3 +185,37 @@ def test_simdr_targets_loss_decode(dev, golden_dir):
     tot, d = crit(hm.detach(), {"target": t, "target_weight": w, "simdr_x": torch.from_numpy(ox), "simdr_y": torch.from_numpy(oy)})
     assert abs(float(d["simdr"]) - 0.1 * float(g["loss"])) <= 1e-5 * float(g["loss"])
     assert abs(float(tot) - float(d["heatmap"]) - float(d["simdr"])) <= 1e-6 * abs(float(tot))
+
+
+def test_gpu_input_path(dev):
+    """TopDownAffine + ToTensor + NormalizeTensor fused on the GPU vs the numpy restatement (exact bilinear + uint8 rounding;
+    cv2.warpAffine parity is unpinned -- cv2 is absent).  Tolerance: at most ONE uint8 level (1/255/std), and only on the
+    few per cent of pixels whose interpolated value sits on a .5 rounding tie (dyadic scale factors make ties common; the
+    float64 oracle and the exact float32 kernel break them differently); 1e-5 elsewhere; joints to 1e-3 px."""
+    from litehandnet_amd import pipeline
+    r = np.random.Generator(np.random.PCG64(77))
+    N, Hs, Ws = 3, 120, 160
+    img = r.integers(0, 256, (N, Hs, Ws, 3), dtype=np.uint8)
+    center = np.array([[80, 60], [40.5, 70.25], [120, 30]], np.float32)
+    scale = np.array([[0.5, 0.5], [0.3, 0.3], [0.8, 0.8]], np.float32)
+    rot = np.array([0.0, 25.0, -40.0], np.float32)
+    joints = np.zeros((N, 21, 3), np.float32)
+    joints[..., :2] = r.uniform(0, 120, (N, 21, 2))
+    vis = np.ones((N, 21, 3), np.float32)
+    vis[1, 3] = 0
+    out, j = pipeline.affine_warp_normalize(img, center, scale, rot, [64, 64], joints, vis)
+    out, j = out.cpu().numpy(), j.cpu().numpy()
+    for n in range(N):
+        ref, M = onp.warp_affine_normalize(img[n], center[n], scale[n], rot[n], [64, 64])
+        diff = np.abs(out[n] - ref)
+        level = 1.0 / 255 / 0.224
+        assert (diff > 1e-5).mean() < 0.05 and diff.max() <= 1.05 * level / 0.98, (n, diff.max(), (diff > 1e-5).mean())
+        jr = joints[n].copy()
+        jr[:, :2] = (np.concatenate([joints[n, :, :2], np.ones((21, 1))], 1) @ M.T)
+        jr[vis[n, :, 0] == 0] = joints[n][vis[n, :, 0] == 0]
+        assert np.abs(j[n] - jr).max() < 1e-3
+    # and the whole evaluation pipeline object: crops + targets from the transformed joints
+    cfg = litehandnet_cfg("B", image_size=64)
+    pipe = pipeline.TopDownBatchPipeline(cfg)
+    x, meta = pipe(img, center, scale, rot, joints, vis)
+    assert x.shape == (N, 3, 64, 64) and meta["target"].shape == (N, 21, 16, 16) and meta["target_weight"].shape[:2] == (N, 21)
