@@ -86,7 +86,8 @@ int         lhn_device_ok(void);              /* 0 if a gfx950 device is usable 
  */
 int lhn_heatmap_encode(const float* joints /*[N,K,3]*/, const float* visible /*[N,K,3]*/,
                        float* target /*[N,K,H,W]*/, float* weight /*[N,K]*/, int N, int K, int H, int W,
-                       float img_w, float img_h, float sigma, int unbiased, void* stream);
+                       float img_w, float img_h, float sigma, int unbiased /*0 MSRA patch, 1 DARK full map, 2 UDP patch (generateTarget.py:160-236)*/,
+                       void* stream);
 int lhn_heatmap_argmax(const float* hm /*[N,K,H,W]*/, float* preds /*[N,K,2]*/, float* maxvals /*[N,K]*/,
                        int32_t* index /*[N,K] or NULL*/, int N, int K, int H, int W, void* stream);
 int lhn_heatmap_refine(const float* hm, float* preds /*[N,K,2] in/out*/, int N, int K, int H, int W,
@@ -104,7 +105,8 @@ int lhn_heatmap_decode(const float* hm, const float* center, const float* scale,
 int lhn_affine_warp_normalize(const unsigned char* img, int N, int Hs, int Ws, const float* center /*[N,2]*/,
                               const float* scale /*[N,2]*/, const float* rot_deg /*[N]*/, const float* mean3,
                               const float* std3, float* out, int Ho, int Wo, float* joints /*or NULL*/,
-                              const float* visible, int vis_stride, int K, void* stream);
+                              const float* visible, int vis_stride, int K,
+                              int use_udp /*get_warp_matrix + warp_affine_joints, post_transforms.py:49-100*/, void* stream);
 /* SimDR (cfg.PIPELINE.simdr_split_ratio = k > 0): 1-D Gaussian target vectors (generate_simder.py:9-31) and the
  * auxiliary loss on the decoded vectors (centernet_simdr_loss.py:6-71: per joint, SmoothL1 'mean' over [N, L] times the
  * MEAN of that joint's weights, x and y, averaged over joints).  The two shared Linear decoders are plain library
@@ -120,6 +122,10 @@ int lhn_simdr_loss_bwd(const float* px, const float* py, const float* tx, const 
  * twin utils/heatmap_post_processing.py:35-91), fused with argmax and transform_preds */
 int lhn_heatmap_decode_dark(const float* hm, const float* center, const float* scale, float* hm_preds,
                             float* preds, float* maxvals, int N, int K, int H, int W, int kernel, void* stream);
+/* UDP + DARK decode: keypoints_from_heatmaps(use_udp=True, GaussianHeatmap) = _get_max_preds + post_dark_udp
+ * (top_down_eval.py:275-337, 404-411) + transform_preds(use_udp=True) (post_transforms.py:37-43) */
+int lhn_heatmap_decode_dark_udp(const float* hm, const float* center, const float* scale, float* hm_preds,
+                                float* preds, float* maxvals, int N, int K, int H, int W, int kernel, void* stream);
 int lhn_heatmap_nms(float* hm /*in place*/, float* scratch /*same size*/, int N, int K, int H, int W,
                     int kernel, void* stream);
 int lhn_pck_accuracy(const float* pred, const float* gt, const uint8_t* mask /*[N,K]*/,

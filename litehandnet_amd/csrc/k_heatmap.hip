@@ -24,7 +24,7 @@ __global__ void __launch_bounds__(256) k_encode(const float* __restrict__ joints
   const double r = (double)sigma * 3.0;
   float* out = target + (int64_t)nk * H * W;
   const int HW = H * W;
-  if (unbiased) {
+  if (unbiased == 1) {
     const double mx = (double)jx / stride_x, my = (double)jy / stride_y;
     if (mx - r >= W || my - r >= H || mx + r + 1 < 0 || my + r + 1 < 0) wgt = 0.f;
     const bool on = wgt > 0.5f;
@@ -52,13 +52,21 @@ __global__ void __launch_bounds__(256) k_encode(const float* __restrict__ joints
     const bool on = wgt > 0.5f;
     const float den = 2.f * sigma * sigma;
     const int size = 2 * ri + 1, c0 = size / 2;
+    // UDP (generateTarget.py:160-236, stride_* = (image-1)/(heatmap-1)): same patch, but the Gaussian is centred on the
+    // sub-pixel position  size//2 + (joint/stride - mu)  and evaluated in float64 like the reference's mixed-type expression
+    const double x0 = (double)c0 + ((double)jx / stride_x - (double)mx), y0 = (double)c0 + ((double)jy / stride_y - (double)my);
     for (int i = threadIdx.x; i < HW; i += blockDim.x) {
       const int x = i % W, y = i / W;
       float v = 0.f;
       if (on && x >= ulx && x < brx && y >= uly && y < bry) {
-        const float gx = (float)(x - ulx) - (float)c0, gy = (float)(y - uly) - (float)c0;
-        const float a = add_rn(mul_rn(gx, gx), mul_rn(gy, gy));
-        v = expf(-a / den);
+        if (unbiased == 2) {
+          const double gx = (double)(float)(x - ulx) - x0, gy = (double)(float)(y - uly) - y0;
+          v = (float)exp(-(gx * gx + gy * gy) / (2.0 * (double)sigma * (double)sigma));
+        } else {
+          const float gx = (float)(x - ulx) - (float)c0, gy = (float)(y - uly) - (float)c0;
+          const float a = add_rn(mul_rn(gx, gx), mul_rn(gy, gy));
+          v = expf(-a / den);
+        }
       }
       out[i] = v;
     }
@@ -347,8 +355,11 @@ int lhn_heatmap_encode(const float* joints, const float* visible, float* target,
   LHN_CHECK_ARG(joints && visible && target && weight, "lhn_heatmap_encode: null pointer");
   LHN_CHECK_ARG(N > 0 && K > 0 && H > 0 && W > 0 && (H * W) % 4 == 0, "lhn_heatmap_encode: bad shape N=%d K=%d H=%d W=%d", N, K, H, W);
   LHN_CHECK_ARG(sigma > 0.f, "lhn_heatmap_encode: sigma must be > 0");
+  LHN_CHECK_ARG(unbiased >= 0 && unbiased <= 2 && (unbiased != 2 || (W > 1 && H > 1)), "lhn_heatmap_encode: mode %d", unbiased);
+  const double sx = unbiased == 2 ? ((double)img_w - 1.0) / ((double)W - 1.0) : (double)img_w / (double)W;
+  const double sy = unbiased == 2 ? ((double)img_h - 1.0) / ((double)H - 1.0) : (double)img_h / (double)H;
   hipLaunchKernelGGL(k_encode, dim3(N * K), dim3(256), 0, (hipStream_t)stream, joints, visible, target, weight, N * K,
-                     H, W, (double)img_w / (double)W, (double)img_h / (double)H, sigma, unbiased);
+                     H, W, sx, sy, sigma, unbiased);
   LHN_CHECK_LAUNCH("lhn_heatmap_encode");
   return 0;
 }
@@ -662,20 +673,30 @@ extern "C" int lhn_simdr_loss_bwd(const float* px, const float* py, const float*
 __global__ void __launch_bounds__(256) k_affine_warp_norm(const unsigned char* __restrict__ img, int Hs, int Ws,
                                                           const float* __restrict__ center, const float* __restrict__ scale,
                                                           const float* __restrict__ rot, float m0, float m1, float m2, float s0,
-                                                          float s1, float s2, float* __restrict__ out, int Ho, int Wo) {
+                                                          float s1, float s2, float* __restrict__ out, int Ho, int Wo, int udp) {
   const int n = blockIdx.y;
-  const float cx = center[n * 2], cy = center[n * 2 + 1];
-  const float src_w = scale[n * 2] * 200.f;
-  const float inv_s = src_w / (float)Wo;                          // 1 / s
   const float r = rot[n] * 3.14159265358979323846f / 180.f;
   const float cr = cosf(r), sr = sinf(r);
+  // src = (qx, qy) + [[a00, a01], [a10, a11]] * (dst - (px, py))
+  float a00, a01, a10, a11, qx, qy, px, py;
+  if (!udp) {   // get_affine_transform: dst = s R(-rot) (src - center) + out/2
+    const float inv_s = scale[n * 2] * 200.f / (float)Wo;
+    a00 = inv_s * cr; a01 = -inv_s * sr; a10 = inv_s * sr; a11 = inv_s * cr;
+    qx = center[n * 2]; qy = center[n * 2 + 1]; px = 0.5f * Wo; py = 0.5f * Ho;
+  } else {      // get_warp_matrix(rot, center*2, image_size-1, scale*200) (post_transforms.py:49-83): dst = S R(rot) src + t
+    const float tw = scale[n * 2] * 200.f, th = scale[n * 2 + 1] * 200.f, iw = center[n * 2] * 2.f, ih = center[n * 2 + 1] * 2.f;
+    const float sx = ((float)Wo - 1.f) / tw, sy = ((float)Ho - 1.f) / th;
+    a00 = cr / sx; a01 = sr / sy; a10 = -sr / sx; a11 = cr / sy;
+    qx = 0.f; qy = 0.f;
+    px = sx * (-0.5f * iw * cr + 0.5f * ih * sr + 0.5f * tw);
+    py = sy * (-0.5f * iw * sr - 0.5f * ih * cr + 0.5f * th);
+  }
   const unsigned char* src = img + (size_t)n * Hs * Ws * 3;
   const float mean[3] = {m0, m1, m2}, istd[3] = {1.f / s0, 1.f / s1, 1.f / s2};
   for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < Ho * Wo; p += gridDim.x * blockDim.x) {
     const int y = p / Wo, x = p - y * Wo;
-    const float dx = (float)x - 0.5f * Wo, dy = (float)y - 0.5f * Ho;
-    // src = center + (1/s) * R(rot) * (dst - out/2)
-    const float sx = cx + inv_s * (cr * dx - sr * dy), sy = cy + inv_s * (sr * dx + cr * dy);
+    const float dx = (float)x - px, dy = (float)y - py;
+    const float sx = qx + a00 * dx + a01 * dy, sy = qy + a10 * dx + a11 * dy;
     const float fx = floorf(sx), fy = floorf(sy);
     const int x0 = (int)fx, y0 = (int)fy;
     const float ax = sx - fx, ay = sy - fy;
@@ -702,13 +723,21 @@ __global__ void __launch_bounds__(256) k_affine_warp_norm(const unsigned char* _
 }
 __global__ void k_affine_joints(float* __restrict__ joints, const float* __restrict__ visible, int vis_stride,
                                 const float* __restrict__ center, const float* __restrict__ scale, const float* __restrict__ rot,
-                                int K, int Ho, int Wo, int total) {
+                                int K, int Ho, int Wo, int total, int udp) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const int n = i / K;
+  const float r = rot[n] * 3.14159265358979323846f / 180.f, cr = cosf(r), sr = sinf(r);
+  if (udp) {   // warp_affine_joints (post_transforms.py:86-100): every joint, visible or not
+    const float tw = scale[n * 2] * 200.f, th = scale[n * 2 + 1] * 200.f, iw = center[n * 2] * 2.f, ih = center[n * 2 + 1] * 2.f;
+    const float sx = ((float)Wo - 1.f) / tw, sy = ((float)Ho - 1.f) / th;
+    const float x = joints[(size_t)i * 3], y = joints[(size_t)i * 3 + 1];
+    joints[(size_t)i * 3] = cr * sx * x - sr * sx * y + sx * (-0.5f * iw * cr + 0.5f * ih * sr + 0.5f * tw);
+    joints[(size_t)i * 3 + 1] = sr * sy * x + cr * sy * y + sy * (-0.5f * iw * sr - 0.5f * ih * cr + 0.5f * th);
+    return;
+  }
   if (!(visible[(size_t)i * vis_stride] > 0.f)) return;
   const float s = (float)Wo / (scale[n * 2] * 200.f);
-  const float r = rot[n] * 3.14159265358979323846f / 180.f, cr = cosf(r), sr = sinf(r);
   const float dx = joints[(size_t)i * 3] - center[n * 2], dy = joints[(size_t)i * 3 + 1] - center[n * 2 + 1];
   joints[(size_t)i * 3] = s * (cr * dx + sr * dy) + 0.5f * Wo;            // dst = s * R(-rot) * (src - center) + out/2
   joints[(size_t)i * 3 + 1] = s * (-sr * dx + cr * dy) + 0.5f * Ho;
@@ -716,7 +745,7 @@ __global__ void k_affine_joints(float* __restrict__ joints, const float* __restr
 
 extern "C" int lhn_affine_warp_normalize(const unsigned char* img, int N, int Hs, int Ws, const float* center, const float* scale,
                                          const float* rot, const float* mean3, const float* std3, float* out, int Ho, int Wo,
-                                         float* joints, const float* visible, int vis_stride, int K, void* stream) {
+                                         float* joints, const float* visible, int vis_stride, int K, int use_udp, void* stream) {
   LHN_CHECK_ARG(img && center && scale && rot && mean3 && std3 && out && N > 0 && Hs > 0 && Ws > 0 && Ho > 0 && Wo > 0,
                 "lhn_affine_warp_normalize: bad argument");
   LHN_CHECK_ARG(!joints || (visible && K > 0), "lhn_affine_warp_normalize: joints need visibility flags");
@@ -724,10 +753,101 @@ extern "C" int lhn_affine_warp_normalize(const unsigned char* img, int N, int Hs
   int gx = (Ho * Wo + 255) / 256;
   if (gx > 64) gx = 64;
   hipLaunchKernelGGL(k_affine_warp_norm, dim3(gx, N), dim3(256), 0, s, img, Hs, Ws, center, scale, rot, mean3[0], mean3[1], mean3[2],
-                     std3[0], std3[1], std3[2], out, Ho, Wo);
+                     std3[0], std3[1], std3[2], out, Ho, Wo, use_udp);
   if (joints)
     hipLaunchKernelGGL(k_affine_joints, dim3((N * K + 255) / 256), dim3(256), 0, s, joints, visible, vis_stride, center, scale, rot, K,
-                       Ho, Wo, N * K);
+                       Ho, Wo, N * K, use_udp);
   LHN_CHECK_LAUNCH("lhn_affine_warp_normalize");
+  return 0;
+}
+
+
+// ------------------------------------------------------------------ UDP + DARK decode (use_udp, 'unbiased')
+// top_down_eval.py:275-337 (post_dark_udp) behind keypoints_from_heatmaps(use_udp=True, target_type GaussianHeatmap,
+// :404-411): blur the map in place (cv2.GaussianBlur, default REFLECT_101 border -- parity unpinned, cv2 absent), clip to
+// [0.001, 50], log, Newton step with edge-replicated finite differences and (Hessian + eps*I)^-1, then the UDP
+// back-transform (post_transforms.py:37-43: scale / (size - 1)).
+__device__ __forceinline__ int reflect101(int i, int n) {
+  if (n == 1) return 0;
+  while (i < 0 || i >= n) i = i < 0 ? -i : 2 * n - 2 - i;
+  return i;
+}
+__global__ void __launch_bounds__(256) k_dark_udp(const float* __restrict__ hm, const float* __restrict__ center,
+                                                  const float* __restrict__ scale, float* __restrict__ hm_preds,
+                                                  float* __restrict__ preds, float* __restrict__ maxvals, int K, int H, int W,
+                                                  int ksize) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int HW = H * W, nk = blockIdx.x, b = (ksize - 1) / 2;
+  float* A = smem;
+  float* B = smem + HW;
+  __shared__ float taps[32];
+  const float* m = hm + (int64_t)nk * HW;
+  if (threadIdx.x < ksize) {
+    const double sigma = 0.3 * ((ksize - 1) * 0.5 - 1) + 0.8;
+    double sum = 0;
+    for (int t = 0; t < ksize; ++t) {
+      const double xx = t - (ksize - 1) * 0.5;
+      sum += exp(-(xx * xx) / (2 * sigma * sigma));
+    }
+    const double xx = threadIdx.x - (ksize - 1) * 0.5;
+    taps[threadIdx.x] = (float)(exp(-(xx * xx) / (2 * sigma * sigma)) / sum);
+  }
+  for (int i = threadIdx.x; i < HW; i += blockDim.x) A[i] = m[i];
+  const MaxI r = block_argmax(m, HW);
+  __syncthreads();
+  for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+    const int x = i % W, y = i / W;
+    float s = 0.f;
+    for (int t = 0; t < ksize; ++t) s += taps[t] * A[y * W + reflect101(x + t - b, W)];
+    B[i] = s;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+    const int x = i % W, y = i / W;
+    float s = 0.f;
+    for (int t = 0; t < ksize; ++t) s += taps[t] * B[reflect101(y + t - b, H) * W + x];
+    A[i] = logf(fminf(fmaxf(s, 0.001f), 50.f));
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float x = (float)(r.i % W), y = (float)(r.i / W);
+    if (!(r.v > 0.f)) x = y = -1.f;
+    // np.pad(..., mode='edge') + index arithmetic: coordinates are clamped into the padded map
+    auto L = [&](int yy, int xx) { return A[min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 1)]; };
+    const int px = (int)x, py = (int)y;
+    const float i_ = L(py, px), ix1 = L(py, px + 1), iy1 = L(py + 1, px), ix1y1 = L(py + 1, px + 1);
+    const float ix1_y1_ = L(py - 1, px - 1), ix1_ = L(py, px - 1), iy1_ = L(py - 1, px);
+    const float dx = 0.5f * (ix1 - ix1_), dy = 0.5f * (iy1 - iy1_);
+    const float eps = 1.1920929e-07f;
+    const float dxx = ix1 - 2.f * i_ + ix1_ + eps, dyy = iy1 - 2.f * i_ + iy1_ + eps;
+    const float dxy = 0.5f * (ix1y1 - ix1 - iy1 + i_ + i_ - ix1_ - iy1_ + ix1_y1_);
+    const float det = dxx * dyy - dxy * dxy;
+    x -= (dyy * dx - dxy * dy) / det;
+    y -= (-dxy * dx + dxx * dy) / det;
+    maxvals[nk] = r.v;
+    hm_preds[nk * 2 + 0] = x;
+    hm_preds[nk * 2 + 1] = y;
+    const int n = nk / K;
+    float ox, oy;
+    xform_xy(x, y, center + n * 2, scale + n * 2, W, H, 1, ox, oy);
+    preds[nk * 2 + 0] = ox;
+    preds[nk * 2 + 1] = oy;
+  }
+}
+
+extern "C" int lhn_heatmap_decode_dark_udp(const float* hm, const float* center, const float* scale, float* hm_preds, float* preds,
+                                           float* maxvals, int N, int K, int H, int W, int kernel, void* stream) {
+  LHN_CHECK_ARG(hm && center && scale && hm_preds && preds && maxvals, "lhn_heatmap_decode_dark_udp: null pointer");
+  LHN_CHECK_ARG(kernel % 2 == 1 && kernel >= 3 && kernel <= 31, "lhn_heatmap_decode_dark_udp: kernel %d (odd, 3..31)", kernel);
+  LHN_CHECK_ARG((H * W) % 4 == 0 && H * W <= 16384 && H > 1 && W > 1, "lhn_heatmap_decode_dark_udp: H*W must be a multiple of 4 and <= 16384");
+  const size_t lds = (size_t)2 * H * W * sizeof(float);
+  static bool done = false;
+  if (!done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dark_udp), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 16384 * 4);
+    done = true;
+  }
+  hipLaunchKernelGGL(k_dark_udp, dim3(N * K), dim3(256), lds, (hipStream_t)stream, hm, center, scale, hm_preds, preds, maxvals, K,
+                     H, W, kernel);
+  LHN_CHECK_LAUNCH("lhn_heatmap_decode_dark_udp");
   return 0;
 }

@@ -22,8 +22,10 @@ def _dev(x, device=None):
 
 
 # ------------------------------------------------------------------ encode
-def generate_target_batch(joints_3d, joints_3d_visible, image_size, heatmap_size, sigma=2, unbiased_encoding=True):
-    """[N,K,3] joints (image px) + visibility -> target [N,K,H,W], weight [N,K,1] on the GPU."""
+def generate_target_batch(joints_3d, joints_3d_visible, image_size, heatmap_size, sigma=2, unbiased_encoding=True,
+                          encoding="MSRA"):
+    """[N,K,3] joints (image px) + visibility -> target [N,K,H,W], weight [N,K,1] on the GPU.
+    encoding 'MSRA' (generateTarget.py:74-159, biased patch / DARK full map) or 'UDP' (:160-236, GaussianHeatmap)."""
     j = _lib.f32c(_dev(joints_3d))
     v = _lib.f32c(_dev(joints_3d_visible, j.device))
     N, K, _ = j.shape
@@ -33,7 +35,8 @@ def generate_target_batch(joints_3d, joints_3d_visible, image_size, heatmap_size
     L = _lib.lib()
     _lib.check(L.lhn_heatmap_encode(_lib.ptr(j), _lib.ptr(v), _lib.ptr(target), _lib.ptr(weight), N, K, H, W,
                                     C.c_float(image_size[0]), C.c_float(image_size[1]), C.c_float(sigma),
-                                    1 if unbiased_encoding else 0, _lib.stream()), "lhn_heatmap_encode")
+                                    2 if encoding == "UDP" else (1 if unbiased_encoding else 0), _lib.stream()),
+               "lhn_heatmap_encode")
     return target, weight
 
 
@@ -43,14 +46,16 @@ class TopDownGenerateTarget:
 
     def __init__(self, sigma=2, kernel=(11, 11), target_type="GaussianHeatmap", encoding="MSRA",
                  unbiased_encoding=False):
-        if encoding != "MSRA" or isinstance(sigma, (list, tuple)):
-            raise _lib.LhnError("TopDownGenerateTarget: only single-sigma MSRA encoding is built")
+        if encoding not in ("MSRA", "UDP") or isinstance(sigma, (list, tuple)):
+            raise _lib.LhnError("TopDownGenerateTarget: single-sigma MSRA / UDP encodings are built")
+        if encoding == "UDP" and target_type.lower() != "gaussianheatmap":
+            raise _lib.LhnError("TopDownGenerateTarget: UDP is built for target_type 'GaussianHeatmap' only")
         self.sigma, self.kernel, self.unbiased_encoding = sigma, kernel, unbiased_encoding
         self.target_type, self.encoding = target_type, encoding
 
     def batch(self, joints_3d, joints_3d_visible, image_size, heatmap_size):
         return generate_target_batch(joints_3d, joints_3d_visible, image_size, heatmap_size, self.sigma,
-                                     self.unbiased_encoding)
+                                     self.unbiased_encoding, self.encoding)
 
     def __call__(self, results):
         cfg = results["ann_info"]
@@ -102,14 +107,22 @@ def transform_preds(coords, center, scale, output_size, use_udp=False):
 def keypoints_from_heatmaps(heatmaps, center, scale, post_process="default", kernel=11, use_udp=False,
                             target_type="GaussianHeatmap", only_original_preds=False):
     """top_down_eval.py:375-463 fused in one kernel (argmax -> shift -> back-transform); device tensors out."""
-    if use_udp or post_process not in (None, "default", "unbiased"):
-        raise _lib.LhnError("keypoints_from_heatmaps: post_process None|'default'|'unbiased' without UDP are built")
+    if post_process not in (None, "default", "unbiased"):
+        raise _lib.LhnError("keypoints_from_heatmaps: post_process None|'default'|'unbiased' are built")
+    if use_udp and target_type.lower() != "gaussianheatmap":
+        raise _lib.LhnError("keypoints_from_heatmaps: UDP is built for target_type 'GaussianHeatmap' only")
     h = _lib.f32c(_dev(heatmaps))
     ce, sc = _lib.f32c(_dev(center, h.device)), _lib.f32c(_dev(scale, h.device))
     N, K, H, W = h.shape
     hm_preds = torch.empty((N, K, 2), dtype=torch.float32, device=h.device)
     preds = torch.empty_like(hm_preds)
     maxvals = torch.empty((N, K, 1), dtype=torch.float32, device=h.device)
+    if use_udp:      # top_down_eval.py:404-411: _get_max_preds + post_dark_udp, then the UDP back-transform
+        assert kernel > 0
+        _lib.check(_lib.lib().lhn_heatmap_decode_dark_udp(_lib.ptr(h), _lib.ptr(ce), _lib.ptr(sc), _lib.ptr(hm_preds),
+                                                          _lib.ptr(preds), _lib.ptr(maxvals), N, K, H, W, int(kernel),
+                                                          _lib.stream()), "lhn_heatmap_decode_dark_udp")
+        return (preds, maxvals) if only_original_preds else (hm_preds, preds, maxvals)
     if post_process == "unbiased":
         assert kernel > 0
         _lib.check(_lib.lib().lhn_heatmap_decode_dark(_lib.ptr(h), _lib.ptr(ce), _lib.ptr(sc), _lib.ptr(hm_preds),

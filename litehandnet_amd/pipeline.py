@@ -13,7 +13,7 @@ IMAGENET_STD = (0.229, 0.224, 0.225)
 
 
 def affine_warp_normalize(images_u8, center, scale, rotation, image_size, joints=None, visible=None, mean=IMAGENET_MEAN,
-                          std=IMAGENET_STD):
+                          std=IMAGENET_STD, use_udp=False):
     """images_u8 [N,Hs,Ws,3] uint8, center/scale [N,2], rotation [N] degrees -> float32 [N,3,H,W] normalised crops
     (+ joints [N,K,3] mapped into the crop, visible ones only, when given)."""
     _lib.require_device()
@@ -37,7 +37,7 @@ def affine_warp_normalize(images_u8, center, scale, rotation, image_size, joints
         K = j.shape[1]
     _lib.check(_lib.lib().lhn_affine_warp_normalize(_lib.ptr(img), N, Hs, Ws, _lib.ptr(ce), _lib.ptr(sc), _lib.ptr(ro), m3, s3,
                                                     _lib.ptr(out), Ho, Wo, _lib.ptr(j), _lib.ptr(v),
-                                                    0 if v is None else v.shape[-1], K, _lib.stream()),
+                                                    0 if v is None else v.shape[-1], K, 1 if use_udp else 0, _lib.stream()),
                "lhn_affine_warp_normalize")
     return (out, j) if joints is not None else out
 
@@ -48,16 +48,16 @@ class TopDownBatchPipeline:
 
     def __init__(self, cfg):
         P = cfg.PIPELINE
-        if P.use_udp:
-            raise _lib.LhnError("TopDownBatchPipeline: the UDP variant of TopDownAffine is not built")
+        self.use_udp, self.encoding = bool(P.use_udp), P.get("encoding", "MSRA")
         self.image_size = list(cfg.DATASET.image_size)
         self.heatmap_size = list(cfg.DATASET.heatmap_size)
         self.sigma, self.unbiased, self.k = P.sigma, bool(P.unbiased_encoding), int(P.get("simdr_split_ratio", 0))
 
     def __call__(self, images_u8, center, scale, rotation, joints, visible):
-        img, j = affine_warp_normalize(images_u8, center, scale, rotation, self.image_size, joints, visible)
+        img, j = affine_warp_normalize(images_u8, center, scale, rotation, self.image_size, joints, visible, use_udp=self.use_udp)
         vis = torch.as_tensor(visible, dtype=torch.float32).to(img.device)
-        target, weight = heatmap.generate_target_batch(j, vis, self.image_size, self.heatmap_size, self.sigma, self.unbiased)
+        target, weight = heatmap.generate_target_batch(j, vis, self.image_size, self.heatmap_size, self.sigma, self.unbiased,
+                                                       self.encoding)
         meta = {"target": target, "target_weight": weight, "joints_3d": j}
         if self.k > 0:
             meta["simdr_x"], meta["simdr_y"] = heatmap.generate_simdr_batch(j, vis, self.image_size, self.k, self.sigma)

@@ -276,10 +276,23 @@ def affine_matrix(center, scale, rot, output_size):
     return np.concatenate([A, t[:, None]], 1)
 
 
-def warp_affine_normalize(img_u8, center, scale, rot, output_size, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)):
+def warp_matrix_udp(theta, size_input, size_dst, size_target):
+    """post_transforms.get_warp_matrix (:49-83), float64."""
+    th = np.deg2rad(theta)
+    sx, sy = size_dst[0] / size_target[0], size_dst[1] / size_target[1]
+    c, s = np.cos(th), np.sin(th)
+    return np.array([[c * sx, -s * sx, sx * (-0.5 * size_input[0] * c + 0.5 * size_input[1] * s + 0.5 * size_target[0])],
+                     [s * sy, c * sy, sy * (-0.5 * size_input[0] * s - 0.5 * size_input[1] * c + 0.5 * size_target[1])]], np.float64)
+
+
+def warp_affine_normalize(img_u8, center, scale, rot, output_size, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225),
+                          use_udp=False):
     """TopDownAffine (topdown_affine.py:95-107) + ToTensor + NormalizeTensor for one HWC uint8 image, with exact bilinear
     interpolation (cv2 interpolates with 5-bit fixed-point weights -- parity unpinned, cv2 absent) and uint8 rounding."""
     M = affine_matrix(center, scale, rot, output_size)
+    if use_udp:       # topdown_affine.py:76-93
+        M = warp_matrix_udp(rot, np.asarray(center, np.float64) * 2.0, np.asarray(output_size, np.float64) - 1.0,
+                            np.asarray(scale, np.float64) * 200.0)
     Ai = np.linalg.inv(M[:, :2])
     W, H = int(output_size[0]), int(output_size[1])
     ys, xs = np.mgrid[0:H, 0:W].astype(np.float64)
@@ -297,3 +310,90 @@ def warp_affine_normalize(img_u8, center, scale, rot, output_size, mean=(0.485, 
             out += (wgt * ok)[..., None] * img_u8[np.clip(yy, 0, Hs - 1), np.clip(xx, 0, Ws - 1)].astype(np.float64)
     u8 = np.clip(np.rint(out), 0, 255)
     return (((u8 / 255.0) - np.asarray(mean)) / np.asarray(std)).transpose(2, 0, 1).astype(np.float32), M
+
+
+def udp_generate_target(joints_3d, joints_3d_visible, image_size, heatmap_size, sigma=2):
+    """datasets/data_pipeline/generateTarget.py:160-236 (_udp_generate_target, GaussianHeatmap) for one sample."""
+    image_size, heatmap_size = np.asarray(image_size), np.asarray(heatmap_size)
+    K = joints_3d.shape[0]
+    W, H = int(heatmap_size[0]), int(heatmap_size[1])
+    weight = np.ones((K, 1), np.float32)
+    weight[:, 0] = joints_3d_visible[:, 0]
+    target = np.zeros((K, H, W), np.float32)
+    tmp = sigma * 3
+    size = 2 * tmp + 1
+    x = np.arange(0, size, 1, np.float32)
+    y = x[:, None]
+    for j in range(K):
+        fs = (image_size - 1.0) / (heatmap_size - 1.0)
+        mu_x, mu_y = int(joints_3d[j][0] / fs[0] + 0.5), int(joints_3d[j][1] / fs[1] + 0.5)
+        ul = [int(mu_x - tmp), int(mu_y - tmp)]
+        br = [int(mu_x + tmp + 1), int(mu_y + tmp + 1)]
+        if ul[0] >= W or ul[1] >= H or br[0] < 0 or br[1] < 0:
+            weight[j] = 0
+            continue
+        x0 = y0 = size // 2
+        x0 = x0 + joints_3d[j][0] / fs[0] - mu_x
+        y0 = y0 + joints_3d[j][1] / fs[1] - mu_y
+        g = np.exp(-((x - x0) ** 2 + (y - y0) ** 2) / (2 * sigma ** 2))
+        gx = max(0, -ul[0]), min(br[0], W) - ul[0]
+        gy = max(0, -ul[1]), min(br[1], H) - ul[1]
+        ix = max(0, ul[0]), min(br[0], W)
+        iy = max(0, ul[1]), min(br[1], H)
+        if weight[j] > 0.5:
+            target[j][iy[0]:iy[1], ix[0]:ix[1]] = g[gy[0]:gy[1], gx[0]:gx[1]]
+    return target, weight
+
+
+def gaussian_blur_reflect(hm, k):
+    """cv2.GaussianBlur(hm, (k, k), 0) with its default BORDER_REFLECT_101, restated (cv2 absent: parity unpinned)."""
+    k1 = opencv_gaussian_kernel1d(k)
+    b = (k - 1) // 2
+    p = np.pad(hm.astype(np.float32), b, mode="reflect")
+    H, W = hm.shape
+    tmp = np.zeros((H + 2 * b, W), np.float32)
+    for t in range(k):
+        tmp += k1[t] * p[:, t:t + W]
+    out = np.zeros((H, W), np.float32)
+    for t in range(k):
+        out += k1[t] * tmp[t:t + H]
+    return out
+
+
+def post_dark_udp(coords, batch_heatmaps, kernel=3):
+    """utils/post_processing/evaluation/top_down_eval.py:275-337."""
+    batch_heatmaps = batch_heatmaps.copy()
+    B, K, H, W = batch_heatmaps.shape
+    N = coords.shape[0]
+    for b in range(B):
+        for k in range(K):
+            batch_heatmaps[b, k] = gaussian_blur_reflect(batch_heatmaps[b, k], kernel)
+    np.clip(batch_heatmaps, 0.001, 50, batch_heatmaps)
+    np.log(batch_heatmaps, batch_heatmaps)
+    pad = np.pad(batch_heatmaps, ((0, 0), (0, 0), (1, 1), (1, 1)), mode="edge").flatten()
+    index = coords[..., 0] + 1 + (coords[..., 1] + 1) * (W + 2)
+    index += (W + 2) * (H + 2) * np.arange(0, B * K).reshape(-1, K)
+    index = index.astype(int).reshape(-1, 1)
+    i_, ix1, iy1 = pad[index], pad[index + 1], pad[index + W + 2]
+    ix1y1, ix1_y1_ = pad[index + W + 3], pad[index - W - 3]
+    ix1_, iy1_ = pad[index - 1], pad[index - 2 - W]
+    dx, dy = 0.5 * (ix1 - ix1_), 0.5 * (iy1 - iy1_)
+    derivative = np.concatenate([dx, dy], axis=1).reshape(N, K, 2, 1)
+    dxx, dyy = ix1 - 2 * i_ + ix1_, iy1 - 2 * i_ + iy1_
+    dxy = 0.5 * (ix1y1 - ix1 - iy1 + i_ + i_ - ix1_ - iy1_ + ix1_y1_)
+    hessian = np.concatenate([dxx, dxy, dxy, dyy], axis=1).reshape(N, K, 2, 2)
+    hessian = np.linalg.inv(hessian + np.finfo(np.float32).eps * np.eye(2))
+    coords = coords - np.einsum("ijmn,ijnk->ijmk", hessian, derivative).squeeze()
+    return coords.astype(np.float32)
+
+
+def keypoints_from_heatmaps_udp(heatmaps, center, scale, kernel=11):
+    """keypoints_from_heatmaps(use_udp=True, target_type='GaussianHeatmap') (top_down_eval.py:404-411, 455-463)."""
+    heatmaps = heatmaps.copy()
+    N, K, H, W = heatmaps.shape
+    hm_preds, maxvals = get_max_preds(heatmaps)
+    hm_preds = post_dark_udp(hm_preds, heatmaps, kernel)
+    preds = hm_preds.copy()
+    for i in range(N):
+        preds[i] = transform_preds(preds[i], center[i], scale[i], [W, H], use_udp=True)
+    return hm_preds, preds, maxvals

@@ -272,6 +272,20 @@ def main():
         enc[f"{tag}_max"] = flat.max(2)
         enc[f"{tag}_sum"] = flat.astype(np.float64).sum(2)
         enc[f"{tag}_full_first2"] = T[:2]
+    # UDP encoding (generateTarget.py:160-236, pure numpy in the reference)
+    G = gt.TopDownGenerateTarget(sigma=2, encoding="UDP")
+    T, Wt = [], []
+    for a, v in zip(joints, vis):
+        ai = dict(num_joints=21, image_size=np.array([256, 256]), heatmap_size=np.array([64, 64]), joint_weights=None,
+                  use_different_joint_weights=False)
+        tr, wr = G._udp_generate_target(ai, a, v, 2)
+        to, wo = onp.udp_generate_target(a, v, [256, 256], [64, 64], 2)
+        assert np.array_equal(tr, to) and np.array_equal(wr, wo)
+        T.append(tr); Wt.append(wr)
+    T, Wt = np.stack(T), np.stack(Wt)
+    flat = T.reshape(T.shape[0], 21, -1)
+    enc.update(udp_weight=Wt, udp_argmax=flat.argmax(2).astype(np.int32), udp_max=flat.max(2),
+               udp_sum=flat.astype(np.float64).sum(2), udp_full_first2=T[:2])
     np.savez_compressed(os.path.join(HERE, "encode.npz"), joints=joints, visible=vis, **enc)
 
     # ---- decode: argmax (+ties, non-positive maps), 'default' shift, transform_preds, PCK/AUC/EPE

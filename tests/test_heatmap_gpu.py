@@ -214,8 +214,42 @@ def test_gpu_input_path(dev):
         jr[:, :2] = (np.concatenate([joints[n, :, :2], np.ones((21, 1))], 1) @ M.T)
         jr[vis[n, :, 0] == 0] = joints[n][vis[n, :, 0] == 0]
         assert np.abs(j[n] - jr).max() < 1e-3
+    # UDP variant (get_warp_matrix + warp_affine_joints: every joint is mapped)
+    out, j = pipeline.affine_warp_normalize(img, center, scale, rot, [64, 64], joints, vis, use_udp=True)
+    out, j = out.cpu().numpy(), j.cpu().numpy()
+    for n in range(N):
+        ref, M = onp.warp_affine_normalize(img[n], center[n], scale[n], rot[n], [64, 64], use_udp=True)
+        diff = np.abs(out[n] - ref)
+        assert (diff > 1e-5).mean() < 0.05 and diff.max() <= 1.05 * level / 0.98, ("udp", n, diff.max())
+        jr = joints[n].copy()
+        jr[:, :2] = (np.concatenate([joints[n, :, :2], np.ones((21, 1))], 1) @ M.T)
+        assert np.abs(j[n] - jr).max() < 1e-3
     # and the whole evaluation pipeline object: crops + targets from the transformed joints
     cfg = litehandnet_cfg("B", image_size=64)
     pipe = pipeline.TopDownBatchPipeline(cfg)
     x, meta = pipe(img, center, scale, rot, joints, vis)
     assert x.shape == (N, 3, 64, 64) and meta["target"].shape == (N, 21, 16, 16) and meta["target_weight"].shape[:2] == (N, 21)
+
+
+def test_udp_encode_and_decode(dev, golden_dir):
+    """UDP (use_udp / encoding='UDP', config/mynet/_3_freihand2d_224x224_udp.py): target maps against the
+    reference-generated fixture (float64 exp rounded once: <= 1 ulp, argmax / weights exact); decode
+    (_get_max_preds + post_dark_udp + UDP back-transform) against the numpy oracle, 2e-3 heatmap px -- the Gaussian blur
+    inside post_dark_udp is cv2's (absent): parity unpinned, as for DARK."""
+    from litehandnet_amd import heatmap
+    g = np.load(os.path.join(golden_dir, "encode.npz"))
+    t, w = heatmap.generate_target_batch(g["joints"], g["visible"], [256, 256], [64, 64], 2, True, encoding="UDP")
+    t, w = t.cpu().numpy(), w.cpu().numpy()
+    assert np.array_equal(w, g["udp_weight"])
+    flat = t.reshape(t.shape[0], 21, -1)
+    assert np.array_equal(flat.argmax(2), g["udp_argmax"])
+    assert _ulp_close(flat.max(2), g["udp_max"], 1) and _ulp_close(t[:2], g["udp_full_first2"], 1)
+    assert np.allclose(flat.astype(np.float64).sum(2), g["udp_sum"], rtol=1e-6)
+    d = np.load(os.path.join(golden_dir, "decode.npz"))
+    hm = np.maximum(d["heatmaps"], 0).astype(np.float32) + 1e-4
+    ohp, opr, omv = onp.keypoints_from_heatmaps_udp(hm, d["center"], d["scale"], 11)
+    hp, pr, mv = heatmap.keypoints_from_heatmaps(hm, d["center"], d["scale"], post_process="unbiased", kernel=11, use_udp=True)
+    assert np.array_equal(mv.cpu().numpy(), omv)
+    ok = np.isfinite(ohp).all(-1)
+    assert np.abs(hp.cpu().numpy() - ohp)[ok].max() < 2e-3, np.abs(hp.cpu().numpy() - ohp)[ok].max()
+    assert np.abs(pr.cpu().numpy() - opr)[ok].max() < 2e-2

@@ -173,3 +173,14 @@ def test_simdr(golden_dir):
     assert abs(float(l) - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
     assert abs(float(hm.grad.abs().sum()) - float(g["dheatmap_abs_sum"])) <= 1e-4 * float(g["dheatmap_abs_sum"])
     assert np.array_equal(onp.keypoints_from_simdr(sx, sy, g["center"], g["scale"], 2), g["keypoints"])
+
+
+def test_encode_udp(golden_dir):
+    g = np.load(os.path.join(golden_dir, "encode.npz"))
+    for i, (j, v) in enumerate(zip(g["joints"], g["visible"])):
+        t, w = onp.udp_generate_target(j, v, [256, 256], [64, 64], 2)
+        flat = t.reshape(21, -1)
+        assert np.array_equal(w, g["udp_weight"][i]) and np.array_equal(flat.argmax(1), g["udp_argmax"][i])
+        assert np.array_equal(flat.max(1), g["udp_max"][i])
+        if i < 2:
+            assert np.array_equal(t, g["udp_full_first2"][i])
