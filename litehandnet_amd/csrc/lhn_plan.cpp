@@ -80,6 +80,8 @@ static lhn_bnfin mkfin(const Plan* P, void* ws, const lhn_op& o, void* const* pa
 // The finalize runs as its own tiny launch unless LHN_FUSE_FINALIZE=1: measured on MI355X the in-kernel
 // last-block hand-off (one returning ticket atomic per workgroup on one word, ~88 tickets/us) costs MORE than
 // the ~5.5 us launch it replaces (variant B step 13.5 ms fused vs 12.9 ms separate), so separate is the default.
+// Fusing only the small maps does not pay either (B step, fuse when N*H*W <= 0 / 4096 / 16384 / 65536:
+// 10.57 / 10.62 / 10.67 / 10.86 ms): back-to-back launches overlap their ~5 us with the previous kernel's tail.
 static bool fuse_finalize() {
   static int v = -1;
   if (v < 0) {
