@@ -184,3 +184,31 @@ def test_encode_udp(golden_dir):
         assert np.array_equal(flat.max(1), g["udp_max"][i])
         if i < 2:
             assert np.array_equal(t, g["udp_full_first2"][i])
+
+
+def test_training_trajectory(golden_dir):
+    """The oracle under torch Adam follows the REAL reference's 6-step trajectory (tests/golden/make_golden_train.py).
+    Step 1 is tight; later steps are ill-conditioned (Adam moves noise-gradient parameters by +-lr), so the bar there is
+    the reference's own fp32-vs-float64 drift stored in the fixture."""
+    g = np.load(os.path.join(golden_dir, "train_B_64.npz"))
+    n, size = int(g["n"]), int(g["size"])
+    cfg = litehandnet_cfg("B")
+    m = torch_ref.get_model(cfg, p_drop=0.0)
+    m.load_state_dict(synth.synth_state_dict(m, int(g["weights_seed"])))
+    m.train()
+    crit = torch_ref.TopdownHeatmapLoss(cfg)
+    opt = torch.optim.Adam(m.parameters(), lr=float(g["lr"]))
+    losses = []
+    for s in range(int(g["steps"])):
+        x = synth.synth_images(n, size, 50 + 2 * s)
+        j = synth.synth_joints(n, 21, size, 51 + 2 * s)
+        t = np.stack([onp.msra_generate_target(a, np.ones_like(a), [size, size], [size // 4, size // 4])[0] for a in j])
+        loss, _ = crit(m(x), {"target": torch.from_numpy(t), "target_weight": torch.ones(n, 21, 1)})
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    ref, f64 = g["losses"], g["losses_f64"]
+    assert abs(losses[0] - ref[0]) <= 1e-6 * abs(ref[0])
+    for s in range(1, len(ref)):
+        assert abs(losses[s] - ref[s]) <= max(5 * abs(ref[s] - f64[s]), 2e-2 * abs(ref[s])), (s, losses, ref.tolist())
