@@ -90,7 +90,12 @@ class Engine:
         self.plans = {}
         self.anchor = None
         self.flat_grads = None
-        self.grads_via_autograd = False     # True: return per-parameter grads through autograd (DDP-hook compatible)
+        # True: per-parameter gradients are returned through autograd, so AccumulateGrad (and with it the hooks of
+        # torch's DistributedDataParallel, train/spawn_dist.py:49-52) fires for every parameter.  False: views of the
+        # flat gradient buffer are published straight into `param.grad` (no per-parameter launches; what
+        # litehandnet_amd.train.Trainer uses, doing the all-reduce itself).  None = automatic: through autograd whenever
+        # a torch.distributed process group exists, because the model may then sit inside a DDP wrapper.
+        self.grads_via_autograd = None
         self.p_drop = p_drop
         self.sync_override = None           # (world, all_reduce_fn): tests / custom process groups
 
@@ -106,6 +111,12 @@ class Engine:
         if not any(isinstance(m, nn.SyncBatchNorm) for m in self.module.modules()):
             return None
         return dist.get_world_size(), (lambda t: dist.all_reduce(t))
+
+    def _via_autograd(self):
+        if self.grads_via_autograd is not None:
+            return bool(self.grads_via_autograd)
+        import torch.distributed as dist
+        return dist.is_available() and dist.is_initialized()
 
     # -------------------------------------------------------------- state
     def _state(self, device):
@@ -185,7 +196,7 @@ class Engine:
         training = self.module.training
         if self.anchor is None or self.anchor.device != x.device:
             self._ensure_grads(self._state(x.device), x.device)
-        if self.grads_via_autograd and torch.is_grad_enabled():
+        if self._via_autograd() and torch.is_grad_enabled():
             return _PlanFn.apply(x, self.anchor, self, training, *self.param_list)
         anchor = self.anchor if torch.is_grad_enabled() else self.anchor.detach()
         return _PlanFn.apply(x, anchor, self, training)

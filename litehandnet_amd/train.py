@@ -84,6 +84,7 @@ class Trainer:
             eng = Engine(model)
             model.__dict__["_engine"] = eng
         self.engine = eng
+        eng.grads_via_autograd = False                 # this class owns the flat gradient and its all-reduce
         self.fp = FlatParams(model)
         self.fp.broadcast(0)
         for b in model.buffers():                      # BN running statistics start identical on every rank

@@ -121,3 +121,59 @@ def test_pck_parity_end_to_end(dev):
     assert cnt_ref == cnt_hip == 21
     assert 0.3 < pck_ref < 0.7                                        # a non-trivial operating point
     assert abs(pck_hip - pck_ref) <= 1e-3, (pck_hip, pck_ref)
+
+
+def test_ddp_wrapper_single_rank(dev):
+    """Boundary row (b): the model must survive `DistributedDataParallel(model, device_ids=[gpu], find_unused_parameters=...)`
+    (train/spawn_dist.py:49-52) with the reference's own loop and optimizer.  With a process group present the engine
+    hands every parameter's gradient to autograd, so DDP's reducer hooks fire; here: one rank over RCCL, gradients equal
+    to the direct (flat-buffer) path, and a second iteration runs (DDP raises if a reduction never finished)."""
+    import socket
+
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+
+    from litehandnet_amd import get_loss, get_model
+    from litehandnet_amd.engine import Engine
+    cfg = litehandnet_cfg("B")
+    cfg.MODEL["ca_dropout"] = 0.0
+    a, b = get_model(cfg), get_model(cfg)
+    sd = synth.synth_state_dict(torch_ref.get_model(cfg, p_drop=0.0), 71)
+    a.load_state_dict(sd)
+    b.load_state_dict(sd)
+    a.to(dev).train()
+    b.to(dev).train()
+    crit = get_loss(cfg)
+    x, meta, _ = _batch(72, 8, 64)
+    x, meta = x.to(dev), {k: v.to(dev) for k, v in meta.items()}
+    ea = Engine(a)
+    ea.grads_via_autograd = False
+    a.__dict__["_engine"] = ea
+    la, _ = crit(a(x), meta)
+    la.backward()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        ddp = DDP(b, device_ids=[dev.index], find_unused_parameters=True)
+        opt = torch.optim.Adam(b.parameters(), lr=5e-4)
+        lb, _ = crit(ddp(x), meta)
+        opt.zero_grad()
+        lb.backward()
+        assert abs(float(la.detach()) - float(lb.detach())) <= 1e-6 * abs(float(la.detach()))
+        gmax = max(float(p.grad.norm()) for p in a.parameters())
+        for (k, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+            assert pb.grad is not None, k
+            assert float((pa.grad - pb.grad).norm()) <= 1e-3 * float(pa.grad.norm()) + 1e-5 * gmax, k
+        before = [p.detach().clone() for p in b.parameters()]
+        opt.step()
+        assert any(not torch.equal(p0, p) for p0, p in zip(before, b.parameters()))
+        l2, _ = crit(ddp(x), meta)                      # second iteration through the wrapper
+        opt.zero_grad()
+        l2.backward()
+        assert torch.isfinite(l2.detach()) and all(torch.isfinite(p.grad).all() for p in b.parameters())
+    finally:
+        dist.destroy_process_group()
