@@ -184,6 +184,9 @@ class PlanBuilder:
     def ew(self, srcs, out_slope=1.0, out=None):
         """out = lrelu_{out_slope}(sum of sources); smaller sources are nearest-upsampled.  Plain output."""
         assert 1 <= len(srcs) <= 3
+        if out_slope == SLOPE_SILU and len(srcs) > 1:
+            # the SiLU backward recomputes the pre-activation from its (single, same-size) source: sum first
+            return self.ew([self.ew(srcs, 1.0)], SLOPE_SILU, out)
         H, W = max(s.H for s in srcs), max(s.W for s in srcs)
         if out is None:
             out = self.new(H, W, srcs[0].C)

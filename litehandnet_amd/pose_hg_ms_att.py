@@ -214,8 +214,6 @@ class MultiScaleAttentionHourglass(PlanModule):
         oup_dim = M.get("output_channel", cfg.DATASET.num_joints)
         num_block = M.get("num_block", [2, 2, 2])
         self.with_activation = M.get("output_acitivation", False)
-        if self.with_activation:
-            raise _lib.LhnError("mynet: output_acitivation=True (leaky_relu(preds, 0.5) on the head) is not built")
         self.p_drop = float(M.get("ca_dropout", 0.3))
         self.pre = my_pelee_stem(inp_dim)
         self.hgs = EncoderDecoder(num_stage, inp_dim, num_block, p_drop=self.p_drop)
@@ -229,6 +227,14 @@ class MultiScaleAttentionHourglass(PlanModule):
         y = self.features[0].emit(pb, y)
         y = pb.conv(y, self.features[1], self.features[2], slope=_slope_of(self.features[3]))
         return pb.conv(y, self.outs, None, nchw_out=True)
+
+    def forward(self, imgs):
+        preds = super().forward(imgs)
+        if self.with_activation:
+            # pose_hg_ms_att.py:251-252.  No shipped config can switch this on (they spell the key `output_activation` /
+            # `output_swish`, the model reads `output_acitivation`), so it stays one library elementwise op on the head.
+            preds = nn.functional.leaky_relu(preds, 0.5)
+        return preds
 
     def init_weights(self):
         # pose_hg_ms_att.py:256-262: conv weight ~ N(0,1), bias 0 (weight_init.py:28-32); BatchNorm gamma 1, beta 0

@@ -8,6 +8,7 @@ from torch import nn
 
 from . import _lib
 from .engine import PlanModule
+from .plan import SLOPE_SILU
 
 
 def _fold_branch(w, bn, out_w, out_b, k, cin_g, accumulate):
@@ -61,7 +62,9 @@ def act_slope(activation, inplace=False, positional=True):
         return 0.0
     if activation is nn.Identity:
         return 1.0
-    raise _lib.LhnError(f"activation {activation} is not expressible as a leaky slope (SiLU: not built yet)")
+    if activation is nn.SiLU:
+        return SLOPE_SILU          # not a leaky slope: applied by the elementwise combine (see RepConv.emit)
+    raise _lib.LhnError(f"activation {activation} is neither a leaky slope nor SiLU")
 
 
 class RepConv(PlanModule):
@@ -78,9 +81,12 @@ class RepConv(PlanModule):
             self.conv = conv_bn(in_channels, out_channels, kernel, stride, padding, dilation, groups)
 
     def emit(self, pb, x, out=None):
-        if hasattr(self, "rep_conv"):
-            return pb.conv(x, self.rep_conv, None, slope=self.slope, out=out)
-        return pb.conv(x, self.conv.conv, self.conv.bn, slope=self.slope, out=out)
+        conv, bn = (self.rep_conv, None) if hasattr(self, "rep_conv") else (self.conv.conv, self.conv.bn)
+        if self.slope == SLOPE_SILU:
+            # SiLU is not piecewise linear, so it cannot ride in the consumer's per-channel (scale, shift, slope) table:
+            # the convolution keeps its pending BatchNorm and one elementwise combine stores silu(BN(conv(x))).
+            return pb.ew([pb.conv(x, conv, bn, slope=1.0)], out_slope=SLOPE_SILU, out=out)
+        return pb.conv(x, conv, bn, slope=self.slope, out=out)
 
     def switch_to_deploy(self):
         """repblocks.py:46-73.  (The reference builds `rep_conv` with out_channels=in_channels and then overwrites

@@ -93,6 +93,23 @@ def test_repconv_pointwise(dev, cin, cout, act, inplace):
                  torch_ref.RepConv(cin, cout, 1, activation=a, inplace=inplace), _x(3, cin, 12, 20), dev)
 
 
+def test_silu_activation(dev):
+    """activation='silu' (liteHandNet.py:203-205 maps the cfg string to nn.SiLU): RepConv stores
+    silu(BN(conv)) through the elementwise combine, RepBlock / BasicBlock / BottleNeck apply it in their own combine."""
+    from litehandnet_amd import get_model, liteHandNet, repblocks
+    S = torch.nn.SiLU
+    _check_block(repblocks.RepConv(64, 64, 1, activation=S), torch_ref.RepConv(64, 64, 1, activation=S), _x(3, 64, 12, 20), dev)
+    _check_block(repblocks.RepConv(32, 32, 3, 1, 1, groups=32, activation=S, inplace=True),
+                 torch_ref.RepConv(32, 32, 3, 1, 1, groups=32, activation=S, inplace=True), _x(2, 32, 16, 24), dev, seed=1)
+    _check_block(repblocks.RepBlock(32, 32, 7, 1, 3, groups=32, activation=S),
+                 torch_ref.RepBlock(32, 32, 7, 1, 3, groups=32, activation=S), _x(2, 32, 16, 16), dev, seed=2)
+    _check_block(liteHandNet.BottleNeck(128, 4, S), torch_ref.BottleNeck(128, 4, S), _x(4, 128, 16, 16), dev, seed=3)
+    cfg = litehandnet_cfg("A", activation="silu")
+    cfg.MODEL["ca_dropout"] = 0.0
+    ours, ref = get_model(cfg), torch_ref.get_model(cfg, p_drop=0.0)
+    _check_block(ours, ref, synth.synth_images(8, 64, 13), dev, seed=14, no_dx=True, grad_tol=2e-2)
+
+
 @pytest.mark.parametrize("c,dil,stride", [(32, 1, 1), (64, 2, 1), (32, 1, 2)])
 def test_repconv_depthwise(dev, c, dil, stride):
     from litehandnet_amd import repblocks
@@ -385,6 +402,11 @@ def test_mynet_contract(dev):
     for (k, a), (_, b) in zip(ours.state_dict().items(), ref.state_dict().items()):
         assert a.shape == b.shape, k
     assert sum(p.numel() for p in ours.parameters()) == 2240405       # test_models_performance.ipynb
+    # output_acitivation=True (the reference's spelling, pose_hg_ms_att.py:232,251-252): leaky_relu(preds, 0.5) on the head
+    cfg.MODEL["output_acitivation"] = True
+    cfg.MODEL["ca_dropout"] = 0.0
+    ours, ref = get_model(cfg), torch_ref.get_model(cfg, p_drop=0.0)
+    _check_block(ours, ref, synth.synth_images(4, 128, 3), dev, seed=52, no_dx=True, grad_tol=2e-2)
 
 
 def test_model_M_128_golden(dev, golden_dir):
