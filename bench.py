@@ -166,7 +166,8 @@ def main():
         trainer.step(img, meta)
     sync()
     el = time.perf_counter() - t0
-    tmax = torch.tensor([el], dtype=torch.float64, device=dev)
+    # max over ranks (RCCL reduces device tensors; the gloo rehearsal backend, LHN_DIST_BACKEND=gloo, takes host tensors)
+    tmax = torch.tensor([el], dtype=torch.float64, device=dev if world > 1 and dist.get_backend() == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     el = float(tmax.item())

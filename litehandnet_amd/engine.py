@@ -110,7 +110,8 @@ class Engine:
             return None
         if not any(isinstance(m, nn.SyncBatchNorm) for m in self.module.modules()):
             return None
-        return dist.get_world_size(), (lambda t: dist.all_reduce(t))
+        from .train import all_reduce_sum_
+        return dist.get_world_size(), all_reduce_sum_
 
     def _via_autograd(self):
         if self.grads_via_autograd is not None:

@@ -25,8 +25,35 @@ def init_distributed(backend=None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group(backend or ("nccl" if torch.cuda.is_available() else "gloo"), rank=rank, world_size=world)
+        backend = backend or os.environ.get("LHN_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, local, world
+
+
+def _staged(t, group=None):
+    """RCCL ("nccl") reduces device tensors in place.  The gloo backend is the REHEARSAL path (several ranks sharing one
+    GPU, or no GPU at all): device tensors are staged through the host for it."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def all_reduce_sum_(t, group=None):
+    if _staged(t, group):
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
+def broadcast_(t, src=0, group=None):
+    if _staged(t, group):
+        h = t.cpu()
+        dist.broadcast(h, src, group=group)
+        t.copy_(h)
+    else:
+        dist.broadcast(t, src, group=group)
+    return t
 
 
 def prepare_model(model, cfg):
@@ -58,7 +85,7 @@ class FlatParams:
 
     def broadcast(self, src=0):
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.broadcast(self.flat, src)
+            broadcast_(self.flat, src)
 
 
 def allreduce_mean_(flat_grads, group=None):
@@ -67,7 +94,7 @@ def allreduce_mean_(flat_grads, group=None):
     if dist.is_available() and dist.is_initialized():
         w = dist.get_world_size(group)
         if w > 1:
-            dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=group)
+            all_reduce_sum_(flat_grads, group)
             flat_grads.div_(w)
     return flat_grads
 
@@ -89,7 +116,7 @@ class Trainer:
         self.fp.broadcast(0)
         for b in model.buffers():                      # BN running statistics start identical on every rank
             if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and b.is_floating_point():
-                dist.broadcast(b, 0)
+                broadcast_(b, 0)
         self.world = world_size
         lr = lr * world_size                           # dist_train.py:68
         if optimizer.lower() == "adam":
