@@ -225,4 +225,5 @@ def main():
 if __name__ == "__main__":
     main()
     if dist.is_available() and dist.is_initialized():
+        dist.barrier()                 # rank 0 is still timing its single-rank extras: tear the communicator down together
         dist.destroy_process_group()
