@@ -60,6 +60,9 @@ class _PlanFn(torch.autograd.Function):
             raise _lib.LhnError("backward through an eval-mode (running-statistics) plan is not supported")
         if plan.n_bwd == 0:
             raise _lib.LhnError("plan was compiled without a backward pass")
+        # torch semantics: a backward without a zero_grad in between ACCUMULATES.  Gradients published by the previous
+        # backward are views of the flat buffer this one overwrites, so keep them aside first (rare path: one 1-9 MB copy).
+        held = eng.flat_grads.clone() if (not ctx.via_autograd and eng.accumulate_published and eng._published_live()) else None
         eng.grad_parts.zero_()
         plan.set_grads(eng.part_views)
         dx, xc, dnchw = None, None, None
@@ -73,6 +76,8 @@ class _PlanFn(torch.autograd.Function):
         _lib.check(_lib.lib().lhn_reduce_replicas(_lib.ptr(eng.flat_grads), _lib.ptr(eng.grad_parts),
                                                   C.c_int64(eng.grad_stride), eng.GRAD_REPLICAS, C.c_int64(eng.grad_stride),
                                                   _lib.stream()), "lhn_reduce_replicas")
+        if held is not None:
+            eng.flat_grads.add_(held)
         if not eng.full:
             dx = plan.buf_data(plan.pb.in_ref, grad=True).permute(0, 3, 1, 2).contiguous()
         if ctx.via_autograd:
@@ -98,6 +103,9 @@ class Engine:
         self.grads_via_autograd = None
         self.p_drop = p_drop
         self.sync_override = None           # (world, all_reduce_fn): tests / custom process groups
+        # direct mode: add to gradients that are still published in `param.grad` (no zero_grad since the last backward).
+        # litehandnet_amd.train.Trainer owns the flat buffer and its zeroing, and switches this off.
+        self.accumulate_published = True
 
     def sync_config(self):
         """SyncBatchNorm (train/spawn_dist.py:37-38, cfg.TRAIN.syncBN): active when the model holds nn.SyncBatchNorm
@@ -151,6 +159,13 @@ class Engine:
                 views.append(None)
                 parts.append(None)
         self.grad_views, self.param_grad_views, self.param_list, self.part_views = views, pviews, plist, parts
+
+    def _published_live(self):
+        """True when some parameter's .grad is still the view this engine published (the user did not reset it)."""
+        for p, g in zip(self.param_list, self.param_grad_views):
+            if p.requires_grad:
+                return p.grad is not None and p.grad.data_ptr() == g.data_ptr()
+        return False
 
     def publish_grads(self):
         for p, g in zip(self.param_list, self.param_grad_views):

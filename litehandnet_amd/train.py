@@ -112,6 +112,7 @@ class Trainer:
             model.__dict__["_engine"] = eng
         self.engine = eng
         eng.grads_via_autograd = False                 # this class owns the flat gradient and its all-reduce
+        eng.accumulate_published = False               # ... and overwrites it every step (zero_grad of the flat leaf)
         self.fp = FlatParams(model)
         self.fp.broadcast(0)
         for b in model.buffers():                      # BN running statistics start identical on every rank

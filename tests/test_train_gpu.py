@@ -261,3 +261,31 @@ def test_two_rank_syncbn_data_parallel(dev, tmp_path):
         float(np.linalg.norm(r[0]["grads"] - ref_g) / np.linalg.norm(ref_g)), worst)
     assert np.allclose(r[0]["rv"], sd[k].cpu().numpy(), rtol=1e-4, atol=1e-6)
     assert np.array_equal(r[0]["rv"], r[1]["rv"])
+
+
+def test_gradient_accumulation_semantics(dev):
+    """torch semantics outside the Trainer: backward without zero_grad accumulates into param.grad, zero_grad resets."""
+    from litehandnet_amd import litehourglass as lh
+    m = lh.MSRB(64, 64, "ca", p_drop=0.0)
+    m.load_state_dict(synth.synth_state_dict(torch_ref.MSRB(64, 64, "ca", 0.0), 91))
+    m.to(dev).train()
+    x = torch.randn(4, 64, 16, 16, generator=torch.Generator().manual_seed(5)).to(dev)
+    g = torch.randn(4, 64, 16, 16, generator=torch.Generator().manual_seed(6)).to(dev)
+
+    def rel(a, b):
+        return float((a - b).norm() / (b.norm() + 1e-12))
+    m(x).backward(g)
+    g1 = {k: p.grad.clone() for k, p in m.named_parameters()}
+    # BatchNorm running statistics move between the passes, the batch-statistics gradients do not depend on them
+    m(x).backward(g)
+    for k, p in m.named_parameters():
+        assert rel(p.grad, 2 * g1[k]) < 1e-4, k
+    m.zero_grad()
+    m(x).backward(g)
+    for k, p in m.named_parameters():
+        assert rel(p.grad, g1[k]) < 1e-4, k
+    for p in m.parameters():                       # in-place zeroing keeps the published views: still a fresh gradient
+        p.grad.zero_()
+    m(x).backward(g)
+    for k, p in m.named_parameters():
+        assert rel(p.grad, g1[k]) < 1e-4, k
