@@ -37,6 +37,9 @@ class _PlanFn(torch.autograd.Function):
     def forward(ctx, x, anchor, eng, training, *params):
         plan = eng.plan_for(x, with_backward=torch.is_grad_enabled() or ctx.needs_input_grad[0] or anchor.requires_grad)
         ctx.eng, ctx.plan, ctx.training, ctx.via_autograd = eng, plan, training, len(params) > 0
+        if eng.full and ctx.needs_input_grad[0]:
+            raise _lib.LhnError("the gradient with respect to the input image is not built (the stem backward computes "
+                                "weight gradients only): pass the image without requires_grad")
         plan.refresh_params()
         xc = x.contiguous()
         if not eng.full:
@@ -136,6 +139,8 @@ class Engine:
                 raise _lib.LhnError("module parameters must live on the input's GPU (call .cuda() first)")
             if not t.is_contiguous():
                 raise _lib.LhnError("parameters must be contiguous")
+            if t.is_floating_point() and t.dtype != torch.float32:
+                raise _lib.LhnError(f"parameters and buffers must be float32 (found {t.dtype}): the kernels compute in fp32")
         return tensors
 
     def _ensure_grads(self, tensors, device):

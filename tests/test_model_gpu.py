@@ -52,7 +52,7 @@ def _check_block(ours, ref, x, dev, seed=0, fwd_tol=FWD_TOL, grad_tol=GRAD_TOL, 
     if pick is not None:
         y32 = y32[pick]
     y32.backward(g)
-    xg = x.clone().to(dev).requires_grad_()
+    xg = x.clone().to(dev).requires_grad_(not no_dx)      # whole models take the image without a gradient
     yg = ours(xg)
     assert yg.shape == yr.shape
     assert _rel(yg, yr) < max(fwd_tol, 3 * _rel(y32, yr)), ("forward", _rel(yg, yr), _rel(y32, yr))
@@ -176,7 +176,7 @@ def _model_case(dev, golden_dir, tag, variant="B", **kw):
     err = np.abs(y.detach().cpu().numpy() - y64n).max() / scale
     assert err <= max(3 * ref32_err, 1e-4), (err, ref32_err)
     loss, _ = get_loss(cfg)(y, {"target": torch.from_numpy(tgt), "target_weight": tw})
-    assert abs(float(loss) - float(l64)) <= max(3 * abs(float(g["loss"]) - float(l64)), 1e-5 * abs(float(l64)))
+    assert abs(float(loss.detach()) - float(l64)) <= max(3 * abs(float(g["loss"]) - float(l64)), 1e-5 * abs(float(l64)))
     loss.backward()
     gn32 = dict(zip(g["grad_keys"].tolist(), g["grad_norms"].tolist()))
     gn64 = {k: float(p.grad.norm()) for k, p in ref.named_parameters()}
@@ -582,3 +582,19 @@ def test_unsupported_width_fails_loudly(dev):
     m = get_model(litehandnet_cfg("B", channels=256)).to(dev).train()
     with pytest.raises(_lib.LhnError, match="unsupported channels|C="):
         m(torch.zeros(2, 3, 64, 64, device=dev))
+
+
+def test_unsupported_inputs_fail_loudly(dev):
+    """No silent wrong answers at the module boundary: image gradients, reduced-precision parameters, CPU tensors."""
+    from litehandnet_amd import _lib, get_model
+    cfg = litehandnet_cfg("B")
+    m = get_model(cfg).to(dev).train()
+    with pytest.raises(_lib.LhnError, match="input image"):
+        m(torch.zeros(2, 3, 64, 64, device=dev, requires_grad=True))
+    with pytest.raises(_lib.LhnError, match="float32"):
+        m(torch.zeros(2, 3, 64, 64, device=dev, dtype=torch.float16))
+    with pytest.raises(_lib.LhnError):
+        m(torch.zeros(2, 3, 64, 64))                      # CPU input: there is no CPU path
+    h = get_model(cfg).to(dev).half()
+    with pytest.raises(_lib.LhnError, match="float32"):
+        h(torch.zeros(2, 3, 64, 64, device=dev))
