@@ -165,6 +165,7 @@ def _model_case(dev, golden_dir, tag, variant="B", **kw):
     y64 = ref(synth.synth_images(n, size, seed).double())
     l64 = cfg.LOSS.loss_weight[0] * torch_ref.distance_loss(y64, torch.from_numpy(tgt).double(), tw.double())
     l64.backward()
+    l64 = l64.detach()
     y64n = y64.detach().numpy()
     scale = np.abs(y64n).max()
     ref32_err = np.abs(g["heatmap"] - y64n).max() / scale
