@@ -289,3 +289,18 @@ def test_gradient_accumulation_semantics(dev):
     m(x).backward(g)
     for k, p in m.named_parameters():
         assert rel(p.grad, g1[k]) < 1e-4, k
+
+
+def test_synthetic_training_learns(dev):
+    """End to end on the GPU: images of 21 colour-coded blobs -> backbone -> loss -> backward -> Adam, device-side target
+    encode / DARK decode / PCK (scripts/train_synthetic.py).  300 steps take PCK@0.2 from chance (~0.04) past 0.35
+    (measured 0.55; 0.91 after 1500 steps)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "train_synthetic.py"), "--steps", "300"],
+                         capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("step ")]
+    first, last = float(lines[0].split("PCK@0.2")[1].split()[0]), float(lines[-1].split("PCK@0.2")[1].split()[0])
+    assert first < 0.1 and last > 0.35, (first, last)
