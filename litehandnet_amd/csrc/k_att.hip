@@ -5,15 +5,16 @@
 // save layout (floats): ad[N*C] (dropout output = Linear input) | g[N*C] | mean[C] | invstd[C] | dad[N*C] (backward scratch)
 #include "lhn_common.h"
 
-// grid = ceil(C/32) blocks; thread = (channel lane 0..31, sample lane 0..7)
-__global__ void __launch_bounds__(256) k_att1(const float* __restrict__ pooled, const float* __restrict__ gamma,
+// grid = ceil(C/32) blocks; thread = (channel lane 0..31, sample lane 0..NL-1), NL = blockDim.x / 32 (32 as launched)
+__global__ void __launch_bounds__(1024) k_att1(const float* __restrict__ pooled, const float* __restrict__ gamma,
                                               const float* __restrict__ beta, float* __restrict__ rmean,
                                               float* __restrict__ rvar, int64_t* __restrict__ nbt,
                                               const float* __restrict__ w3, const float* __restrict__ b3,
                                               const float* __restrict__ mask, float* __restrict__ save, int N, int C, float eps,
                                               float momentum, int training, int stage, double* __restrict__ gsum,
                                               double count_scale) {
-  __shared__ double rs[8][32], rq[8][32];
+  __shared__ double rs[32][32], rq[32][32];
+  const int NL = blockDim.x >> 5;
   __shared__ float s_mean[32], s_inv[32];
   float* ad = save;
   float* smean = save + (int64_t)N * C * 2;
@@ -22,7 +23,7 @@ __global__ void __launch_bounds__(256) k_att1(const float* __restrict__ pooled, 
   const bool ok = c < C;
   double s = 0, q = 0;
   if (ok && training && stage != 2)
-    for (int n = nl; n < N; n += 8)
+    for (int n = nl; n < N; n += NL)
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         const float p = pooled[((int64_t)n * 9 + t) * C + c];
@@ -33,7 +34,7 @@ __global__ void __launch_bounds__(256) k_att1(const float* __restrict__ pooled, 
   rq[nl][cl] = q;
   __syncthreads();
   if (nl == 0 && ok) {
-    for (int j = 1; j < 8; ++j) {
+    for (int j = 1; j < NL; ++j) {
       s += rs[j][cl];
       q += rq[j][cl];
     }
@@ -70,7 +71,7 @@ __global__ void __launch_bounds__(256) k_att1(const float* __restrict__ pooled, 
 #pragma unroll
     for (int t = 0; t < 9; ++t) wt[t] = w3[c * 9 + t];
     const float bb = b3 ? b3[c] : 0.f;
-    for (int n = nl; n < N; n += 8) {
+    for (int n = nl; n < N; n += NL) {
       float a = bb;
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
@@ -128,7 +129,7 @@ __global__ void __launch_bounds__(256) k_att_bwd2(const float* __restrict__ wl, 
 }
 
 // backward of dropout, dw3x3, relu, BatchNorm; writes the 25-segment pooled gradient (lhn_dpool_store)
-__global__ void __launch_bounds__(256) k_att_bwd1(const float* __restrict__ pooled, const float* __restrict__ gamma,
+__global__ void __launch_bounds__(1024) k_att_bwd1(const float* __restrict__ pooled, const float* __restrict__ gamma,
                                                   const float* __restrict__ beta, const float* __restrict__ w3,
                                                   const float* __restrict__ mask, const float* __restrict__ save,
                                                   const float* __restrict__ dad, float* __restrict__ dpool, int cs, int coff,
@@ -136,8 +137,9 @@ __global__ void __launch_bounds__(256) k_att_bwd1(const float* __restrict__ pool
                                                   float* __restrict__ dw3, float* __restrict__ db3, int N, int C,
                                                   int training, int stage, double* __restrict__ gsum, double count_scale,
                                                   float pgrad_scale) {
-  __shared__ double rs[8][32], rq[8][32];
-  __shared__ float rw[8][32][10];
+  __shared__ double rs[32][32], rq[32][32];
+  const int NL = blockDim.x >> 5;
+  __shared__ float rw[32][32][10];
   const float* smean = save + (int64_t)N * C * 2;
   const float* sinv = smean + C;
   const int cl = threadIdx.x & 31, nl = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
@@ -154,7 +156,7 @@ __global__ void __launch_bounds__(256) k_att_bwd1(const float* __restrict__ pool
   double sd = 0, sdx = 0;
   float dbias = 0.f;
   if (ok)
-    for (int n = nl; n < N; n += 8) {
+    for (int n = nl; n < N; n += NL) {
       float da = dad[(int64_t)n * C + c];
       if (mask) da *= mask[(int64_t)n * C + c];
       dbias += da;
@@ -177,7 +179,7 @@ __global__ void __launch_bounds__(256) k_att_bwd1(const float* __restrict__ pool
   __syncthreads();
   sd = 0;
   sdx = 0;
-  for (int j = 0; j < 8; ++j) {
+  for (int j = 0; j < NL; ++j) {
     sd += rs[j][cl];
     sdx += rq[j][cl];
   }
@@ -185,7 +187,7 @@ __global__ void __launch_bounds__(256) k_att_bwd1(const float* __restrict__ pool
   if (nl == 0 && ok && stage != 2) {
     for (int t = 0; t < 10; ++t) {
       float v = 0.f;
-      for (int j = 0; j < 8; ++j) v += rw[j][cl][t];
+      for (int j = 0; j < NL; ++j) v += rw[j][cl][t];
       if (t < 9) dw3[c * 9 + t] += v;
       else if (db3) db3[c] += v;
     }
@@ -208,7 +210,7 @@ __global__ void __launch_bounds__(256) k_att_bwd1(const float* __restrict__ pool
   if (ok) {
     const double cnt = 9.0 * N * count_scale;
     const float m1 = (float)(sd / cnt), m2 = (float)(sdx / cnt);
-    for (int n = nl; n < N; n += 8) {
+    for (int n = nl; n < N; n += NL) {
       float da = dad[(int64_t)n * C + c];
       if (mask) da *= mask[(int64_t)n * C + c];
       float dseg[9];
@@ -233,7 +235,7 @@ extern "C" int lhn_att_mlp_fwd(const float* pooled, const float* gamma, const fl
   LHN_CHECK_ARG(C > 0 && C <= 256 && N > 0, "lhn_att_mlp_fwd: C=%d (<=256)", C);
   hipStream_t s = (hipStream_t)stream;
   LHN_CHECK_ARG(stage == 0 || (gsum && stage >= 1 && stage <= 2 && count_scale >= 1), "lhn_att_mlp_fwd: stage %d needs gsum", stage);
-  hipLaunchKernelGGL(k_att1, dim3((C + 31) / 32), dim3(256), 0, s, pooled, gamma, beta, rmean, rvar, nbt, w3, b3, dropmask, save, N,
+  hipLaunchKernelGGL(k_att1, dim3((C + 31) / 32), dim3(1024), 0, s, pooled, gamma, beta, rmean, rvar, nbt, w3, b3, dropmask, save, N,
                      C, eps, momentum, training, stage, gsum, stage ? count_scale : 1.0);
   if (stage != 1) hipLaunchKernelGGL(k_att2, dim3(N), dim3(128), 0, s, wl, bl, save, gate, gate_stride, gate_coff, N, C);
   LHN_CHECK_LAUNCH("lhn_att_mlp_fwd");
@@ -251,7 +253,7 @@ extern "C" int lhn_att_mlp_bwd(const float* pooled, const float* gamma, const fl
   float* dad = save + (int64_t)N * C * 2 + 2 * C;
   LHN_CHECK_ARG(stage == 0 || (gsum && stage >= 1 && stage <= 2 && count_scale >= 1), "lhn_att_mlp_bwd: stage %d needs gsum", stage);
   if (stage != 2) hipLaunchKernelGGL(k_att_bwd2, dim3(N), dim3(256), 0, s, wl, save, dgate, dad, dwl, dbl, N, C);
-  hipLaunchKernelGGL(k_att_bwd1, dim3((C + 31) / 32), dim3(256), 0, s, pooled, gamma, beta, w3, dropmask, save, dad, dpool, cstride,
+  hipLaunchKernelGGL(k_att_bwd1, dim3((C + 31) / 32), dim3(1024), 0, s, pooled, gamma, beta, w3, dropmask, save, dad, dpool, cstride,
                      coff, H, W, dgamma, dbeta, dw3, db3, N, C, 1, stage, gsum, stage ? count_scale : 1.0, stage ? pgrad_scale : 1.f);
   LHN_CHECK_LAUNCH("lhn_att_mlp_bwd");
   return 0;

@@ -320,7 +320,7 @@ __global__ void __launch_bounds__(256) k_avgpool_bwd(lhn_view x, const float* __
 // ------------------------------------------------------------------ channel attention MLP (common.py:40-66)
 // save layout (floats): a[N*C] | ahat[N*C] | h[N*C/2] | g[N*C] | mean[C] | invstd[C]
 // grid = C/32 blocks; thread = (channel lane 0..31, sample lane 0..7)
-__global__ void __launch_bounds__(256) k_ca1(const float* __restrict__ pooled, const float* __restrict__ w3,
+__global__ void __launch_bounds__(1024) k_ca1(const float* __restrict__ pooled, const float* __restrict__ w3,
                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                              float* __restrict__ rmean, float* __restrict__ rvar, int64_t* __restrict__ nbt,
                                              const float* __restrict__ mask, float* __restrict__ save, int N, int C,
@@ -328,7 +328,8 @@ __global__ void __launch_bounds__(256) k_ca1(const float* __restrict__ pooled, c
                                              double count_scale) {
   // stage 0: everything; SyncBatchNorm splits the kernel around an all-reduce of gsum[2][C] (stage 1: conv + local sums,
   // stage 2: statistics over N*count_scale samples + normalisation)
-  __shared__ double rs[8][32], rq[8][32];
+  __shared__ double rs[32][32], rq[32][32];
+  const int NL = blockDim.x >> 5;   // sample lanes (32 at the 1024-thread launch)
   __shared__ float s_sc[32], s_sh[32];
   float* a = save;
   float* ahat = save + (int64_t)N * C;
@@ -341,7 +342,7 @@ __global__ void __launch_bounds__(256) k_ca1(const float* __restrict__ pooled, c
   for (int t = 0; t < 9; ++t) wt[t] = ok ? w3[c * 9 + t] : 0.f;
   double s = 0, q = 0;
   if (ok && stage != 2)
-    for (int n = nl; n < N; n += 8) {
+    for (int n = nl; n < N; n += NL) {
       float v = 0.f;
 #pragma unroll
       for (int t = 0; t < 9; ++t) v += pooled[((int64_t)n * 9 + t) * C + c] * wt[t];
@@ -353,7 +354,7 @@ __global__ void __launch_bounds__(256) k_ca1(const float* __restrict__ pooled, c
   rq[nl][cl] = q;
   __syncthreads();
   if (nl == 0 && ok) {
-    for (int j = 1; j < 8; ++j) {
+    for (int j = 1; j < NL; ++j) {
       s += rs[j][cl];
       q += rq[j][cl];
     }
@@ -395,7 +396,7 @@ __global__ void __launch_bounds__(256) k_ca1(const float* __restrict__ pooled, c
   __syncthreads();
   if (ok) {
     const float sc = s_sc[cl], sh = s_sh[cl];
-    for (int n = nl; n < N; n += 8) {
+    for (int n = nl; n < N; n += NL) {
       float v = a[(int64_t)n * C + c] * sc + sh;
       if (mask) v *= mask[(int64_t)n * C + c];
       ahat[(int64_t)n * C + c] = v;
@@ -473,16 +474,21 @@ __global__ void __launch_bounds__(256) k_ca_bwd2(const float* __restrict__ w1, c
   const float* ahat = save + (int64_t)N * C + (int64_t)n * C;
   const float* h = save + (int64_t)N * C * 2 + (int64_t)n * Ch;
   const float* g = save + (int64_t)N * C * 2 + (int64_t)N * Ch + (int64_t)n * C;
+  // two blocks per sample (blockIdx.y): 0 = second layer's parameter gradients, 1 = back through it and the first layer
+  const bool second = blockIdx.y == 0;
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     const float gg = g[c];
     const float dv = dgate[(int64_t)n * C + c] * gg * (1.f - gg);
     sdv[c] = dv;
     sa[c] = ahat[c];
-    atomicAdd(db2 + c, dv);
+    if (second) atomicAdd(db2 + c, dv);
   }
   for (int j = threadIdx.x; j < Ch; j += blockDim.x) shh[j] = h[j];
   __syncthreads();
-  for (int i = threadIdx.x; i < C * Ch; i += blockDim.x) atomicAdd(dw2 + i, sdv[i / Ch] * shh[i % Ch]);
+  if (second) {
+    for (int i = threadIdx.x; i < C * Ch; i += blockDim.x) atomicAdd(dw2 + i, sdv[i / Ch] * shh[i % Ch]);
+    return;
+  }
   for (int j = threadIdx.x; j < Ch; j += blockDim.x) {
     float d = 0.f;
     for (int c = 0; c < C; ++c) d += w2[c * Ch + j] * sdv[c];
@@ -499,7 +505,7 @@ __global__ void __launch_bounds__(256) k_ca_bwd2(const float* __restrict__ w1, c
   }
 }
 // grid = C/32 blocks; thread = (channel lane, sample lane) as in k_ca1
-__global__ void __launch_bounds__(256) k_ca_bwd1(const float* __restrict__ pooled, const float* __restrict__ w3,
+__global__ void __launch_bounds__(1024) k_ca_bwd1(const float* __restrict__ pooled, const float* __restrict__ w3,
                                                  const float* __restrict__ gamma, const float* __restrict__ mask,
                                                  const float* __restrict__ save, const float* __restrict__ dahat,
                                                  float* __restrict__ dpool, int cs, int coff, int H, int W,
@@ -507,8 +513,9 @@ __global__ void __launch_bounds__(256) k_ca_bwd1(const float* __restrict__ poole
                                                  float* __restrict__ dbeta, int N, int C, int training, int stage,
                                                  double* __restrict__ gsum, double count_scale, float pgrad_scale) {
   // stage 0: everything; SyncBatchNorm: stage 1 = local (sum d, sum d*xhat) -> gsum[2][C], all-reduce, stage 2 = the rest
-  __shared__ double rs[8][32], rq[8][32];
-  __shared__ float rw[8][32][9];
+  __shared__ double rs[32][32], rq[32][32];
+  __shared__ float rw[32][32][9];
+  const int NL = blockDim.x >> 5;   // sample lanes (32 at the 1024-thread launch)
   const float* a = save;
   const float* smean = save + (int64_t)N * C * 3 + (int64_t)N * (C / 2);
   const float* sinv = smean + C;
@@ -517,7 +524,7 @@ __global__ void __launch_bounds__(256) k_ca_bwd1(const float* __restrict__ poole
   const float mean = ok ? smean[c] : 0.f, invstd = ok ? sinv[c] : 0.f, gm = ok ? gamma[c] : 0.f;
   double sd = 0, sdx = 0;
   if (ok && stage != 2)
-    for (int n = nl; n < N; n += 8) {
+    for (int n = nl; n < N; n += NL) {
       float d = dahat[(int64_t)n * C + c];
       if (mask) d *= mask[(int64_t)n * C + c];
       const float xh = (a[(int64_t)n * C + c] - mean) * invstd;
@@ -529,7 +536,7 @@ __global__ void __launch_bounds__(256) k_ca_bwd1(const float* __restrict__ poole
   __syncthreads();
   sd = 0;
   sdx = 0;
-  for (int j = 0; j < 8; ++j) {
+  for (int j = 0; j < NL; ++j) {
     sd += rs[j][cl];
     sdx += rq[j][cl];
   }
@@ -558,7 +565,7 @@ __global__ void __launch_bounds__(256) k_ca_bwd1(const float* __restrict__ poole
     binv[t] = 1.f / (float)((lhn_bin_hi(bi, H) - lhn_bin_lo(bi, H)) * (lhn_bin_hi(bj, W) - lhn_bin_lo(bj, W)));
   }
   if (ok)
-    for (int n = nl; n < N; n += 8) {
+    for (int n = nl; n < N; n += NL) {
       float d = dahat[(int64_t)n * C + c];
       if (mask) d *= mask[(int64_t)n * C + c];
       const float xh = (a[(int64_t)n * C + c] - mean) * invstd;
@@ -579,7 +586,7 @@ __global__ void __launch_bounds__(256) k_ca_bwd1(const float* __restrict__ poole
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
       float v = 0.f;
-      for (int j = 0; j < 8; ++j) v += rw[j][cl][t];
+      for (int j = 0; j < NL; ++j) v += rw[j][cl][t];
       dw3[c * 9 + t] += v;
     }
   }
@@ -785,7 +792,7 @@ int lhn_ca_mlp_fwd(const float* pooled, const float* w3, const float* gamma, con
   LHN_CHECK_ARG(C > 0 && C <= 256 && C % 2 == 0 && N > 0, "lhn_ca_mlp_fwd: C=%d (<=256)", C);
   hipStream_t s = (hipStream_t)stream;
   LHN_CHECK_ARG(stage == 0 || (gsum && stage >= 1 && stage <= 2 && count_scale >= 1), "lhn_ca_mlp_fwd: stage %d needs gsum", stage);
-  hipLaunchKernelGGL(k_ca1, dim3((C + 31) / 32), dim3(256), 0, s, pooled, w3, gamma, beta, rmean, rvar, nbt, dropmask, save, N, C, eps, momentum, training, stage, gsum, stage ? count_scale : 1.0);
+  hipLaunchKernelGGL(k_ca1, dim3((C + 31) / 32), dim3(1024), 0, s, pooled, w3, gamma, beta, rmean, rvar, nbt, dropmask, save, N, C, eps, momentum, training, stage, gsum, stage ? count_scale : 1.0);
   if (stage != 1) hipLaunchKernelGGL(k_ca2, dim3(N), dim3(128), 0, s, w1, b1, w2, b2, save, gate, gate_stride, gate_coff, N, C);
   LHN_CHECK_LAUNCH("lhn_ca_mlp_fwd");
   return 0;
@@ -818,8 +825,8 @@ int lhn_ca_mlp_bwd(const float* pooled, const float* w3, const float* gamma, con
   hipStream_t s = (hipStream_t)stream;
   float* dahat = const_cast<float*>(save) + (int64_t)N * C * 3 + (int64_t)N * (C / 2) + 2 * C;
   LHN_CHECK_ARG(stage == 0 || (gsum && stage >= 1 && stage <= 2 && count_scale >= 1), "lhn_ca_mlp_bwd: stage %d needs gsum", stage);
-  if (stage != 2) hipLaunchKernelGGL(k_ca_bwd2, dim3(N), dim3(256), 0, s, w1, w2, save, dgate, dahat, dw1, db1, dw2, db2, N, C);
-  hipLaunchKernelGGL(k_ca_bwd1, dim3((C + 31) / 32), dim3(256), 0, s, pooled, w3, gamma, dropmask, save, dahat, dpool, cstride, coff, H, W, dw3, dgamma, dbeta, N, C, 1, stage, gsum, stage ? count_scale : 1.0, stage ? pgrad_scale : 1.f);
+  if (stage != 2) hipLaunchKernelGGL(k_ca_bwd2, dim3(N, 2), dim3(256), 0, s, w1, w2, save, dgate, dahat, dw1, db1, dw2, db2, N, C);
+  hipLaunchKernelGGL(k_ca_bwd1, dim3((C + 31) / 32), dim3(1024), 0, s, pooled, w3, gamma, dropmask, save, dahat, dpool, cstride, coff, H, W, dw3, dgamma, dbeta, N, C, 1, stage, gsum, stage ? count_scale : 1.0, stage ? pgrad_scale : 1.f);
   LHN_CHECK_LAUNCH("lhn_ca_mlp_bwd");
   return 0;
 }
