@@ -228,7 +228,9 @@ extern "C" int lhn_conv_pw_fwd(const lhn_view* x, const float* w, const float* b
 // and issues   dX[m][ci] = sum_co dYs[m][co] * W[co][ci]   (K = Cout)   -> global, store or accumulate
 //              dW[co][ci] += sum_m dYs[m][co] * Xs[m][ci]  (K = 64)     -> registers across tiles, one
 //                                                                           fp32 atomic add per block at the end
-template <int CIN, int NTO>
+// NCHW = the head's gradient arrives as a plain NCHW tensor (dy_nchw); a template flag so that the NHWC instances do not
+// carry its prefetch registers (they cost k_pw_bwd<64,2> 44 -> 56 us when the switch was a runtime one)
+template <int CIN, int NTO, bool NCHW>
 __global__ void __launch_bounds__(256) k_pw_bwd(lhn_view x, const float* __restrict__ w, lhn_view y, lhn_gradview gy,
                                                 float* __restrict__ dx, int dx_acc, float* __restrict__ dw,
                                                 float* __restrict__ dbias, int stride, const float* __restrict__ dy_nchw,
@@ -268,7 +270,7 @@ __global__ void __launch_bounds__(256) k_pw_bwd(lhn_view x, const float* __restr
   const bool ych_ok = 4 * yc4 < cout;  // cout is a multiple of 4 on the NHWC path
   Xf4 yxf;
   Gr4 ygr;
-  if (!dy_nchw && ych_ok) {
+  if (!NCHW && ych_ok) {
     yxf = lhn_load_xf(y, yabs);
     ygr = lhn_load_coef(gy, y.cstride, yabs);
   }
@@ -290,13 +292,23 @@ __global__ void __launch_bounds__(256) k_pw_bwd(lhn_view x, const float* __restr
   // global loads of a tile go to registers (issue) one iteration ahead of their transform + LDS store (commit), so the
   // next tile's HBM latency overlaps this tile's MFMA work
   f4 xraw[XPF], yraw[YPF], ydz[YPF];
+  constexpr int NCHW_PF = NCHW ? 64 * COP / 256 : 1;   // NCHW head: dY elements per thread and tile, prefetched like the rest
+  float ynch[NCHW_PF];
   auto issue = [&](int tile) __attribute__((always_inline)) {
+    if constexpr (NCHW) {
+#pragma unroll
+      for (int k = 0; k < NCHW_PF; ++k) {
+        const int i = tid + 256 * k, row = i & 63, co = i >> 6, m = min(tile * 64 + row, M - 1);
+        const int n = m / HoWo, p = m - n * HoWo;
+        ynch[k] = co < cout ? dy_nchw[((int64_t)n * cout + co) * HoWo + p] : 0.f;
+      }
+    }
 #pragma unroll
     for (int p = 0; p < XPF; ++p) {
       const int m = min(tile * 64 + xr0 + p * XRP, M - 1);      // clamped (branch-free); commit() zeroes rows >= M
       xraw[p] = *reinterpret_cast<const f4*>(x.data + in_pix(m) * x.cstride + xabs);
     }
-    if (!dy_nchw && ych_ok) {
+    if (!NCHW && ych_ok) {
 #pragma unroll
       for (int p = 0; p < YPF; ++p) {
         const int m = min(tile * 64 + yr0 + p * YRP, M - 1);
@@ -316,15 +328,11 @@ __global__ void __launch_bounds__(256) k_pw_bwd(lhn_view x, const float* __restr
       }
       *reinterpret_cast<f4*>(Xs + row * LDX + 4 * xc4) = v;
     }
-    if (dy_nchw) {
-      for (int i = tid; i < 64 * COP; i += 256) {
-        const int row = i & 63, co = i >> 6, m = tile * 64 + row;
-        float v = 0.f;
-        if (m < M && co < cout) {
-          const int n = m / HoWo, p = m - n * HoWo;
-          v = dy_nchw[((int64_t)n * cout + co) * HoWo + p];
-        }
-        dYs[row * LDY + co] = v;
+    if constexpr (NCHW) {
+#pragma unroll
+      for (int k = 0; k < NCHW_PF; ++k) {
+        const int i = tid + 256 * k, row = i & 63, co = i >> 6;
+        dYs[row * LDY + co] = (tile * 64 + row < M) ? ynch[k] : 0.f;
       }
     } else {
 #pragma unroll
@@ -426,7 +434,7 @@ __global__ void __launch_bounds__(256) k_pw_bwd(lhn_view x, const float* __restr
     }
   }
   if (dbias) {
-    if (dy_nchw) {
+    if (NCHW) {
       // head: few channels; recompute per-channel sums is cheap -- done by a separate tiny pass on the host side
     } else if (ych_ok) {
       atomicAdd(dbias + 4 * yc4 + 0, bsum.x);
@@ -455,8 +463,8 @@ __global__ void __launch_bounds__(256) k_bias_grad_nchw(const float* __restrict_
   if (threadIdx.x == 0) atomicAdd(db + co, (float)(red[0] + red[1] + red[2] + red[3]));
 }
 
-template <int CIN, int NTO>
-static int launch_pw_bwd(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx, int dx_acc,
+template <int CIN, int NTO, bool NCHW>
+static int launch_pw_bwd_t(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx, int dx_acc,
                          float* dw, float* dbias, int stride, const float* dy_nchw, int cout, int nrep, int64_t rep_stride,
                          hipStream_t s) {
   const int M = y->N * y->H * y->W;
@@ -465,7 +473,7 @@ static int launch_pw_bwd(const lhn_view* x, const float* w, const lhn_view* y, c
   const size_t lds = (size_t)(COP * (CIN + 4) + 64 * (COP + 4) + 64 * (CIN + 4)) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pw_bwd<CIN, NTO>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pw_bwd<CIN, NTO, NCHW>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess) {
       lhn_set_error("lhn_conv_pw_bwd: cannot reserve %zu B of LDS", lds);
       return 2;
@@ -473,16 +481,24 @@ static int launch_pw_bwd(const lhn_view* x, const float* w, const lhn_view* y, c
     attr_done = true;
   }
   static int per_cu = 0;
-  if (!per_cu) per_cu = lhn_resident_per_cu(&k_pw_bwd<CIN, NTO>, lds, 3);
+  if (!per_cu) per_cu = lhn_resident_per_cu(&k_pw_bwd<CIN, NTO, NCHW>, lds, 3);
   int grid = lhn_num_cus() * per_cu;
   if (grid > ntiles) grid = ntiles;
   lhn_gradview g = *gy;
-  hipLaunchKernelGGL((k_pw_bwd<CIN, NTO>), dim3(grid), dim3(256), lds, s, *x, w, *y, g, dx, dx_acc, dw, dbias, stride, dy_nchw,
+  hipLaunchKernelGGL((k_pw_bwd<CIN, NTO, NCHW>), dim3(grid), dim3(256), lds, s, *x, w, *y, g, dx, dx_acc, dw, dbias, stride, dy_nchw,
                      cout, M, ntiles, nrep, rep_stride);
   if (dbias && dy_nchw)
     hipLaunchKernelGGL(k_bias_grad_nchw, dim3(cout, y->N < 16 ? y->N : 16), dim3(256), 0, s, dy_nchw, dbias, y->N, cout,
                        y->H * y->W);
   return 0;
+}
+
+template <int CIN, int NTO>
+static int launch_pw_bwd(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx, int dx_acc,
+                         float* dw, float* dbias, int stride, const float* dy_nchw, int cout, int nrep, int64_t rep_stride,
+                         hipStream_t s) {
+  if (dy_nchw) return launch_pw_bwd_t<CIN, NTO, true>(x, w, y, gy, dx, dx_acc, dw, dbias, stride, dy_nchw, cout, nrep, rep_stride, s);
+  return launch_pw_bwd_t<CIN, NTO, false>(x, w, y, gy, dx, dx_acc, dw, dbias, stride, dy_nchw, cout, nrep, rep_stride, s);
 }
 
 int lhn_pw_bwd_split(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx, int dx_accumulate,
