@@ -231,7 +231,7 @@ extern "C" int lhn_conv_pw_fwd(const lhn_view* x, const float* w, const float* b
 // NCHW = the head's gradient arrives as a plain NCHW tensor (dy_nchw); a template flag so that the NHWC instances do not
 // carry its prefetch registers (they cost k_pw_bwd<64,2> 44 -> 56 us when the switch was a runtime one)
 template <int CIN, int NTO, bool NCHW>
-__global__ void __launch_bounds__(256) k_pw_bwd(lhn_view x, const float* __restrict__ w, lhn_view y, lhn_gradview gy,
+__global__ void __launch_bounds__(256, (CIN == 32 && NTO == 1 && !NCHW) ? 4 : (CIN <= 64 && NTO <= 2 && !NCHW) ? 3 : 1) k_pw_bwd(lhn_view x, const float* __restrict__ w, lhn_view y, lhn_gradview gy,
                                                 float* __restrict__ dx, int dx_acc, float* __restrict__ dw,
                                                 float* __restrict__ dbias, int stride, const float* __restrict__ dy_nchw,
                                                 int cout, int M, int ntiles, int nrep, int64_t rep_stride) {
@@ -481,7 +481,7 @@ static int launch_pw_bwd_t(const lhn_view* x, const float* w, const lhn_view* y,
     attr_done = true;
   }
   static int per_cu = 0;
-  if (!per_cu) per_cu = lhn_resident_per_cu(&k_pw_bwd<CIN, NTO, NCHW>, lds, 3);
+  if (!per_cu) per_cu = lhn_resident_per_cu(&k_pw_bwd<CIN, NTO, NCHW>, lds, 4);
   int grid = lhn_num_cus() * per_cu;
   if (grid > ntiles) grid = ntiles;
   lhn_gradview g = *gy;
