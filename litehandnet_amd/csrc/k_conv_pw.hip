@@ -9,7 +9,7 @@
 #include "lhn_common.h"
 
 template <int CIN, int NT>
-__global__ void __launch_bounds__(256) k_pw_fwd(lhn_view x, const float* __restrict__ w, const float* __restrict__ bias,
+__global__ void __launch_bounds__(256, (CIN == 64 && NT == 2) || (CIN == 32 && NT == 4) ? 3 : (CIN == 64 && NT == 4) ? 2 : 1) k_pw_fwd(lhn_view x, const float* __restrict__ w, const float* __restrict__ bias,
                                                 lhn_view y, double* __restrict__ stats, int stride,
                                                 float* __restrict__ y_nchw, int cout, int M, int ntiles, lhn_bnfin fin) {
   constexpr int LDA = CIN + 4;
