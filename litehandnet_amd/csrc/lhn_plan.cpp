@@ -132,9 +132,14 @@ void lhn_plan_destroy(void* plan) {
 // finalize, second half of an attention op).  SyncBatchNorm runs [.., 2*i] / all-reduce / [2*i+1, ..]; a plain run is
 // the whole range.  count_scale = world size (statistics are over N*world samples), pgrad_scale = 1/world for the
 // d(gamma), d(beta) that come out of globally reduced sums.
-static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void* const* grads, void* const* io, int training,
+static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void* const* grads, void* const* io, int mode,
                    int nrep, int64_t rstr, void* stream, size_t sb = 0, size_t se = (size_t)-1, double cscale = 1.0,
                    float pscale = 1.f) {
+  // mode bit 0 = training (batch statistics); bit 1 (eval only, LHN_RUN_TABLES_CURRENT) = the per-buffer (scale, shift,
+  // slope) tables already hold the running-statistics BatchNorms / deployed biases of the current parameters: skip the
+  // launches that only rebuild them (52 of variant B's ~200 forward launches)
+  const int training = mode & 1;
+  const bool skip_tables = (mode & 2) != 0 && !training;
   const std::vector<lhn_op>& ops = phase == 0 ? P->fwd : P->bwd;
   hipStream_t s = static_cast<hipStream_t>(stream);
   int rc = 0;
@@ -156,6 +161,7 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
         break;
       }
       case OP_TABLE_FILL: {
+        if (skip_tables) break;
         const lhn_buf& b = P->bufs[o.out_buf];
         if (o.i[0])  // deployed conv: (1, bias, slope)
           rc = lhn_table_bias(reinterpret_cast<float*>(at(ws, b.table_off)), b.C, o.out_coff, o.out_C, prm<const float>(params, o.p[0]), o.f[2], stream);
@@ -174,7 +180,7 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
         if (h0) rc = lhn_conv_stem_fwd(static_cast<const float*>(io[0]), prm<const float>(params, o.p[0]), &y,
                                (training && o.ws[0] >= 0) ? reinterpret_cast<double*>(at(ws, o.ws[0])) : nullptr, o.i[3], o.i[4], o.i[0], o.i[1],
                                o.i[2], (bn && training && fuse_finalize() && whole) ? &fin : nullptr, stream);
-        if (!rc && bn && h1 && !(training && fuse_finalize() && whole)) rc = sep_finalize(fin, reinterpret_cast<const double*>(at(ws, o.ws[0])), training, stream);
+        if (!rc && bn && h1 && !skip_tables && !(training && fuse_finalize() && whole)) rc = sep_finalize(fin, reinterpret_cast<const double*>(at(ws, o.ws[0])), training, stream);
         break;
       }
       case OP_PW: {
@@ -198,7 +204,7 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
         if (h0) rc = lhn_conv_pw_fwd(&x, prm<const float>(params, o.p[0]), bn ? nullptr : prm<const float>(params, o.p[1]), &y,
                              (training && o.ws[0] >= 0) ? reinterpret_cast<double*>(at(ws, o.ws[0])) : nullptr, o.i[0], nchw,
                              (bn && training && fuse_finalize() && whole) ? &fin : nullptr, stream);
-        if (!rc && bn && h1 && !(training && fuse_finalize() && whole)) rc = sep_finalize(fin, reinterpret_cast<const double*>(at(ws, o.ws[0])), training, stream);
+        if (!rc && bn && h1 && !skip_tables && !(training && fuse_finalize() && whole)) rc = sep_finalize(fin, reinterpret_cast<const double*>(at(ws, o.ws[0])), training, stream);
         break;
       }
       case OP_DW: {
@@ -213,7 +219,7 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
         if (h0) rc = lhn_conv_dw_fwd(&x, prm<const float>(params, o.p[0]), &y,
                              (training && o.ws[0] >= 0) ? reinterpret_cast<double*>(at(ws, o.ws[0])) : nullptr, o.i[0], o.i[1], o.i[2], o.i[3],
                              (bn && training && fuse_finalize() && whole) ? &fin : nullptr, stream);
-        if (!rc && bn && h1 && !(training && fuse_finalize() && whole)) rc = sep_finalize(fin, reinterpret_cast<const double*>(at(ws, o.ws[0])), training, stream);
+        if (!rc && bn && h1 && !skip_tables && !(training && fuse_finalize() && whole)) rc = sep_finalize(fin, reinterpret_cast<const double*>(at(ws, o.ws[0])), training, stream);
         break;
       }
       case OP_KXK: {
@@ -229,10 +235,11 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
                               (training && o.ws[0] >= 0) ? reinterpret_cast<double*>(at(ws, o.ws[0])) : nullptr, o.i[0],
                               (bn && training && fuse_finalize() && whole) ? &fin : nullptr,
                               o.ws[3] >= 0 ? reinterpret_cast<float*>(at(ws, o.ws[3])) : nullptr, stream);
-        if (!rc && bn && h1 && !(training && fuse_finalize() && whole)) rc = sep_finalize(fin, reinterpret_cast<const double*>(at(ws, o.ws[0])), training, stream);
+        if (!rc && bn && h1 && !skip_tables && !(training && fuse_finalize() && whole)) rc = sep_finalize(fin, reinterpret_cast<const double*>(at(ws, o.ws[0])), training, stream);
         break;
       }
       case OP_FINALIZE: {
+        if (skip_tables) break;
         const lhn_buf& b = P->bufs[o.out_buf];
         const int src = o.in_buf[0] >= 0 ? o.in_buf[0] : o.out_buf;   // geometry the statistics were taken over
         const lhn_buf& sb = P->bufs[src];

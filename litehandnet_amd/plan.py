@@ -572,6 +572,9 @@ class PlanBuilder:
     _no_grad_buf = -1   # the image never needs a gradient
 
 
+_TRAIN_RUNS = 0      # bumped by every train-mode forward of any plan in this process (see CompiledPlan.run)
+
+
 class CompiledPlan:
     """Owns the C plan + the workspace arena (a torch uint8 tensor) for one (module, input shape)."""
 
@@ -595,6 +598,7 @@ class CompiledPlan:
         self._params = (C.c_void_p * len(state_tensors))()
         self._grads = (C.c_void_p * len(state_tensors))()
         self._io = (C.c_void_p * 2)()
+        self._table_sig = None
         self.mask_view = None
         if pb.ar["mask"].size:
             self.mask_view = self.view_f32(pb.arena_base["mask"], pb.ar["mask"].size // 4)
@@ -620,6 +624,10 @@ class CompiledPlan:
         statistics buffer, `all_reduce_fn(float64 view)` sums it over the ranks, statistics count N*world samples."""
         self._io[0] = 0 if io0 is None else io0.data_ptr()
         self._io[1] = 0 if io1 is None else io1.data_ptr()
+        global _TRAIN_RUNS
+        if phase == 0 and training:
+            _TRAIN_RUNS += 1           # running statistics are about to move: every plan's eval tables become stale
+            self._table_sig = None
         if phase == 0 and training and self.mask_view is not None:
             keep = 1.0 - self.pb.p_drop
             self.mask_view.bernoulli_(keep).mul_(1.0 / keep)
@@ -641,8 +649,18 @@ class CompiledPlan:
                 begin = 2 * oi + 1
             run_range(begin, nsteps)
             return
+        mode = 1 if training else 0
+        if phase == 0:
+            # eval-mode BatchNorm tables / deployed biases only depend on the parameters: rebuild them when something changed
+            # (torch's per-tensor version counters catch load_state_dict / optimizer steps; our own train-mode kernels update
+            # running statistics behind torch's back, so any training run anywhere invalidates every plan's tables)
+            if not training:
+                sig = (_TRAIN_RUNS, tuple(t._version for t in self.state_tensors), tuple(t.data_ptr() for t in self.state_tensors[:4]))
+                if sig == self._table_sig:
+                    mode |= 2          # LHN_RUN_TABLES_CURRENT
+                self._table_sig = sig
         rc = L.lhn_plan_run(C.c_void_p(self.handle), phase, _lib.ptr(self.ws), self._params, self._grads, self._io,
-                            1 if training else 0, int(grad_replicas), C.c_int64(int(grad_rep_stride)), _lib.stream())
+                            mode, int(grad_replicas), C.c_int64(int(grad_rep_stride)), _lib.stream())
         _lib.check(rc, "lhn_plan_run")
 
     def __del__(self):

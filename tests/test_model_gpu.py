@@ -599,3 +599,52 @@ def test_unsupported_inputs_fail_loudly(dev):
     h = get_model(cfg).to(dev).half()
     with pytest.raises(_lib.LhnError, match="float32"):
         h(torch.zeros(2, 3, 64, 64, device=dev))
+
+
+def test_eval_tables_are_cached_and_invalidated(dev):
+    """Eval / deployed forwards skip the BatchNorm-table launches when nothing changed (LHN_RUN_TABLES_CURRENT); any change of
+    a parameter or running statistic -- through torch or through our own train-mode kernels -- must rebuild them."""
+    from litehandnet_amd import get_model
+    cfg = litehandnet_cfg("B")
+    cfg.MODEL["ca_dropout"] = 0.0
+    m = get_model(cfg)
+    m.load_state_dict(synth.synth_state_dict(torch_ref.get_model(cfg, p_drop=0.0), 5))
+    m.to(dev).eval()
+    x = synth.synth_images(2, 64, 11).to(dev)
+
+    def fresh():
+        m.__dict__.pop("_engine", None)            # new engine = new plan = tables rebuilt from scratch
+        with torch.no_grad():
+            return m(x).clone()
+    with torch.no_grad():
+        y1 = m(x).clone()
+        y2 = m(x).clone()                          # second run: tables reused
+    assert torch.equal(y1, y2)
+    plan = next(iter(m.__dict__["_engine"].plans.values()))
+    assert plan._table_sig is not None
+    # 1. torch-side change of a running statistic
+    with torch.no_grad():
+        next(b for k, b in m.named_buffers() if k.endswith("running_mean")).add_(0.25)
+        y3 = m(x).clone()
+    assert not torch.equal(y3, y1)
+    assert torch.equal(y3, fresh())
+    # 2. our own train-mode kernels move the running statistics behind torch's back
+    with torch.no_grad():
+        y4 = m(x).clone()
+        y4b = m(x).clone()
+    assert torch.equal(y4, y4b)
+    m.train()
+    with torch.no_grad():
+        m(synth.synth_images(4, 64, 12).to(dev))
+    m.eval()
+    with torch.no_grad():
+        y5 = m(x).clone()
+    assert not torch.equal(y5, y4)
+    assert torch.equal(y5, fresh())
+    # 3. deployed form: biases live in the same tables
+    m.deploy_model()
+    with torch.no_grad():
+        y6 = m(x).clone()
+        y7 = m(x).clone()
+    assert torch.equal(y6, y7)
+    assert float((y6 - y5).abs().max()) <= 1e-3 * float(y5.abs().max())
