@@ -1,0 +1,85 @@
+"""CPU: host logic of the plan compiler (litehandnet_amd/plan.py) -- no GPU, no kernel launch.  The module mirrors emit
+their launch records into a PlanBuilder; these tests check the structure the C executor relies on and tie bench.py's
+algorithmic-byte constants to the plan that is actually run."""
+import importlib.util
+import os
+
+import pytest
+
+from litehandnet_amd import get_model
+from litehandnet_amd.config import litehandnet_cfg
+from litehandnet_amd.plan import AVGPOOL, DW, EW, KXK, MAXPOOL, PW, STEM, PlanBuilder
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _build(variant, n=2, size=256, backward=True, **kw):
+    cfg = litehandnet_cfg(variant, image_size=size, **kw)
+    cfg.MODEL["ca_dropout"] = 0.0
+    m = get_model(cfg)
+    tensors = list(m.state_dict(keep_vars=True).values())
+    pb = PlanBuilder(n, {id(t): j for j, t in enumerate(tensors)}, image_hw=(size, size), with_backward=backward, p_drop=0.0)
+    y = m.emit(pb, pb.image())
+    if y.buf != -2:
+        pb.set_output(y)
+    return m, pb, y
+
+
+def _conv_bytes(pb):
+    return sum(4 * (r["x"].H * r["x"].W * r["x"].C + r["out"].H * r["out"].W * r["out"].C)
+               for r in pb.recs if r["op"] in (STEM, PW, DW, KXK))
+
+
+@pytest.mark.parametrize("variant", ["A", "B", "M"])
+def test_plan_structure(variant):
+    m, pb, y = _build(variant)
+    assert y.buf == -2 and (y.C, y.H, y.W) == (21, 64, 64)            # NCHW head: [N,21,64,64] written straight to the caller
+    # every launch reads buffers that an earlier launch (or the image) wrote
+    written = {-1}
+    for r in pb.recs:
+        ins = [r["x"]] if r["op"] in (STEM, PW, DW, KXK, MAXPOOL, AVGPOOL) else (r["srcs"] if r["op"] == EW else [])
+        for t in ins:
+            assert t.buf in written, (r["op"], t.buf)
+        if "out" in r and r["out"] is not None:
+            written.add(r["out"].buf)
+    cb, cf, cbw, nf, nb = pb.finalize()
+    assert nf >= len(pb.recs) and nb > nf                               # backward has at least one launch per forward record
+    assert pb.grad_aliases >= 4                                         # residual-add sources share their consumer's gradient
+    # SyncBatchNorm cut points: one per statistics buffer and direction, in launch order
+    for phase in (0, 1):
+        ois = [oi for oi, _, _ in pb.sync_points[phase]]
+        assert ois == sorted(ois) and len(ois) >= 60
+    # channel slices stay inside their buffers and 16-byte aligned
+    for b in pb.bufs:
+        assert b.C % 4 == 0 and b.off["data"] % 16 == 0 and b.off["table"] % 16 == 0
+    assert pb.total_bytes < 2 * 1024 ** 3                                # N=2 workspace; scales linearly with N
+
+
+def test_algorithmic_bytes_match_bench_constants():
+    """bench.py prices the roofline with SURVEY section 8d's algorithmic bytes per image (4 B x conv in+out elements).  The
+    plan of variant B moves exactly those convolutions; A and M add BatchNorm-only statistics passes on top."""
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    n = 2
+    for variant, lo, hi in (("B", 0.995, 1.005), ("A", 1.0, 1.25), ("M", 1.0, 1.25)):
+        _, pb, _ = _build(variant, n=n, backward=False)
+        per_img = _conv_bytes(pb)                 # record geometry is per image
+        ratio = per_img / bench.ALG_FWD_BYTES[variant]
+        assert lo <= ratio <= hi, (variant, per_img, bench.ALG_FWD_BYTES[variant])
+    assert bench.LOSS_BYTES == 12 * 21 * 64 * 64 and bench.HBM_PEAK_GBS == 8000.0
+
+
+def test_plan_shapes_and_options():
+    # 224x224 (freihand configs): odd 7x7 lowest level, ceil-mode pooling
+    _, pb, y = _build("B", size=224)
+    assert (y.H, y.W) == (56, 56)
+    assert min(r["out"].H for r in pb.recs if r["op"] in (PW, DW)) == 7
+    # inference plan: no backward launches, smaller arena
+    _, pf, _ = _build("B", backward=False)
+    _, pt, _ = _build("B", backward=True)
+    assert pf.finalize()[4] == 0 and pf.total_bytes < pt.total_bytes
+    # squeeze-and-excitation and SiLU variants compile too
+    _build("B", msrb_ca="se", rbu_ca="se")
+    _, ps, _ = _build("A", activation="silu")
+    assert sum(1 for r in ps.recs if r["op"] == EW and r["slope"] == 2.0) > 20      # SiLU lives in elementwise combines
