@@ -414,6 +414,13 @@ def test_model_M_128_golden(dev, golden_dir):
     _model_case(dev, golden_dir, "M_128", variant="M")
 
 
+def test_model_options_golden(dev, golden_dir):
+    """activation='silu' in variant A and mynet's output_acitivation head against the REAL reference's vectors
+    (tests/golden/make_golden_extra.py)."""
+    _model_case(dev, golden_dir, "Asilu_64", variant="A", activation="silu")
+    _model_case(dev, golden_dir, "Mact_128", variant="M", output_acitivation=True)
+
+
 def test_model_M_256_golden(dev, golden_dir):
     _model_case(dev, golden_dir, "M_256", variant="M")
 

@@ -212,3 +212,13 @@ def test_training_trajectory(golden_dir):
     assert abs(losses[0] - ref[0]) <= 1e-6 * abs(ref[0])
     for s in range(1, len(ref)):
         assert abs(losses[s] - ref[s]) <= max(5 * abs(ref[s] - f64[s]), 2e-2 * abs(ref[s])), (s, losses, ref.tolist())
+
+
+def test_model_A_silu_64(golden_dir):
+    """cfg.MODEL.activation='silu' (row a1): fixture from the real reference (tests/golden/make_golden_extra.py)."""
+    _run_case(golden_dir, "Asilu_64", "A", activation="silu")
+
+
+def test_model_M_output_activation_128(golden_dir):
+    """mynet with output_acitivation=True: leaky_relu(preds, 0.5) on the head (pose_hg_ms_att.py:251-252)."""
+    _run_case(golden_dir, "Mact_128", "M", output_acitivation=True)
