@@ -253,3 +253,12 @@ def test_udp_encode_and_decode(dev, golden_dir):
     ok = np.isfinite(ohp).all(-1)
     assert np.abs(hp.cpu().numpy() - ohp)[ok].max() < 2e-3, np.abs(hp.cpu().numpy() - ohp)[ok].max()
     assert np.abs(pr.cpu().numpy() - opr)[ok].max() < 2e-2
+
+
+def test_transform_preds_udp_golden(dev, golden_dir):
+    """lhn_transform_preds, plain and UDP scaling, non-square map: bit-exact against the reference's vectors."""
+    from litehandnet_amd import heatmap
+    g = np.load(os.path.join(golden_dir, "decode_udp.npz"))
+    for key, udp in (("plain", False), ("udp", True)):
+        out = heatmap.transform_preds(g["coords"], g["center"], g["scale"], g["output_size"].tolist(), use_udp=udp)
+        assert np.array_equal(out.cpu().numpy(), g[key]), key

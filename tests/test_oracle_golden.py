@@ -222,3 +222,12 @@ def test_model_A_silu_64(golden_dir):
 def test_model_M_output_activation_128(golden_dir):
     """mynet with output_acitivation=True: leaky_relu(preds, 0.5) on the head (pose_hg_ms_att.py:251-252)."""
     _run_case(golden_dir, "Mact_128", "M", output_acitivation=True)
+
+
+def test_transform_preds_udp(golden_dir):
+    """post_transforms.py:6-48 with and without use_udp, non-square heatmap: oracle vs the reference's vectors."""
+    g = np.load(os.path.join(golden_dir, "decode_udp.npz"))
+    for key, udp in (("plain", False), ("udp", True)):
+        out = np.stack([onp.transform_preds(g["coords"][i].copy(), g["center"][i], g["scale"][i], g["output_size"].tolist(), use_udp=udp)
+                        for i in range(len(g["coords"]))])
+        assert np.array_equal(out, g[key]), key
