@@ -3,6 +3,8 @@
   model_Asilu_64.npz  variant A with cfg.MODEL.activation = 'silu' (liteHandNet.py:203-205 -> nn.SiLU everywhere)
   model_Mact_128.npz  mynet with cfg.MODEL.output_acitivation = True (pose_hg_ms_att.py:232,251-252, the reference's spelling)
   decode_udp.npz      transform_preds(..., use_udp=True) (post_transforms.py:6-48, the (W-1) scaling of the UDP configs)
+  decode_legacy.npz   adjust_keypoints_by_offset (utils/heatmap_post_processing.py:6-33) and the 11x11 peak NMS
+                      (utils/result_parser.py:50-59 = torch max_pool2d + eq + mul)
 
 Same recipe as make_golden.py::_model_case: the REAL reference and the oracle run forward + TopdownHeatmapLoss + backward on
 seeded inputs with synthesised weights, must agree, and the reference's outputs are stored.
@@ -53,7 +55,30 @@ def main():
         assert np.array_equal(a, b), udp
         res["udp" if udp else "plain"] = a
     np.savez_compressed(os.path.join(HERE, "decode_udp.npz"), coords=coords, center=center, scale=scale, output_size=np.array([64, 48]), **res)
-    print("written model_Asilu_64.npz, model_Mact_128.npz, decode_udp.npz")
+    # legacy +-0.25 offset refinement (clamped neighbours, then +0.5) and the heat-map peak NMS, straight from the
+    # reference's files (heatmap_post_processing.py imports cv2 and config.pcfg at module level; neither is used here)
+    import types
+    from make_golden import by_path_ref
+    if "config" not in sys.modules:                      # config/__init__.py needs `addict` (absent); only the unused `pcfg` name is imported
+        stub = types.ModuleType("config")
+        stub.pcfg = {}
+        sys.modules["config"] = stub
+    hp = by_path_ref("ref_heatmap_post_processing", "utils/heatmap_post_processing.py")
+    hm = r.random((3, 21, 24, 20)).astype(np.float32)
+    hm[0, 0, 0, 0] = 2.0          # peaks on the border: the clamped-neighbour branches
+    hm[0, 1, 23, 19] = 2.0
+    hm[0, 2, 0, 19] = 2.0
+    p0, mv = onp.get_max_preds(hm)
+    kp = torch.from_numpy(np.concatenate([p0, mv], 2).copy())
+    ref_adj = hp.adjust_keypoints_by_offset(kp.clone(), torch.from_numpy(hm)).numpy()[..., :2]
+    assert np.array_equal(ref_adj, onp.refine_offset_legacy(hm, p0))
+    t = torch.from_numpy(hm.copy())
+    mx = torch.nn.functional.max_pool2d(t, 11, 1, 5)                 # result_parser.py:25-27,50-59 with nms_kernel 11
+    ref_nms = (t * torch.eq(mx, t).float()).numpy()
+    assert np.array_equal(ref_nms, onp.heatmap_nms(hm, 11))
+    np.savez_compressed(os.path.join(HERE, "decode_legacy.npz"), heatmaps=hm, argmax_xy=p0, adjusted=ref_adj,
+                        nms_nonzero=np.argwhere(ref_nms != 0).astype(np.int32), nms_sum=np.float64(ref_nms.astype(np.float64).sum()))
+    print("written model_Asilu_64.npz, model_Mact_128.npz, decode_udp.npz, decode_legacy.npz")
 
 
 if __name__ == "__main__":

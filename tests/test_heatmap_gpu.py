@@ -88,6 +88,12 @@ def test_decode_legacy_offset_and_nms(dev):
     got = heatmap.refine_preds(hm, p, "offset").cpu().numpy()
     assert np.array_equal(got, onp.refine_offset_legacy(hm, p))
     assert np.array_equal(heatmap.heatmap_nms(hm, 11).cpu().numpy(), onp.heatmap_nms(hm, 11))
+    # the reference's own vectors (non-square map, peaks on the border; tests/golden/make_golden_extra.py)
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "decode_legacy.npz"))
+    got = heatmap.refine_preds(g["heatmaps"], g["argmax_xy"], "offset").cpu().numpy()
+    assert np.array_equal(got, g["adjusted"])
+    nms = heatmap.heatmap_nms(g["heatmaps"], 11).cpu().numpy()
+    assert np.array_equal(np.argwhere(nms != 0).astype(np.int32), g["nms_nonzero"])
 
 
 def test_argmax_full_size_properties(dev):

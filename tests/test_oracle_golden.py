@@ -231,3 +231,16 @@ def test_transform_preds_udp(golden_dir):
         out = np.stack([onp.transform_preds(g["coords"][i].copy(), g["center"][i], g["scale"][i], g["output_size"].tolist(), use_udp=udp)
                         for i in range(len(g["coords"]))])
         assert np.array_equal(out, g[key]), key
+
+
+def test_legacy_offset_and_nms(golden_dir):
+    """utils/heatmap_post_processing.py:6-33 (clamped +-0.25 offset, then +0.5) and the 11x11 peak NMS
+    (utils/result_parser.py:50-59) on a non-square map with border peaks: oracle vs the reference's vectors."""
+    g = np.load(os.path.join(golden_dir, "decode_legacy.npz"))
+    hm = g["heatmaps"]
+    p0, _ = onp.get_max_preds(hm)
+    assert np.array_equal(p0, g["argmax_xy"])
+    assert np.array_equal(onp.refine_offset_legacy(hm, p0), g["adjusted"])
+    nms = onp.heatmap_nms(hm, 11)
+    assert np.array_equal(np.argwhere(nms != 0).astype(np.int32), g["nms_nonzero"])
+    assert nms.astype(np.float64).sum() == float(g["nms_sum"])
