@@ -3,6 +3,8 @@
   model_Asilu_64.npz  variant A with cfg.MODEL.activation = 'silu' (liteHandNet.py:203-205 -> nn.SiLU everywhere)
   model_Mact_128.npz  mynet with cfg.MODEL.output_acitivation = True (pose_hg_ms_att.py:232,251-252, the reference's spelling)
   decode_udp.npz      transform_preds(..., use_udp=True) (post_transforms.py:6-48, the (W-1) scaling of the UDP configs)
+  affine.npz          the geometry of TopDownAffine (post_transforms.py:52-156): get_warp_matrix / warp_affine_joints outputs,
+                      and the three source / destination points get_affine_transform hands to cv2.getAffineTransform
   decode_legacy.npz   adjust_keypoints_by_offset (utils/heatmap_post_processing.py:6-33) and the 11x11 peak NMS
                       (utils/result_parser.py:50-59 = torch max_pool2d + eq + mul)
 
@@ -55,6 +57,41 @@ def main():
         assert np.array_equal(a, b), udp
         res["udp" if udp else "plain"] = a
     np.savez_compressed(os.path.join(HERE, "decode_udp.npz"), coords=coords, center=center, scale=scale, output_size=np.array([64, 48]), **res)
+    # TopDownAffine geometry.  get_affine_transform ends in cv2.getAffineTransform (absent), so its three point pairs are
+    # rebuilt here with the reference's own helpers (post_transforms.py:129-147) and the oracle's closed form has to map
+    # one triplet onto the other; get_warp_matrix / warp_affine_joints are pure numpy and are compared directly.
+    ra = np.random.Generator(np.random.PCG64(43))     # own stream: the sections below keep theirs
+    cs = ra.uniform(40, 220, (12, 2)).astype(np.float32)
+    ss = ra.uniform(0.4, 1.6, (12, 1)).astype(np.float32).repeat(2, 1)
+    rots = ra.uniform(-60, 60, 12).astype(np.float32)
+    rots[0] = 0.0
+    osz = np.array([256, 192], np.float32)
+    src_pts, dst_pts, udp_m, udp_j = [], [], [], []
+    jj = ra.uniform(0, 255, (12, 21, 2)).astype(np.float32)
+    for c, sc, ro, jn in zip(cs, ss, rots, jj):
+        scale_tmp = sc * 200.0
+        src_dir = pt.rotate_point([0., scale_tmp[0] * -0.5], np.pi * ro / 180)
+        dst_dir = np.array([0., osz[0] * -0.5])
+        src = np.zeros((3, 2), np.float32)
+        src[0, :] = c
+        src[1, :] = c + src_dir
+        src[2, :] = pt._get_3rd_point(src[0, :], src[1, :])
+        dst = np.zeros((3, 2), np.float32)
+        dst[0, :] = [osz[0] * 0.5, osz[1] * 0.5]
+        dst[1, :] = np.array([osz[0] * 0.5, osz[1] * 0.5]) + dst_dir
+        dst[2, :] = pt._get_3rd_point(dst[0, :], dst[1, :])
+        M = onp.affine_matrix(c, sc, ro, osz)
+        got = src.astype(np.float64) @ M[:, :2].T + M[:, 2]
+        assert np.abs(got - dst).max() < 2e-4, np.abs(got - dst).max()
+        src_pts.append(src)
+        dst_pts.append(dst)
+        mu = pt.get_warp_matrix(ro, c * 2.0, osz - 1.0, sc * 200.0)          # topdown_affine.py:76-93
+        assert np.allclose(mu, onp.warp_matrix_udp(ro, c * 2.0, osz - 1.0, sc * 200.0), rtol=1e-5, atol=1e-4)
+        udp_m.append(mu)
+        udp_j.append(pt.warp_affine_joints(jn, mu))
+    np.savez_compressed(os.path.join(HERE, "affine.npz"), center=cs, scale=ss, rot=rots, output_size=osz, src=np.stack(src_pts),
+                        dst=np.stack(dst_pts), joints=jj, udp_matrix=np.stack(udp_m), udp_joints=np.stack(udp_j))
+
     # legacy +-0.25 offset refinement (clamped neighbours, then +0.5) and the heat-map peak NMS, straight from the
     # reference's files (heatmap_post_processing.py imports cv2 and config.pcfg at module level; neither is used here)
     import types
@@ -78,7 +115,7 @@ def main():
     assert np.array_equal(ref_nms, onp.heatmap_nms(hm, 11))
     np.savez_compressed(os.path.join(HERE, "decode_legacy.npz"), heatmaps=hm, argmax_xy=p0, adjusted=ref_adj,
                         nms_nonzero=np.argwhere(ref_nms != 0).astype(np.int32), nms_sum=np.float64(ref_nms.astype(np.float64).sum()))
-    print("written model_Asilu_64.npz, model_Mact_128.npz, decode_udp.npz, decode_legacy.npz")
+    print("written model_Asilu_64.npz, model_Mact_128.npz, decode_udp.npz, affine.npz, decode_legacy.npz")
 
 
 if __name__ == "__main__":

@@ -244,3 +244,20 @@ def test_legacy_offset_and_nms(golden_dir):
     nms = onp.heatmap_nms(hm, 11)
     assert np.array_equal(np.argwhere(nms != 0).astype(np.int32), g["nms_nonzero"])
     assert nms.astype(np.float64).sum() == float(g["nms_sum"])
+
+
+def test_affine_geometry(golden_dir):
+    """TopDownAffine geometry (post_transforms.py:52-156).  The closed-form matrix of the oracle maps the three source points
+    the reference builds for cv2.getAffineTransform onto its three destination points; the UDP matrix and the joint mapping
+    (pure numpy in the reference) are compared directly.  Only cv2.warpAffine's interpolation stays unpinned."""
+    g = np.load(os.path.join(golden_dir, "affine.npz"))
+    osz = g["output_size"]
+    for i in range(len(g["center"])):
+        M = onp.affine_matrix(g["center"][i], g["scale"][i], g["rot"][i], osz)
+        got = g["src"][i].astype(np.float64) @ M[:, :2].T + M[:, 2]
+        assert np.abs(got - g["dst"][i]).max() < 2e-4
+        Mu = onp.warp_matrix_udp(g["rot"][i], g["center"][i] * 2.0, osz - 1.0, g["scale"][i] * 200.0)
+        assert np.allclose(Mu, g["udp_matrix"][i], rtol=1e-5, atol=1e-4)
+        j = g["joints"][i].astype(np.float64)
+        mapped = np.concatenate([j, np.ones((len(j), 1))], 1) @ Mu.T
+        assert np.abs(mapped - g["udp_joints"][i]).max() < 1e-3
