@@ -3,7 +3,6 @@
 attribute names and state_dict keys as the reference."""
 from torch import nn
 
-from . import _lib
 from .common import ChannelAttension, SEBlock
 from .engine import PlanModule
 from .repblocks import RepBlock, RepConv, act_slope

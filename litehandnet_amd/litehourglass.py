@@ -1,11 +1,10 @@
 """HIP-backed mirror of models/pose_estimation/liteHandNet/litehourglass.py -- the MSRB hourglass
 ("variant B").  Same attribute names / state_dict keys as the reference."""
-import torch
 from torch import nn
 
 from . import _lib
 from .common import ChannelAttension, SEBlock
-from .engine import Engine, PlanModule
+from .engine import PlanModule
 from .repblocks import RepConv
 
 

@@ -1,5 +1,4 @@
 """Model registry -- models/__init__.py:11-26 restricted to the hot path."""
-from . import _lib
 
 __all__ = ["litehandnet", "litehourglass", "mynet"]
 
