@@ -654,14 +654,24 @@ class CompiledPlan:
             # eval-mode BatchNorm tables / deployed biases only depend on the parameters: rebuild them when something changed
             # (torch's per-tensor version counters catch load_state_dict / optimizer steps; our own train-mode kernels update
             # running statistics behind torch's back, so any training run anywhere invalidates every plan's tables)
-            if not training:
-                sig = (_TRAIN_RUNS, tuple(t._version for t in self.state_tensors), tuple(t.data_ptr() for t in self.state_tensors[:4]))
-                if sig == self._table_sig:
-                    mode |= 2          # LHN_RUN_TABLES_CURRENT
-                self._table_sig = sig
+            if not training and self._tables_current():
+                mode |= 2              # LHN_RUN_TABLES_CURRENT
         rc = L.lhn_plan_run(C.c_void_p(self.handle), phase, _lib.ptr(self.ws), self._params, self._grads, self._io,
                             mode, int(grad_replicas), C.c_int64(int(grad_rep_stride)), _lib.stream())
         _lib.check(rc, "lhn_plan_run")
+
+    def _tables_current(self):
+        """True when this eval run may reuse the tables the previous eval run of this plan built.  Remembers the state it
+        saw: (process-wide count of train-mode runs, torch's version counter of every parameter / buffer, a few data
+        pointers).  Tensors without a version counter (created under torch.inference_mode) disable the reuse."""
+        try:
+            sig = (_TRAIN_RUNS, tuple(t._version for t in self.state_tensors), tuple(t.data_ptr() for t in self.state_tensors[:4]))
+        except RuntimeError:
+            self._table_sig = None
+            return False
+        same = sig == self._table_sig
+        self._table_sig = sig
+        return same
 
     def __del__(self):
         try:

@@ -84,3 +84,25 @@ def test_plan_shapes_and_options():
     _build("B", msrb_ca="se", rbu_ca="se")
     _, ps, _ = _build("A", activation="silu")
     assert sum(1 for r in ps.recs if r["op"] == EW and r["slope"] == 2.0) > 20      # SiLU lives in elementwise combines
+
+
+def test_eval_table_reuse_signature():
+    """CompiledPlan._tables_current: reuse only while neither torch nor our train-mode kernels touched a parameter."""
+    import torch
+
+    from litehandnet_amd import plan as planmod
+    p = object.__new__(planmod.CompiledPlan)            # no GPU: exercise the bookkeeping only
+    w, rm = torch.nn.Parameter(torch.zeros(4)), torch.zeros(4)
+    p.state_tensors, p._table_sig, p.handle = [w, rm], None, None
+    assert not p._tables_current()                       # first eval run builds the tables
+    assert p._tables_current()                           # nothing changed
+    rm.add_(1.0)                                         # load_state_dict / in-place edit: version counter moves
+    assert not p._tables_current() and p._tables_current()
+    with torch.no_grad():
+        w.mul_(2.0)                                      # optimizer step
+    assert not p._tables_current() and p._tables_current()
+    planmod._TRAIN_RUNS += 1                             # any train-mode forward in the process (raw-pointer updates)
+    assert not p._tables_current() and p._tables_current()
+    with torch.inference_mode():
+        p.state_tensors = [torch.zeros(4)]               # no version counter: never reuse
+    assert not p._tables_current() and not p._tables_current()
