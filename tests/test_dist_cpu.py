@@ -68,3 +68,32 @@ def test_flat_allreduce_world2():
     out = mgr.dict()
     mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
     assert out[0] and out[1]
+
+
+def test_gradient_handoff_follows_the_process_group():
+    """Engine.grads_via_autograd = None (automatic): per-parameter gradients go through autograd -- so that the hooks of a
+    DistributedDataParallel wrapper fire -- exactly while a torch.distributed process group exists; an explicit setting wins.
+    Also: SyncBatchNorm mode needs converted modules AND more than one rank."""
+    from litehandnet_amd import get_model
+    from litehandnet_amd.config import litehandnet_cfg
+    from litehandnet_amd.engine import Engine
+    from litehandnet_amd.train import all_reduce_sum_, broadcast_, prepare_model
+    cfg = litehandnet_cfg("B")
+    m = get_model(cfg)
+    eng = Engine(m)
+    assert eng._via_autograd() is False
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        assert eng._via_autograd() is True
+        eng.grads_via_autograd = False                   # what Trainer does
+        assert eng._via_autograd() is False
+        eng.grads_via_autograd = None
+        cfg.TRAIN["syncBN"] = True
+        assert prepare_model(m, cfg) is m                # one rank: nothing to synchronise, modules untouched
+        assert eng.sync_config() is None
+        t = torch.arange(4.0)
+        assert torch.equal(all_reduce_sum_(t.clone()), t) and torch.equal(broadcast_(t.clone(), 0), t)
+    finally:
+        dist.destroy_process_group()
+    assert eng._via_autograd() is False
