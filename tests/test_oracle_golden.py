@@ -261,3 +261,21 @@ def test_affine_geometry(golden_dir):
         j = g["joints"][i].astype(np.float64)
         mapped = np.concatenate([j, np.ones((len(j), 1))], 1) @ Mu.T
         assert np.abs(mapped - g["udp_joints"][i]).max() < 1e-3
+
+
+def test_dark_round_trip_property():
+    """Size-independent property of the unpinned part (DARK needs cv2.GaussianBlur, absent): encoding a sub-pixel joint with the
+    unbiased Gaussian and decoding it with blur + log + Taylor step recovers the joint to a few hundredths of a heat-map
+    pixel, for both blur kernels the configs use (11 and 19); the plain argmax alone is off by up to half a pixel."""
+    r = np.random.Generator(np.random.PCG64(77))
+    j = np.zeros((4, 21, 3), np.float32)
+    j[..., :2] = r.uniform(24, 232, (4, 21, 2))                     # image pixels, well inside a 256x256 crop
+    hm = np.stack([onp.msra_generate_target(a, np.ones_like(a), [256, 256], [64, 64], 2, True)[0] for a in j])
+    center = np.full((4, 2), 128.0, np.float32)
+    scale = np.full((4, 2), 256.0 / 200.0, np.float32)             # identity back-transform: heat-map px * 4
+    plain, _, _ = onp.keypoints_from_heatmaps(hm, center, scale, None)
+    assert np.abs(plain - j[..., :2] / 4).max() <= 0.5 + 1e-6
+    for k in (11, 19):
+        hp, pr, _ = onp.keypoints_from_heatmaps(hm, center, scale, "unbiased", k)
+        assert np.abs(hp - j[..., :2] / 4).max() < 0.05, k
+        assert np.abs(pr - j[..., :2]).max() < 0.2, k
