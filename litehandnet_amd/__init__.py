@@ -13,3 +13,9 @@ def get_model(cfg):
 def get_loss(cfg):
     from .loss import get_loss as _g
     return _g(cfg)
+
+
+def invalidate_tables():
+    """See litehandnet_amd.plan.invalidate_tables: call after writing parameters / running statistics through `.data`."""
+    from .plan import invalidate_tables as _i
+    _i()

@@ -14,8 +14,7 @@ class SEBlock(PlanModule):
         self.input_channels = input_channels
 
     def emit(self, pb, x, out=None):
-        b = pb.bufs[x.buf]
-        if x.coff != 0 or x.C != b.C or b.gate or (pb.in_ref is not None and x.buf == pb.in_ref.buf):
+        if not pb.owns_buffer(x):
             x = pb.ew([x])          # a gate needs a buffer of its own whose producer turns (gate, dz, dpool) into d(raw)
         return pb.se_attention(x, self)
 
@@ -47,7 +46,6 @@ class ChannelAttension(PlanModule):
 
     def emit(self, pb, x, out=None):
         # the gate attaches to the buffer behind x; a view that does not own its buffer is materialised first
-        b = pb.bufs[x.buf]
-        if x.coff != 0 or x.C != b.C or b.gate or (pb.in_ref is not None and x.buf == pb.in_ref.buf):
+        if not pb.owns_buffer(x):
             x = pb.ew([x])
         return pb.channel_attention(x, self)

@@ -825,11 +825,8 @@ static void launch_dwk_fwd(const lhn_view* x, const float* w, const lhn_view* y,
   const int th = (sh + TH - 1) / TH, tw = (sw + TW - 1) / TW, ntile = y->N * ps * ps * th * tw * cg;
   const size_t lds = (size_t)((TH + 2 * P) * (TW + 2 * P) * 8 + 512 + K * K * 8) * 16;
   const int per_cu = lds > 80 * 1024 ? 1 : (lds > 52 * 1024 ? 2 : 3);
-  static bool done = false;
-  if (!done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwk_fwd_lds<K, DIL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    done = true;
-  }
+  static LhnKernelCfg cfg;
+  (void)lhn_kernel_cfg(cfg, &k_dwk_fwd_lds<K, DIL>, lds, 4, nullptr);
   hipLaunchKernelGGL((k_dwk_fwd_lds<K, DIL>), dim3(dw3_grid(ntile, cg, per_cu * 2)), dim3(256), lds, s, *x, w, *y, stats, th, tw, cg, fin, ps);
 }
 template <int K, int DIL>
@@ -840,11 +837,8 @@ static void launch_dwk_bwd(const lhn_view* x, const float* w, const lhn_view* y,
   const int sh = (x->H + ps - 1) / ps, sw = (x->W + ps - 1) / ps;
   const int th = (sh + TH - 1) / TH, tw = (sw + TW - 1) / TW, ntile = x->N * ps * ps * th * tw * cg;
   const size_t lds = (size_t)((TH + 2 * P) * (TW + 2 * P) * 16 + 256 + 2 * K * K * 8) * 16;
-  static bool done = false;
-  if (!done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwk_bwd_lds<K, DIL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    done = true;
-  }
+  static LhnKernelCfg cfg;
+  (void)lhn_kernel_cfg(cfg, &k_dwk_bwd_lds<K, DIL>, lds, 4, nullptr);
   hipLaunchKernelGGL((k_dwk_bwd_lds<K, DIL>), dim3(dw3_grid(ntile, cg, 4)), dim3(256), lds, s, *x, w, *y, *gy, dx, dx_acc, dw, th, tw,
                      cg, nrep, rep_stride, ps);
 }

@@ -468,17 +468,12 @@ static int launch_kxk(const lhn_view* x, const float* w, const lhn_view* y, cons
   const lhn_view* ov = MODE == 0 ? y : x;
   const int M = parity ? ov->N * ((ov->H + 1) / 2) * ((ov->W + 1) / 2) : ov->N * ov->H * ov->W, ntiles = (M + 127) / 128;
   const size_t lds = (size_t)((32 * NT + 128) * (KD + 4) + 4 * 32 * NT * 2) * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kxk<KD, NT, MODE, TAPS, PLAIN>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds) != hipSuccess) {
-      lhn_set_error("lhn_conv_kxk: cannot reserve %zu B of LDS", lds);
-      return 2;
-    }
-    attr_done = true;
+  static LhnKernelCfg cfg;
+  int per_cu = 1;
+  if (!lhn_kernel_cfg(cfg, &k_kxk<KD, NT, MODE, TAPS, PLAIN>, lds, 4, &per_cu)) {
+    lhn_set_error("lhn_conv_kxk: cannot reserve %zu B of LDS", lds);
+    return 2;
   }
-  static int per_cu = 0;
-  if (!per_cu) per_cu = lhn_resident_per_cu(&k_kxk<KD, NT, MODE, TAPS, PLAIN>, lds, 4);
   int grid = lhn_num_cus() * per_cu;
   if (grid > ntiles) grid = ntiles;
   lhn_gradview g;
@@ -493,17 +488,12 @@ static int launch_kxk_wgrad(const lhn_view* x, const lhn_view* y, const lhn_grad
   const int M = y->N * y->H * y->W, ntiles = (M + 63) / 64;
   constexpr int COP = 32 * NTO;
   const size_t lds = (size_t)(64 * (COP + 4) + 64 * (CIN + 4)) * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kxk_wgrad<CIN, NTO, TAPS, PLAIN>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds) != hipSuccess) {
-      lhn_set_error("lhn_conv_kxk_bwd: cannot reserve %zu B of LDS", lds);
-      return 2;
-    }
-    attr_done = true;
+  static LhnKernelCfg cfg;
+  int per_cu = 1;
+  if (!lhn_kernel_cfg(cfg, &k_kxk_wgrad<CIN, NTO, TAPS, PLAIN>, lds, 3, &per_cu)) {
+    lhn_set_error("lhn_conv_kxk_bwd: cannot reserve %zu B of LDS", lds);
+    return 2;
   }
-  static int per_cu = 0;
-  if (!per_cu) per_cu = lhn_resident_per_cu(&k_kxk_wgrad<CIN, NTO, TAPS, PLAIN>, lds, 3);
   int grid = TAPS == 1 ? lhn_num_cus() * per_cu : lhn_num_cus() / 4;      // x 9 taps
   if (cosplit > 1 && nrep > 1) grid = nrep;                               // exclusive replica slices: no atomics in the flush
   if (grid < 1) grid = 1;

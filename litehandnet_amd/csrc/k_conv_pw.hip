@@ -167,17 +167,12 @@ static int launch_pw_fwd(const lhn_view* x, const float* w, const float* bias, c
   const int M = y->N * y->H * y->W;
   const int ntiles = (M + 127) / 128;
   const size_t lds = (size_t)((32 * NT + 128) * (CIN + 4)) * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pw_fwd<CIN, NT>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-      lhn_set_error("lhn_conv_pw_fwd: cannot reserve %zu B of LDS", lds);
-      return 2;
-    }
-    attr_done = true;
+  static LhnKernelCfg cfg;
+  int per_cu = 1;
+  if (!lhn_kernel_cfg(cfg, &k_pw_fwd<CIN, NT>, lds, 4, &per_cu)) {
+    lhn_set_error("lhn_conv_pw_fwd: cannot reserve %zu B of LDS", lds);
+    return 2;
   }
-  static int per_cu = 0;
-  if (!per_cu) per_cu = lhn_resident_per_cu(&k_pw_fwd<CIN, NT>, lds, 4);
   int grid = lhn_num_cus() * per_cu;
   if (grid > ntiles) grid = ntiles;
   hipLaunchKernelGGL((k_pw_fwd<CIN, NT>), dim3(grid), dim3(256), lds, s, *x, w, bias, *y, stats, stride, y_nchw, cout, M,
@@ -471,17 +466,12 @@ static int launch_pw_bwd_t(const lhn_view* x, const float* w, const lhn_view* y,
   const int ntiles = (M + 63) / 64;
   constexpr int COP = 32 * NTO;
   const size_t lds = (size_t)(COP * (CIN + 4) + 64 * (COP + 4) + 64 * (CIN + 4)) * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pw_bwd<CIN, NTO, NCHW>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds) != hipSuccess) {
-      lhn_set_error("lhn_conv_pw_bwd: cannot reserve %zu B of LDS", lds);
-      return 2;
-    }
-    attr_done = true;
+  static LhnKernelCfg cfg;
+  int per_cu = 1;
+  if (!lhn_kernel_cfg(cfg, &k_pw_bwd<CIN, NTO, NCHW>, lds, 4, &per_cu)) {
+    lhn_set_error("lhn_conv_pw_bwd: cannot reserve %zu B of LDS", lds);
+    return 2;
   }
-  static int per_cu = 0;
-  if (!per_cu) per_cu = lhn_resident_per_cu(&k_pw_bwd<CIN, NTO, NCHW>, lds, 4);
   int grid = lhn_num_cus() * per_cu;
   if (grid > ntiles) grid = ntiles;
   lhn_gradview g = *gy;

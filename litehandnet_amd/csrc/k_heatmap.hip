@@ -544,11 +544,8 @@ extern "C" int lhn_heatmap_decode_dark(const float* hm, const float* center, con
   LHN_CHECK_ARG(kernel % 2 == 1 && kernel >= 3 && kernel <= 31, "lhn_heatmap_decode_dark: kernel %d (odd, 3..31)", kernel);
   LHN_CHECK_ARG((H * W) % 4 == 0 && H * W <= 16384, "lhn_heatmap_decode_dark: H*W must be a multiple of 4 and <= 16384");
   const size_t lds = (size_t)2 * H * W * sizeof(float);
-  static bool done = false;
-  if (!done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dark), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 16384 * 4);
-    done = true;
-  }
+  static LhnKernelCfg cfg;
+  (void)lhn_kernel_cfg(cfg, &k_dark, (size_t)2 * 16384 * 4, 4, nullptr);
   hipLaunchKernelGGL(k_dark, dim3(N * K), dim3(256), lds, (hipStream_t)stream, hm, center, scale, hm_preds, preds, maxvals, K, H,
                      W, kernel);
   LHN_CHECK_LAUNCH("lhn_heatmap_decode_dark");
@@ -841,11 +838,8 @@ extern "C" int lhn_heatmap_decode_dark_udp(const float* hm, const float* center,
   LHN_CHECK_ARG(kernel % 2 == 1 && kernel >= 3 && kernel <= 31, "lhn_heatmap_decode_dark_udp: kernel %d (odd, 3..31)", kernel);
   LHN_CHECK_ARG((H * W) % 4 == 0 && H * W <= 16384 && H > 1 && W > 1, "lhn_heatmap_decode_dark_udp: H*W must be a multiple of 4 and <= 16384");
   const size_t lds = (size_t)2 * H * W * sizeof(float);
-  static bool done = false;
-  if (!done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dark_udp), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 16384 * 4);
-    done = true;
-  }
+  static LhnKernelCfg cfg;
+  (void)lhn_kernel_cfg(cfg, &k_dark_udp, (size_t)2 * 16384 * 4, 4, nullptr);
   hipLaunchKernelGGL(k_dark_udp, dim3(N * K), dim3(256), lds, (hipStream_t)stream, hm, center, scale, hm_preds, preds, maxvals, K,
                      H, W, kernel);
   LHN_CHECK_LAUNCH("lhn_heatmap_decode_dark_udp");

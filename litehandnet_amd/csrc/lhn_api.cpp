@@ -11,6 +11,19 @@ void lhn_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+int lhn_num_cus() {
+  static std::once_flag once[LHN_MAX_DEVICES];
+  static int cus[LHN_MAX_DEVICES];
+  const int slot = lhn_device_slot();
+  std::call_once(once[slot], [&] {
+    hipDeviceProp_t p;
+    int d = 0, n = 0;
+    if (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess) n = p.multiProcessorCount;
+    cus[slot] = n > 0 ? n : 256;
+  });
+  return cus[slot];
+}
+
 extern "C" {
 int lhn_version(void) { return LHN_VERSION; }
 const char* lhn_last_error(void) { return g_err; }

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <mutex>
 #include "../../include/lhn.h"
 
 #define LHN_WAVE 64
@@ -32,17 +33,17 @@ static inline int lhn_view_ok(const lhn_view* v) {
          v->coff + v->C <= v->cstride && (v->cstride % 4) == 0 && (v->coff % 4) == 0 && (v->C % 4) == 0;
 }
 
-// number of CUs; grid caps for persistent grid-stride kernels
-static inline int lhn_num_cus() {
-  static int n = 0;
-  if (!n) {
-    hipDeviceProp_t p;
-    int d = 0;
-    if (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess) n = p.multiProcessorCount;
-    if (n <= 0) n = 256;
-  }
-  return n;
+// Host-side state is PER DEVICE (the library is re-entrant across devices: one process per GPU, or nn.DataParallel
+// threads each bound to their own device, test.py:81): the CU count and every kernel's one-time attributes
+// (hipFuncSetAttribute is a per-device setting) live in tables indexed by the calling thread's current device and are
+// initialised under std::call_once.
+#define LHN_MAX_DEVICES 16
+static inline int lhn_device_slot() {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0) d = 0;
+  return d % LHN_MAX_DEVICES;
 }
+int lhn_num_cus();   // lhn_api.cpp: CUs of the current device; grid caps for persistent grid-stride kernels
 
 #ifdef __HIPCC__
 // Workgroups of `kernel` (256 threads, `dyn_lds` bytes of dynamic LDS) that are resident on one CU at the same time: the
@@ -60,6 +61,25 @@ static inline int lhn_resident_per_cu(F kernel, size_t dyn_lds, int cap) {
   }
   if (n > cap) n = cap;
   return n < 1 ? 1 : n;
+}
+
+// One-time, per-device setup of a kernel: dynamic-LDS opt-in + resident workgroups per CU.  `static LhnKernelCfg cfg;`
+// at the launch site (one per template instance); returns false when the LDS reservation is refused.
+struct LhnKernelCfg {
+  std::once_flag once[LHN_MAX_DEVICES];
+  int per_cu[LHN_MAX_DEVICES];
+  bool ok[LHN_MAX_DEVICES];
+};
+template <typename F>
+static inline bool lhn_kernel_cfg(LhnKernelCfg& c, F kernel, size_t dyn_lds, int cap, int* per_cu) {
+  const int d = lhn_device_slot();
+  std::call_once(c.once[d], [&] {
+    c.ok[d] = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)dyn_lds) == hipSuccess;
+    c.per_cu[d] = lhn_resident_per_cu(kernel, dyn_lds, cap);
+  });
+  if (per_cu) *per_cu = c.per_cu[d];
+  return c.ok[d];
 }
 
 // ---------------------------------------------------------------- device side

@@ -50,6 +50,7 @@ class _PlanFn(torch.autograd.Function):
                               device=x.device)
         ctx.sync = eng.sync_config() if training else None
         plan.run(0, xc if eng.full else None, out, training, sync=ctx.sync)
+        ctx.serial = plan.fwd_serial
         if eng.full:
             ctx.save_for_backward(xc)
         if not plan.nchw_out:
@@ -63,6 +64,17 @@ class _PlanFn(torch.autograd.Function):
             raise _lib.LhnError("backward through an eval-mode (running-statistics) plan is not supported")
         if plan.n_bwd == 0:
             raise _lib.LhnError("plan was compiled without a backward pass")
+        # One workspace per (module, input shape): the activations a backward reads are those of the LAST forward of that
+        # shape, and the backward kernels overwrite gradients in place.  Anything else must fail loudly, not silently differ
+        # from torch: two forwards then two backwards, a grad-enabled forward in between, backward(retain_graph=True) twice.
+        if ctx.serial != plan.fwd_serial:
+            raise _lib.LhnError("backward of a stale forward: another forward of the same input shape ran on this module "
+                                "since (one workspace per shape; call backward before the next forward of that shape, or "
+                                "run the extra forward under torch.no_grad())")
+        if plan.bwd_serial == ctx.serial:
+            raise _lib.LhnError("second backward through the same forward: the first one consumed the saved activations "
+                                "(retain_graph is not supported; run the forward again)")
+        plan.bwd_serial = ctx.serial
         # torch semantics: a backward without a zero_grad in between ACCUMULATES.  Gradients published by the previous
         # backward are views of the flat buffer this one overwrites, so keep them aside first (rare path: one 1-9 MB copy).
         held = eng.flat_grads.clone() if (not ctx.via_autograd and eng.accumulate_published and eng._published_live()) else None
@@ -106,6 +118,7 @@ class Engine:
         self.grads_via_autograd = None
         self.p_drop = p_drop
         self.sync_override = None           # (world, all_reduce_fn): tests / custom process groups
+        self.mask_fn = None                 # callable(plan) filling plan.mask_slices: injected dropout masks (parity tests)
         # direct mode: add to gradients that are still published in `param.grad` (no zero_grad since the last backward).
         # litehandnet_amd.train.Trainer owns the flat buffer and its zeroing, and switches this off.
         self.accumulate_published = True
@@ -205,11 +218,12 @@ class Engine:
             y = self.module.emit(pb, pb.image())
         else:
             y = self.module.emit(pb, pb.input_tensor(Cc, H, W))
-        nchw_out = y.buf == -2
+        nchw_out = getattr(y, "buf", None) == -2
         if not nchw_out:
             pb.set_output(y)
         plan = CompiledPlan(pb, tensors, x.device)
         plan.out_hw, plan.nchw_out = (y.H, y.W), nchw_out
+        plan.mask_fn = self.mask_fn
         self.plans[key] = plan
         return plan
 

@@ -219,15 +219,49 @@ def keypoints_from_simdr(x_vectors, y_vectors, center, scale, k=2):
 
 
 class TopDownDecoder:
-    """utils/post_processing/decoder.py:9-71."""
+    """utils/post_processing/decoder.py:9-107.  Same attributes (`k` is read by test.py:125) and the same result dicts: host
+    numpy arrays for preds / hm_preds / boxes / output_heatmap, a python list for bbox_ids.  The decode itself runs on the
+    device; everything small comes back in ONE device-to-host copy.  `as_numpy=False` keeps the results as device tensors
+    (the heat maps then never leave HBM -- the reference's evaluate() only reads preds / boxes / image_paths / bbox_ids)."""
 
-    def __init__(self, cfg):
+    def __init__(self, cfg, as_numpy=True):
         self.image_size = np.array(cfg.DATASET.image_size)
         self.heatmap_size = np.array(cfg.DATASET.heatmap_size)
         self.num_joints = cfg.DATASET.num_joints
         self.post_process = "unbiased" if cfg.PIPELINE.unbiased_encoding else "default"
         self.kernel = cfg.PIPELINE.kernel[0]
         self.use_udp = cfg.PIPELINE.use_udp
+        self.k = cfg.PIPELINE.get("simdr_split_ratio", 0)
+        self.as_numpy = as_numpy
+
+    def _boxes(self, meta, center, scale, dev):
+        n = center.shape[0]
+        b = torch.zeros((n, 6), dtype=torch.float32, device=dev)
+        b[:, 0:2] = center[:, 0:2]
+        b[:, 2:4] = scale[:, 0:2]
+        b[:, 4] = torch.prod(scale * 200.0, dim=1)
+        b[:, 5] = _dev(meta["bbox_score"], dev).float().reshape(-1)
+        return b
+
+    @staticmethod
+    def _ids(meta):
+        ids = meta["bbox_id"]
+        return ids.tolist() if hasattr(ids, "tolist") else list(ids)
+
+    def _finish(self, res, small, out):
+        """small: list of (key, [N, ..] device tensor) packed into one host copy; out: the heat maps."""
+        if not self.as_numpy:
+            res.update(dict(small), output_heatmap=out)
+            return res
+        n = small[0][1].shape[0]
+        flat = torch.cat([t.reshape(n, -1) for _, t in small], dim=1).cpu().numpy()
+        off = 0
+        for k, t in small:
+            w = t[0].numel()
+            res[k] = np.ascontiguousarray(flat[:, off:off + w]).reshape(tuple(t.shape))
+            off += w
+        res["output_heatmap"] = out.detach().cpu().numpy()
+        return res
 
     def decode(self, meta, model_output, post_process=None):
         pp = post_process or self.post_process
@@ -235,13 +269,17 @@ class TopDownDecoder:
         center, scale = _dev(meta["center"], out.device).float(), _dev(meta["scale"], out.device).float()
         hm_preds, preds, maxvals = keypoints_from_heatmaps(out, center, scale, post_process=pp, kernel=self.kernel,
                                                            use_udp=self.use_udp)
-        n = out.shape[0]
-        all_boxes = torch.zeros((n, 6), dtype=torch.float32, device=out.device)
-        all_boxes[:, 0:2] = center[:, 0:2]
-        all_boxes[:, 2:4] = scale[:, 0:2]
-        all_boxes[:, 4] = torch.prod(scale * 200.0, dim=1)
-        all_boxes[:, 5] = _dev(meta["bbox_score"], out.device).float().reshape(-1)
-        ids = meta["bbox_id"]
-        return dict(preds=torch.cat([preds, maxvals], dim=2), hm_preds=torch.cat([hm_preds * 4, maxvals], dim=2),
-                    boxes=all_boxes, image_paths=meta.get("image_file"),
-                    bbox_ids=ids.tolist() if hasattr(ids, "tolist") else list(ids), output_heatmap=out)
+        res = dict(image_paths=meta.get("image_file"), bbox_ids=self._ids(meta))
+        small = [("preds", torch.cat([preds, maxvals], dim=2)), ("hm_preds", torch.cat([hm_preds * 4, maxvals], dim=2)),
+                 ("boxes", self._boxes(meta, center, scale, out.device))]
+        res = self._finish(res, small, out)
+        return {k: res[k] for k in ("preds", "hm_preds", "boxes", "image_paths", "bbox_ids", "output_heatmap")}
+
+    def decode_simdr(self, meta, model_output):
+        """decoder.py:73-107: keypoints from the SimDR vectors in `meta`, boxes as in decode()."""
+        out = model_output[:, :self.num_joints]
+        center, scale = _dev(meta["center"], out.device).float(), _dev(meta["scale"], out.device).float()
+        preds = keypoints_from_simdr(_dev(meta["simdr_x"], out.device), _dev(meta["simdr_y"], out.device), center, scale, self.k)
+        res = dict(image_paths=meta.get("image_file"), bbox_ids=self._ids(meta))
+        res = self._finish(res, [("preds", preds), ("boxes", self._boxes(meta, center, scale, out.device))], out)
+        return {k: res[k] for k in ("preds", "boxes", "image_paths", "bbox_ids", "output_heatmap")}

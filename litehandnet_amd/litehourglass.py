@@ -58,6 +58,11 @@ class RepBasicUnit(PlanModule):
     def emit(self, pb, x, out=None):
         L = self.left_part
         gated = isinstance(self.ca, (ChannelAttension, SEBlock))
+        if not gated and out is None:
+            # cat(left, branch(right)) as a two-part tensor: the pass-through half is never copied (its consumers read it
+            # where it lives, its gradient lands in the producer's gradient buffer directly)
+            t = self.conv[0].emit(pb, pb.slice(x, L, self.right_part_in))
+            return pb.cat([pb.slice(x, 0, L), self.conv[1].emit(pb, t)])
         y = out if (out is not None and not gated) else pb.new(x.H, x.W, L + self.right_part_out)
         pb.ew([pb.slice(x, 0, L)], out=pb.slice(y, 0, L))                       # left half passes through
         t = self.conv[0].emit(pb, pb.slice(x, L, self.right_part_in))

@@ -46,6 +46,30 @@ class TRef:
 
 
 @dataclass
+class TCat:
+    """Channel concatenation of views that live in DIFFERENT buffers (same N, H, W) -- the result of a torch.cat whose
+    operands are never copied together: RepBasicUnit's pass-through half stays where it is (litehourglass.py:74-77) and
+    every whole-tensor consumer (max-pool, residual add, average pool) runs once per part."""
+    parts: list
+
+    @property
+    def C(self):
+        return sum(p.C for p in self.parts)
+
+    @property
+    def H(self):
+        return self.parts[0].H
+
+    @property
+    def W(self):
+        return self.parts[0].W
+
+
+def _parts(x):
+    return list(x.parts) if isinstance(x, TCat) else [x]
+
+
+@dataclass
 class _BufRec:
     H: int
     W: int
@@ -107,7 +131,45 @@ class PlanBuilder:
 
     def slice(self, x, coff, C):
         assert 0 <= coff and coff + C <= x.C and coff % 4 == 0 and C % 4 == 0, (coff, C, x)
+        if isinstance(x, TCat):
+            out, lo = [], 0
+            for p in x.parts:
+                a, b = max(coff, lo), min(coff + C, lo + p.C)
+                if a < b:
+                    out.append(TRef(p.buf, p.coff + a - lo, b - a, p.H, p.W))
+                lo += p.C
+            return out[0] if len(out) == 1 else TCat(out)
         return TRef(x.buf, x.coff + coff, C, x.H, x.W)
+
+    def cat(self, xs):
+        """torch.cat(xs, dim=1) without a copy."""
+        parts = [p for x in xs for p in _parts(x)]
+        assert all((p.H, p.W) == (parts[0].H, parts[0].W) for p in parts)
+        return parts[0] if len(parts) == 1 else TCat(parts)
+
+    def single(self, x):
+        """A one-buffer view of x (convolutions and gates read ONE buffer): multi-part tensors are copied together."""
+        return self.ew([x]) if isinstance(x, TCat) else x
+
+    def owns_buffer(self, x):
+        """True when x is the whole of an ungated buffer that is not the block's input (a gate attaches to a buffer)."""
+        if isinstance(x, TCat):
+            return False
+        b = self.bufs[x.buf]
+        return x.coff == 0 and x.C == b.C and not b.gate and not (self.in_ref is not None and x.buf == self.in_ref.buf)
+
+    @staticmethod
+    def _segments(tensors):
+        """Channel ranges (lo, hi) on which every tensor of the list is ONE part."""
+        cuts = set()
+        for t in tensors:
+            lo = 0
+            for p in _parts(t):
+                cuts.add(lo)
+                lo += p.C
+            cuts.add(lo)
+        cuts = sorted(cuts)
+        return list(zip(cuts[:-1], cuts[1:]))
 
     def _ws(self, arena, nbytes):
         return (arena, self.ar[arena].take(nbytes))
@@ -118,6 +180,7 @@ class PlanBuilder:
     # ------------------------------------------------------------------ forward emitters
     def conv(self, x, conv, bn=None, slope=1.0, out=None, nchw_out=False):
         """conv (+ train/eval BatchNorm + leaky slope as a pending transform).  Returns the output view."""
+        x = self.single(x)
         cout, cin_g, kh, kw = conv.weight.shape
         s, p, d, g = conv.stride[0], conv.padding[0], conv.dilation[0], conv.groups
         Ho = (x.H + 2 * p - d * (kh - 1) - 1) // s + 1
@@ -169,6 +232,7 @@ class PlanBuilder:
         """BatchNorm applied straight to a tensor (RepBlock.rbr_identity, repblocks.py:113-114): lowered as an
         identity depthwise 1x1 (weights = NULL = ones), which copies the consumed value, takes the batch
         statistics in its epilogue and leaves the normalisation pending like any other conv+BN."""
+        x = self.single(x)
         out = self.new(x.H, x.W, x.C)
         rec = dict(op=DW, x=x, out=out, conv=_IDENT, bn=bn, slope=float(slope), k=1, stride=1, pad=0, dil=1, nchw=False)
         rec["stats"] = self._ws("zf", STAT_REPLICAS * 2 * x.C * 8)
@@ -191,6 +255,10 @@ class PlanBuilder:
         if out is None:
             out = self.new(H, W, srcs[0].C)
         assert all(s.C == out.C for s in srcs)
+        if any(isinstance(t, TCat) for t in list(srcs) + [out]):
+            for lo, hi in self._segments(list(srcs) + [out]):      # one launch per run of channels that is one part everywhere
+                self.ew([self.slice(t, lo, hi - lo) for t in srcs], out_slope, self.slice(out, lo, hi - lo))
+            return out
         self.recs.append(dict(op=EW, srcs=list(srcs), out=out, slope=float(out_slope)))
         return out
 
@@ -198,11 +266,17 @@ class PlanBuilder:
         Ho, Wo = (x.H + 1) // 2, (x.W + 1) // 2
         if out is None:
             out = self.new(Ho, Wo, x.C)
+        if isinstance(x, TCat) or isinstance(out, TCat):
+            for lo, hi in self._segments([x, out]):
+                self.maxpool(self.slice(x, lo, hi - lo), self.slice(out, lo, hi - lo))
+            return out
         self.recs.append(dict(op=MAXPOOL, x=x, out=out))
         return out
 
     def avgpool(self, x, OH, OW):
-        """adaptive_avg_pool2d of the consumed value -> a plain [N,OH,OW,C] buffer."""
+        """adaptive_avg_pool2d of the consumed value -> a plain [N,OH,OW,C] buffer (one per part of a multi-part x)."""
+        if isinstance(x, TCat):
+            return TCat([self.avgpool(p, OH, OW) for p in x.parts])
         out = self.new(OH, OW, x.C)
         self.recs.append(dict(op=AVGPOOL, x=x, out=out, OH=OH, OW=OW, ca=False))
         return out
@@ -573,6 +647,15 @@ class PlanBuilder:
 
 
 _TRAIN_RUNS = 0      # bumped by every train-mode forward of any plan in this process (see CompiledPlan.run)
+_TABLE_EPOCH = 0     # bumped by invalidate_tables(): state changed where neither torch's version counters nor data pointers see it
+
+
+def invalidate_tables():
+    """Every plan's cached eval-mode BatchNorm tables / deployed biases become stale.  Call after changing parameters or
+    running statistics through `.data` (p.data.mul_(..), EMA / weight surgery): such writes bump no version counter.
+    litehandnet_amd.train.Trainer.step and FlatParams.broadcast call it themselves."""
+    global _TABLE_EPOCH
+    _TABLE_EPOCH += 1
 
 
 class CompiledPlan:
@@ -599,9 +682,21 @@ class CompiledPlan:
         self._grads = (C.c_void_p * len(state_tensors))()
         self._io = (C.c_void_p * 2)()
         self._table_sig = None
+        self.fwd_serial = 0            # forwards run on this workspace so far
+        self.bwd_serial = -1           # serial of the forward whose backward has already consumed the workspace
         self.mask_view = None
+        # dropout masks (Dropout2d of ChannelAttension, common.py:57; Dropout of mynet's attention, pose_hg_ms_att.py:171):
+        # one [N, C] slice per attention module, values 0 or 1/keep.  `mask_fn(plan)`, when set, fills them instead of the
+        # default bernoulli_ draw -- parity tests feed the oracle the same masks.
+        self.mask_fn = None
+        self.mask_slices = []
         if pb.ar["mask"].size:
             self.mask_view = self.view_f32(pb.arena_base["mask"], pb.ar["mask"].size // 4)
+            for r in pb.recs:
+                if r.get("mask") is not None:
+                    mod = r.get("ca", r.get("att"))
+                    Cc = r["y"].C
+                    self.mask_slices.append((mod, self.view_f32(pb._abs(r["mask"]), pb.N * Cc).view(pb.N, Cc)))
 
     def view_f32(self, byte_off, numel):
         return self.ws[byte_off:byte_off + numel * 4].view(torch.float32)
@@ -625,12 +720,17 @@ class CompiledPlan:
         self._io[0] = 0 if io0 is None else io0.data_ptr()
         self._io[1] = 0 if io1 is None else io1.data_ptr()
         global _TRAIN_RUNS
+        if phase == 0:
+            self.fwd_serial += 1       # the workspace (activations, BatchNorm saves, masks, gates) now belongs to THIS forward
         if phase == 0 and training:
             _TRAIN_RUNS += 1           # running statistics are about to move: every plan's eval tables become stale
             self._table_sig = None
         if phase == 0 and training and self.mask_view is not None:
-            keep = 1.0 - self.pb.p_drop
-            self.mask_view.bernoulli_(keep).mul_(1.0 / keep)
+            if self.mask_fn is not None:
+                self.mask_fn(self)
+            else:
+                keep = 1.0 - self.pb.p_drop
+                self.mask_view.bernoulli_(keep).mul_(1.0 / keep)
         L = _lib.lib()
         if sync is not None and training and sync[0] > 1:
             world, allreduce = sync
@@ -662,10 +762,12 @@ class CompiledPlan:
 
     def _tables_current(self):
         """True when this eval run may reuse the tables the previous eval run of this plan built.  Remembers the state it
-        saw: (process-wide count of train-mode runs, torch's version counter of every parameter / buffer, a few data
-        pointers).  Tensors without a version counter (created under torch.inference_mode) disable the reuse."""
+        saw: (process-wide count of train-mode runs, the invalidate_tables() epoch, torch's version counter and the data
+        pointer of every parameter / buffer).  Tensors without a version counter (created under torch.inference_mode)
+        disable the reuse.  Writes through `.data` are invisible to all of these: see invalidate_tables()."""
         try:
-            sig = (_TRAIN_RUNS, tuple(t._version for t in self.state_tensors), tuple(t.data_ptr() for t in self.state_tensors[:4]))
+            sig = (_TRAIN_RUNS, _TABLE_EPOCH, tuple(t._version for t in self.state_tensors),
+                   tuple(t.data_ptr() for t in self.state_tensors))
         except RuntimeError:
             self._table_sig = None
             return False

@@ -13,6 +13,7 @@ from torch import nn
 
 from . import _lib
 from .engine import Engine
+from .plan import invalidate_tables
 
 
 def init_distributed(backend=None):
@@ -86,6 +87,7 @@ class FlatParams:
     def broadcast(self, src=0):
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             broadcast_(self.flat, src)
+            invalidate_tables()
 
 
 def allreduce_mean_(flat_grads, group=None):
@@ -135,5 +137,6 @@ class Trainer:
         allreduce_mean_(g)
         self.fp.leaf.grad = g
         self.opt.step()
+        invalidate_tables()            # the fused step writes the flat leaf: per-parameter version counters do not move
         self.loss_sum += loss.detach()
         return loss

@@ -186,6 +186,32 @@ class ChannelAttension(nn.Module):
         _swap_in(self, "rbr_reparam", self.conv3x3.conv, k, b, ("conv3x3",))
 
 
+class FixedMask(nn.Module):
+    """Test helper: stands in for nn.Dropout2d / nn.Dropout with a GIVEN mask (values 0 or 1/keep, one per (n, c)), so that
+    the HIP path and the oracle can be compared with dropout switched on (common.py:57, pose_hg_ms_att.py:171)."""
+
+    def __init__(self, mask):
+        super().__init__()
+        self.register_buffer("mask", mask.clone())
+
+    def forward(self, x):
+        return x * self.mask.view(self.mask.shape + (1,) * (x.dim() - 2)).to(x.dtype)
+
+
+def install_masks(model, masks):
+    """masks: {module name: [N, C] tensor}; replaces the dropout of every named attention module.  Returns model."""
+    mods = dict(model.named_modules())
+    for name, mk in masks.items():
+        m = mods[name]
+        if isinstance(m, ChannelAttension):
+            m.conv1x1[0] = FixedMask(mk)
+        elif isinstance(m, ME_att):
+            m.att[5] = FixedMask(mk)
+        else:
+            raise TypeError(f"{name}: {type(m).__name__} has no dropout")
+    return model
+
+
 class SEBlock(nn.Module):
     """common.py:23-37: x * sigmoid(up(relu(down(avg_pool2d(x, kernel = width)))))."""
 

@@ -153,8 +153,49 @@ def test_decode_dark_unbiased(dev, golden_dir):
     assert np.abs(hp.cpu().numpy() - ohp).max() < 2e-3, np.abs(hp.cpu().numpy() - ohp).max()
     assert np.abs(pr.cpu().numpy() - opr).max() < 2e-2
     # the Taylor step itself is pinned by the reference's _taylor on the golden log-map (oracle == reference exactly)
-    d = heatmap.TopDownDecoder
-    assert d is not None
+
+
+def test_topdown_decoder_result_contract(dev, golden_dir):
+    """TopDownDecoder.decode / decode_simdr against the REAL reference's result dicts (tests/golden/make_golden_r2.py:
+    utils/post_processing/decoder.py:26-107 run on seeded heat maps, SimDR vectors and meta): same keys in the same order,
+    numpy float32 arrays / python list, values bit-exact; then the access pattern of test.py:125 + evaluate()
+    (`decoder.k`, float(boxes[i][4]), preds[i].tolist())."""
+    from litehandnet_amd import heatmap
+    g = np.load(os.path.join(golden_dir, "decoder_result.npz"))
+    cfg = litehandnet_cfg("B")
+    cfg.PIPELINE["unbiased_encoding"] = False
+    cfg.PIPELINE["simdr_split_ratio"] = 2
+    d = heatmap.TopDownDecoder(cfg)
+    assert d.k == 2 and d.post_process == "default" and d.num_joints == 21
+    n = g["heatmaps"].shape[0]
+    meta = dict(bbox_score=torch.from_numpy(g["bbox_score"]), bbox_id=torch.from_numpy(g["bbox_id"]),
+                image_file=[f"img_{i}.jpg" for i in range(n)], center=torch.from_numpy(g["center"]),
+                scale=torch.from_numpy(g["scale"]), simdr_x=torch.from_numpy(g["simdr_x"]), simdr_y=torch.from_numpy(g["simdr_y"]))
+    out = torch.from_numpy(g["heatmaps"]).to(dev)
+    res = d.decode(meta, out)
+    assert list(res) == ["preds", "hm_preds", "boxes", "image_paths", "bbox_ids", "output_heatmap"]
+    dt = [str(x) for x in g["dtypes"]]
+    for k, want in zip(("preds", "hm_preds", "boxes", "output_heatmap"), dt):
+        assert isinstance(res[k], np.ndarray) and str(res[k].dtype) == want, k
+    assert np.array_equal(res["preds"], g["preds"])
+    assert np.array_equal(res["hm_preds"], g["hm_preds"])
+    assert np.array_equal(res["boxes"], g["boxes"])
+    assert res["bbox_ids"] == g["bbox_id"].tolist() == g["bbox_ids"].tolist() and isinstance(res["bbox_ids"], list)
+    assert res["image_paths"] == meta["image_file"]
+    assert tuple(res["output_heatmap"].shape) == tuple(g["out_heatmap_shape"]) == (n, 21, 64, 64)
+    assert float(res["output_heatmap"].astype(np.float64).sum()) == float(g["out_heatmap_sum"])
+    rs = d.decode_simdr(meta, out)
+    assert list(rs) == ["preds", "boxes", "image_paths", "bbox_ids", "output_heatmap"]
+    assert str(rs["preds"].dtype) == dt[4] or rs["preds"].dtype == np.float32
+    assert np.array_equal(rs["preds"].astype(np.float32), g["simdr_preds"].astype(np.float32))
+    assert np.array_equal(rs["boxes"], g["simdr_boxes"])
+    # test.py / base_dataset.evaluate access pattern
+    for i in range(n):
+        assert isinstance(float(res["boxes"][i][4]), float) and len(res["preds"][i].tolist()) == 21
+    # device-resident variant: same numbers, nothing copied to the host
+    dd = heatmap.TopDownDecoder(cfg, as_numpy=False).decode(meta, out)
+    assert dd["preds"].is_cuda and dd["output_heatmap"].is_cuda
+    assert np.array_equal(dd["preds"].cpu().numpy(), g["preds"])
 
 
 def test_simdr_targets_loss_decode(dev, golden_dir):

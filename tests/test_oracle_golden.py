@@ -279,3 +279,21 @@ def test_dark_round_trip_property():
         hp, pr, _ = onp.keypoints_from_heatmaps(hm, center, scale, "unbiased", k)
         assert np.abs(hp - j[..., :2] / 4).max() < 0.05, k
         assert np.abs(pr - j[..., :2]).max() < 0.2, k
+
+
+def test_decoder_result_fixture(golden_dir):
+    """The oracle's decode restatement against the REAL reference's TopDownDecoder result dicts (make_golden_r2.py;
+    utils/post_processing/decoder.py:26-107), 'default' post-process and SimDR: bit-exact."""
+    g = np.load(os.path.join(golden_dir, "decoder_result.npz"))
+    hm = g["heatmaps"][:, :21]
+    hp, pr, mv = onp.keypoints_from_heatmaps(hm, g["center"], g["scale"], "default", 11)
+    assert np.array_equal(np.concatenate([pr, mv], 2), g["preds"])
+    assert np.array_equal(np.concatenate([hp * 4, mv], 2), g["hm_preds"])
+    boxes = np.zeros((hm.shape[0], 6), np.float32)
+    boxes[:, 0:2], boxes[:, 2:4] = g["center"], g["scale"]
+    boxes[:, 4] = np.prod(g["scale"] * 200.0, axis=1)
+    boxes[:, 5] = g["bbox_score"]
+    assert np.array_equal(boxes, g["boxes"]) and np.array_equal(boxes, g["simdr_boxes"])
+    sp = onp.keypoints_from_simdr(g["simdr_x"], g["simdr_y"], g["center"], g["scale"], 2)
+    assert np.array_equal(sp.astype(np.float32), g["simdr_preds"])
+    assert g["bbox_ids"].tolist() == g["bbox_id"].tolist()

@@ -103,6 +103,30 @@ def test_eval_table_reuse_signature():
     assert not p._tables_current() and p._tables_current()
     planmod._TRAIN_RUNS += 1                             # any train-mode forward in the process (raw-pointer updates)
     assert not p._tables_current() and p._tables_current()
+    # `.data` writes bump no version counter (EMA / weight surgery): invalidate_tables() is the documented way
+    w.data.mul_(3.0)
+    assert p._tables_current()                           # invisible ...
+    import litehandnet_amd
+    litehandnet_amd.invalidate_tables()
+    assert not p._tables_current() and p._tables_current()
+    # re-homing a LATE tensor (FlatParams: p.data = view of a flat buffer) is seen through its data pointer
+    many = [torch.nn.Parameter(torch.zeros(4)) for _ in range(8)]
+    p.state_tensors, p._table_sig = many, None
+    assert not p._tables_current() and p._tables_current()
+    many[6].data = torch.zeros(4)
+    assert not p._tables_current() and p._tables_current()
     with torch.inference_mode():
         p.state_tensors = [torch.zeros(4)]               # no version counter: never reuse
     assert not p._tables_current() and not p._tables_current()
+
+
+def test_two_part_pass_through():
+    """RepBasicUnit without attention returns cat(left, branch) as a two-part tensor: no copy record for the pass-through
+    half, whole-tensor consumers run once per part, and every part of the decoder's adds keeps its own gradient range."""
+    from litehandnet_amd.plan import MAXPOOL
+    _, pb, _ = _build("B", backward=True)
+    copies = [r for r in pb.recs if r["op"] == EW and len(r["srcs"]) == 1 and r["slope"] == 1.0]
+    assert len(copies) == 4                               # the four GATED units (stem, neck) still copy their left half
+    assert sum(1 for r in pb.recs if r["op"] == MAXPOOL) == 1 + 2 * 3     # stem pool + three two-part encoder pools
+    pb.finalize()
+    assert not pb._needs_zero_grad
