@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define LHN_VERSION 1
+#define LHN_VERSION 2
 /* cross-block accumulators (BN statistics, BN-backward sums) are replicated to spread atomic traffic:
  * layout double[LHN_STAT_REPLICAS][2][C]; a block adds into replica (blockIdx % LHN_STAT_REPLICAS). */
 #define LHN_STAT_REPLICAS 32
@@ -153,6 +153,18 @@ int lhn_loss_balanced_mse_bwd(const float* out, const float* target, const float
 int lhn_conv_pw_fwd(const lhn_view* x, const float* w /*[Cout,Cin]*/, const float* bias /*or NULL*/,
                     const lhn_view* y, double* stats /*or NULL*/, int stride, float* y_nchw /*or NULL*/,
                     const lhn_bnfin* fin /*or NULL*/, void* stream);
+/* Extended 1x1 entry points.  Any channel counts that are multiples of 4 (hourglassnet.py: 256; lite_hrnet.py: 20..320): the
+ * library runs (<=128) x (<=128) channel slices itself (input slices accumulate into y; bias and BatchNorm statistics on the
+ * last one).  opts (NULL = defaults):
+ *   w_cols / w_rows   real shape of the weight tensor when the views are padded to a multiple of 4 (the 21-joint head of
+ *                     hourglassnet.py:117 stored as 24 NHWC channels, and merge_preds :119 reading them back);
+ *   nchw_batch_stride floats between two images of the NCHW tensor (the stacked [N, num_stack, K, H, W] output, :136). */
+typedef struct lhn_pw_opts {
+  int32_t w_cols, w_rows;
+  int64_t nchw_batch_stride;
+} lhn_pw_opts;
+int lhn_conv_pw_fwd2(const lhn_view* x, const float* w, const float* bias, const lhn_view* y, double* stats, int stride,
+                     float* y_nchw, const lhn_bnfin* fin, const lhn_pw_opts* opts, void* stream);
 int lhn_conv_dw_fwd(const lhn_view* x, const float* w /*[C,1,k,k]*/, const lhn_view* y, double* stats,
                     int k, int stride, int pad, int dil, const lhn_bnfin* fin, void* stream);
 int lhn_conv_stem_fwd(const float* img /*[N,3,Hi,Wi]*/, const float* w /*[Cout,3,k,k]*/, const lhn_view* y,
@@ -231,6 +243,9 @@ int lhn_bn_bwd_finalize(const double* sums, const float* gamma, const float* sav
 int lhn_conv_pw_bwd(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy,
                     float* dx /*grad buffer of x, same geometry, or NULL*/, int dx_accumulate, float* dw,
                     float* dbias, int stride, const float* dy_nchw, int nrep, int64_t rep_stride, void* stream);
+int lhn_conv_pw_bwd2(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx,
+                     int dx_accumulate, float* dw, float* dbias, int stride, const float* dy_nchw, int nrep, int64_t rep_stride,
+                     const lhn_pw_opts* opts, void* stream);
 int lhn_conv_dw_bwd(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx,
                     int dx_accumulate, float* dw, int k, int stride, int pad, int dil, int nrep, int64_t rep_stride,
                     void* stream);

@@ -41,6 +41,9 @@ def litehandnet_cfg(variant="A", channels=128, num_joints=21, image_size=256, **
                      input_channel=channels, output_channel=num_joints)
     elif variant == "M":            # `mynet`, config/mynet/_2_rhd2d_256x256_dark.py:4-11
         model = dict(name="mynet", num_stage=4, num_block=[2, 2, 2], input_channel=channels, output_channel=num_joints)
+    elif variant == "H":            # stacked hourglass, config/hourglass/_2_rhd2d_256x256_dark_h2.py:4-10 (num_stack 2; _3_*_h1: 1)
+        model = dict(name="hourglass", input_channel=256 if channels == 128 else channels, output_channel=num_joints,
+                     num_stack=2, num_level=4)
     else:
         raise ValueError(variant)
     model.update(model_kw)

@@ -218,7 +218,7 @@ extern "C" int lhn_conv_stem_fwd(const float* img, const float* w, const lhn_vie
   if (finp && stats) fin = *finp; else fin.counter = nullptr;
   LHN_CHECK_ARG(img && w && lhn_view_ok(y), "lhn_conv_stem_fwd: bad view / null pointer");
   LHN_CHECK_ARG(y->C % 8 == 0 && pow2(y->C / 8) && y->C <= 256, "lhn_conv_stem_fwd: Cout=%d", y->C);
-  LHN_CHECK_ARG((k == 1 || k == 3) && stride >= 1, "lhn_conv_stem_fwd: k=%d", k);
+  LHN_CHECK_ARG((k == 1 || k == 3 || k == 5 || k == 7) && stride >= 1, "lhn_conv_stem_fwd: k=%d", k);
   const int Ho = (Hi + 2 * pad - k) / stride + 1, Wo = (Wi + 2 * pad - k) / stride + 1;
   LHN_CHECK_ARG(y->H == Ho && y->W == Wo, "lhn_conv_stem_fwd: output %dx%d, expected %dx%d", y->H, y->W, Ho, Wo);
   const int PL = 256 / (y->C / 8);
@@ -366,13 +366,14 @@ __global__ void __launch_bounds__(256) k_dw_bwd_weight(lhn_view x, lhn_view y, l
   }
 }
 
-// stem wgrad: thread = (pixel lane, 4 output channels); T = 3*K*K accumulators of float4
-template <int K>
+// stem wgrad: thread = (pixel lane, 4 output channels); T = 3*KR*K accumulators of float4 for the kernel rows
+// [kh0, kh0 + KR) (K = 7, hourglassnet.py:100, runs one kernel row per launch: 147 float4 accumulators do not fit)
+template <int K, int KR>
 __global__ void __launch_bounds__(256) k_stem_bwd(const float* __restrict__ img, lhn_view y, lhn_gradview gy,
                                                   float* __restrict__ dw, int Hi, int Wi, int stride, int pad, int nrep,
-                                                  int64_t rep_stride) {
+                                                  int64_t rep_stride, int kh0) {
   dw += (size_t)(blockIdx.x % nrep) * rep_stride;
-  constexpr int T = 3 * K * K;
+  constexpr int T = 3 * KR * K;
   __shared__ f4 red[256];
   const int C4 = y.C >> 2;
   const int tid = threadIdx.x, c4 = tid % C4, pl = tid / C4, PL = 256 / C4;
@@ -392,18 +393,19 @@ __global__ void __launch_bounds__(256) k_stem_bwd(const float* __restrict__ img,
     for (int c = 0; c < 3; ++c) {
       const float* plane = img + ((int64_t)n * 3 + c) * Hi * Wi;
 #pragma unroll
-      for (int kh = 0; kh < K; ++kh) {
-        const int ih = ho * stride - pad + kh;
+      for (int r = 0; r < KR; ++r) {
+        const int ih = ho * stride - pad + kh0 + r;
 #pragma unroll
         for (int kw = 0; kw < K; ++kw) {
           const int iw = wo * stride - pad + kw;
           float v = 0.f;
           if (ih >= 0 && ih < Hi && iw >= 0 && iw < Wi) v = plane[(int64_t)ih * Wi + iw];
-          acc[c * K * K + kh * K + kw] += dy * v;
+          acc[(c * KR + r) * K + kw] += dy * v;
         }
       }
     }
   }
+  constexpr int TW = 3 * K * K;            // weights per output channel
 #pragma unroll
   for (int i = 0; i < T; ++i) {
     __syncthreads();
@@ -412,10 +414,11 @@ __global__ void __launch_bounds__(256) k_stem_bwd(const float* __restrict__ img,
     if (tid < C4) {
       f4 s = (f4){0.f, 0.f, 0.f, 0.f};
       for (int j = 0; j < PL; ++j) s += red[j * C4 + tid];
-      atomicAdd(dw + (4 * tid + 0) * T + i, s.x);
-      atomicAdd(dw + (4 * tid + 1) * T + i, s.y);
-      atomicAdd(dw + (4 * tid + 2) * T + i, s.z);
-      atomicAdd(dw + (4 * tid + 3) * T + i, s.w);
+      const int c = i / (KR * K), r = (i / K) % KR, kw = i % K, e = c * K * K + (kh0 + r) * K + kw;
+      atomicAdd(dw + (4 * tid + 0) * TW + e, s.x);
+      atomicAdd(dw + (4 * tid + 1) * TW + e, s.y);
+      atomicAdd(dw + (4 * tid + 2) * TW + e, s.z);
+      atomicAdd(dw + (4 * tid + 3) * TW + e, s.w);
     }
   }
 }
@@ -462,13 +465,16 @@ extern "C" int lhn_conv_stem_bwd(const float* img, const lhn_view* y, const lhn_
                                  int stride, int pad, int nrep, int64_t rep_stride, void* stream) {
   if (nrep < 1) nrep = 1;
   LHN_CHECK_ARG(img && lhn_view_ok(y) && gy && gy->dz && dw, "lhn_conv_stem_bwd: bad view / null pointer");
-  LHN_CHECK_ARG(pow2(y->C / 4) && y->C <= 256 && (k == 1 || k == 3), "lhn_conv_stem_bwd: Cout=%d k=%d", y->C, k);
+  LHN_CHECK_ARG(pow2(y->C / 4) && y->C <= 256 && (k == 1 || k == 3 || k == 7), "lhn_conv_stem_bwd: Cout=%d k=%d", y->C, k);
   const int PL = 256 / (y->C / 4);
   const int g = grid_for((int64_t)y->N * y->H * y->W, PL, 4);
   if (k == 3)
-    hipLaunchKernelGGL((k_stem_bwd<3>), dim3(g), dim3(256), 0, (hipStream_t)stream, img, *y, *gy, dw, Hi, Wi, stride, pad, nrep, rep_stride);
+    hipLaunchKernelGGL((k_stem_bwd<3, 3>), dim3(g), dim3(256), 0, (hipStream_t)stream, img, *y, *gy, dw, Hi, Wi, stride, pad, nrep, rep_stride, 0);
+  else if (k == 1)
+    hipLaunchKernelGGL((k_stem_bwd<1, 1>), dim3(g), dim3(256), 0, (hipStream_t)stream, img, *y, *gy, dw, Hi, Wi, stride, pad, nrep, rep_stride, 0);
   else
-    hipLaunchKernelGGL((k_stem_bwd<1>), dim3(g), dim3(256), 0, (hipStream_t)stream, img, *y, *gy, dw, Hi, Wi, stride, pad, nrep, rep_stride);
+    for (int kh = 0; kh < 7; ++kh)
+      hipLaunchKernelGGL((k_stem_bwd<7, 1>), dim3(g), dim3(256), 0, (hipStream_t)stream, img, *y, *gy, dw, Hi, Wi, stride, pad, nrep, rep_stride, kh);
   LHN_CHECK_LAUNCH("lhn_conv_stem_bwd");
   return 0;
 }

@@ -313,7 +313,7 @@ __global__ void __launch_bounds__(256) k_kxk(lhn_view x, const float* __restrict
 // wgrad: blockIdx.y = tap.  64-pixel tiles; dYs[m][co], Xs[m][ci] (X shifted by the tap) -> dW_tap += dY^T X.
 template <int CIN, int NTO, int TAPS, bool PLAIN = false>
 __global__ void __launch_bounds__(256) k_kxk_wgrad(lhn_view x, lhn_view y, lhn_gradview gy, float* __restrict__ dw, int stride,
-                                                   int cout, int M, int ntiles, int nrep, int64_t rep_stride) {
+                                                   int cout, int M, int ntiles, int nrep, int64_t rep_stride, int wstride) {
   constexpr int NTI = CIN / 32, COP = 32 * NTO, LDY = COP + 4, LDX = CIN + 4;
   // fewer dW tiles than waves (32 -> 32: one tile): split the 64-pixel K range of a tile over the idle waves; the partial
   // tiles meet in LDS before the flush
@@ -436,7 +436,7 @@ __global__ void __launch_bounds__(256) k_kxk_wgrad(lhn_view x, lhn_view y, lhn_g
       for (int r = 0; r < 16; ++r) {
         const int co = co0 + 32 * it + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (co < cout) {
-          float* o = dw + ((size_t)co * CIN + 32 * jt + l31) * TAPS + tap;
+          float* o = dw + ((size_t)co * wstride + 32 * jt + l31) * TAPS + tap;     // wstride = input channels of the WHOLE weight
           if (exclusive) *o += accw[t][r];
           else atomicAdd(o, accw[t][r]);
         }
@@ -484,7 +484,7 @@ static int launch_kxk(const lhn_view* x, const float* w, const lhn_view* y, cons
 
 template <int CIN, int NTO, int TAPS, bool PLAIN = false>
 static int launch_kxk_wgrad(const lhn_view* x, const lhn_view* y, const lhn_gradview* gy, float* dw, int stride, int nrep,
-                            int64_t rep_stride, hipStream_t s, int cosplit = 1) {
+                            int64_t rep_stride, hipStream_t s, int cosplit = 1, int wstride = CIN) {
   const int M = y->N * y->H * y->W, ntiles = (M + 63) / 64;
   constexpr int COP = 32 * NTO;
   const size_t lds = (size_t)(64 * (COP + 4) + 64 * (CIN + 4)) * sizeof(float);
@@ -494,12 +494,12 @@ static int launch_kxk_wgrad(const lhn_view* x, const lhn_view* y, const lhn_grad
     lhn_set_error("lhn_conv_kxk_bwd: cannot reserve %zu B of LDS", lds);
     return 2;
   }
-  int grid = TAPS == 1 ? lhn_num_cus() * per_cu : lhn_num_cus() / 4;      // x 9 taps
-  if (cosplit > 1 && nrep > 1) grid = nrep;                               // exclusive replica slices: no atomics in the flush
+  int grid = TAPS == 1 ? lhn_num_cus() * per_cu / cosplit : lhn_num_cus() / 4;      // x 9 taps
+  if (TAPS > 1 && cosplit > 1 && nrep > 1) grid = nrep;                   // exclusive replica slices: no atomics in the flush
   if (grid < 1) grid = 1;
   if (grid > ntiles) grid = ntiles;
   hipLaunchKernelGGL((k_kxk_wgrad<CIN, NTO, TAPS, PLAIN>), dim3(grid, TAPS, cosplit), dim3(256), lds, s, *x, *y, *gy, dw, stride, y->C, M, ntiles, nrep,
-                     rep_stride);
+                     rep_stride, wstride);
   return 0;
 }
 
@@ -571,22 +571,52 @@ extern "C" int lhn_conv_kxk_bwd(const lhn_view* x, const float* w, const lhn_vie
 }
 
 // 1x1 backward as two launches (dgrad = the implicit-GEMM kernel with one tap, wgrad = the per-tap kernel with one
-// tap): used by lhn_conv_pw_bwd for large Cin*Cout where the fused kernel is LDS-bound to one block per CU.
+// tap): used by lhn_conv_pw_bwd for large Cin*Cout where the fused kernel is LDS-bound to one block per CU.  Channel counts
+// above 128 (hourglass: 256) run as 128-wide slices: dgrad accumulates over output-channel slices (its K), wgrad runs once
+// per input-channel slice with the output channels on gridDim.z.  Returns -1 when a shape has no instance (the caller then
+// takes the fused kernel).
 int lhn_pw_bwd_split(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx, int dx_accumulate,
                      float* dw, int nrep, int64_t rep_stride, hipStream_t s) {
-  int rc = -1;
+  const int Cin = x->C, Cout = y->C;
+  auto dgrad_ok = [&](int co, int nt) { return (co == 64 && (nt == 4 || nt == 2)) || (co == 128 && (nt == 4 || nt == 2 || nt == 1)) || (co == 32 && nt == 4); };
+  auto wgrad_ok = [&](int ci, int nto) { return (ci == 64 && (nto == 4 || nto == 2)) || (ci == 128 && (nto == 4 || nto == 2 || nto == 1)) || (ci == 32 && nto == 4); };
+  // every slice must have an instance BEFORE anything is launched (dy is formed in place: no way back afterwards)
+  const int ntd = Cin >= 128 ? 4 : (Cin + 31) / 32;                  // dgrad: features per block = 32*ntd, the rest on gridDim.y
+  if (Cin > 128 && Cin % 128 != 0) return -1;
+  for (int co0 = 0; co0 < Cout; co0 += 128)
+    if (dx && !dgrad_ok(Cout - co0 < 128 ? Cout - co0 : 128, ntd)) return -1;
+  const int nto = Cout >= 128 ? 4 : (Cout + 31) / 32;
+  if (Cout > 128 && Cout % 128 != 0) return -1;
+  for (int k0 = 0; k0 < Cin; k0 += 128)
+    if (!wgrad_ok(Cin - k0 < 128 ? Cin - k0 : 128, nto)) return -1;
   launch_dy_inplace(y, gy, s);
+  int rc = -1;
   if (dx) {
-    const int nt = (x->C + 31) / 32;
-#define PB(CO, NTV) if (y->C == CO && nt == NTV) rc = launch_kxk<CO, NTV, 1, 1, true>(x, w, y, gy, nullptr, dx, dx_accumulate, 1, x->C, s);
-    PB(64, 4) PB(128, 4) PB(128, 2) PB(64, 2) PB(128, 1) PB(32, 4)
+    for (int co0 = 0; co0 < Cout; co0 += 128) {
+      const int cc = Cout - co0 < 128 ? Cout - co0 : 128;
+      lhn_view yv = *y;
+      yv.coff += co0;
+      yv.C = cc;
+      const float* wv = w + (size_t)co0 * Cin;
+      const int acc = dx_accumulate || co0 > 0, nsplit = (Cin + 32 * ntd - 1) / (32 * ntd);
+      rc = -1;
+#define PB(CO, NTV) if (cc == CO && ntd == NTV) rc = launch_kxk<CO, NTV, 1, 1, true>(x, wv, &yv, gy, nullptr, dx, acc, 1, x->C, s, nullptr, nsplit);
+      PB(64, 4) PB(128, 4) PB(128, 2) PB(64, 2) PB(128, 1) PB(32, 4)
 #undef PB
-    if (rc) return rc;
+      if (rc) return rc < 0 ? 3 : rc;
+    }
   }
-  rc = -1;
-  const int nto = (y->C + 31) / 32;
-#define PW(CI, NTV) if (x->C == CI && nto == NTV) rc = launch_kxk_wgrad<CI, NTV, 1, true>(x, y, gy, dw, 1, nrep, rep_stride, s);
-  PW(64, 4) PW(128, 4) PW(128, 2) PW(64, 2) PW(128, 1) PW(32, 4)
+  for (int k0 = 0; k0 < Cin; k0 += 128) {
+    const int kc = Cin - k0 < 128 ? Cin - k0 : 128;
+    lhn_view xv = *x;
+    xv.coff += k0;
+    xv.C = kc;
+    const int cosplit = (Cout + 32 * nto - 1) / (32 * nto);
+    rc = -1;
+#define PW(CI, NTV) if (kc == CI && nto == NTV) rc = launch_kxk_wgrad<CI, NTV, 1, true>(&xv, y, gy, dw + k0, 1, nrep, rep_stride, s, cosplit, Cin);
+    PW(64, 4) PW(128, 4) PW(128, 2) PW(64, 2) PW(128, 1) PW(32, 4)
 #undef PW
-  return rc;
+    if (rc) return rc < 0 ? 3 : rc;
+  }
+  return 0;
 }

@@ -8,10 +8,46 @@
 // operands use the same permutation, so only the fp32 summation order differs from a sequential loop.
 #include "lhn_common.h"
 
+// Runtime geometry of ONE launch.  Wide or odd channel counts (hourglass C = 256, lite-hrnet 40/80/160/320) are run by the
+// host as a grid of (<= 128 input channels) x (<= 128 output channels) launches over channel slices of the same buffers:
+//   * the weight tensor keeps its own row stride (`wstride` floats), so a slice is just a pointer offset;
+//   * `kvalid` input channels of the slice are real, the rest of the CIN-wide tile is zero (in A and in W);
+//   * rows >= `wrows` of the slice have zero weights and zero bias (a 21-feature head stored in a 24-channel buffer);
+//   * `yacc`: this launch ADDS to what the previous input slice stored (K split); bias and BatchNorm statistics belong to
+//     the last slice, which sees the complete sum.
+struct PwGeom {
+  int wstride, kvalid, wrows, yacc, statC;
+  int64_t nchw_bstride;      // floats between two images of the NCHW output
+};
+
+// stage a [rows][CIN] weight slice into LDS (row pad LDA): zero beyond wrows / kvalid; 16-byte loads when the slice allows
+template <int CIN>
+__device__ __forceinline__ void pw_stage_w(float* Ws, int LDA, const float* __restrict__ w, int rows_pad, const PwGeom& g) {
+  constexpr int C4 = CIN / 4;
+  const bool vec = (g.wstride % 4 == 0) && (g.kvalid % 4 == 0) && ((reinterpret_cast<uintptr_t>(w) & 15) == 0);
+  for (int i = threadIdx.x; i < rows_pad * C4; i += 256) {
+    const int co = i / C4, k4 = i % C4;
+    f4 v = (f4){0.f, 0.f, 0.f, 0.f};
+    if (co < g.wrows) {
+      const float* r = w + (int64_t)co * g.wstride + k4 * 4;
+      if (vec) {
+        if (4 * k4 < g.kvalid) v = *reinterpret_cast<const f4*>(r);
+      } else {
+        if (4 * k4 + 0 < g.kvalid) v.x = r[0];
+        if (4 * k4 + 1 < g.kvalid) v.y = r[1];
+        if (4 * k4 + 2 < g.kvalid) v.z = r[2];
+        if (4 * k4 + 3 < g.kvalid) v.w = r[3];
+      }
+    }
+    *reinterpret_cast<f4*>(Ws + co * LDA + k4 * 4) = v;
+  }
+}
+
 template <int CIN, int NT>
 __global__ void __launch_bounds__(256, (CIN == 64 && NT == 2) || (CIN == 32 && NT == 4) ? 3 : (CIN == 64 && NT == 4) ? 2 : 1) k_pw_fwd(lhn_view x, const float* __restrict__ w, const float* __restrict__ bias,
                                                 lhn_view y, double* __restrict__ stats, int stride,
-                                                float* __restrict__ y_nchw, int cout, int M, int ntiles, lhn_bnfin fin) {
+                                                float* __restrict__ y_nchw, int cout, int M, int ntiles, lhn_bnfin fin,
+                                                PwGeom geo) {
   constexpr int LDA = CIN + 4;
   constexpr int PF = CIN / 8;   // float4 loads per thread per 128-pixel tile
   constexpr int C4 = CIN / 4;   // float4 per pixel row
@@ -23,15 +59,11 @@ __global__ void __launch_bounds__(256, (CIN == 64 && NT == 2) || (CIN == 32 && N
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
 
-  for (int i = tid; i < 32 * NT * C4; i += 256) {
-    const int co = i / C4, k4 = i % C4;
-    f4 v = (f4){0.f, 0.f, 0.f, 0.f};
-    if (co < cout) v = *reinterpret_cast<const f4*>(w + (int64_t)co * CIN + k4 * 4);
-    *reinterpret_cast<f4*>(Ws + co * LDA + k4 * 4) = v;
-  }
+  pw_stage_w<CIN>(Ws, LDA, w, 32 * NT, geo);
 
   const int c4 = tid % C4, row0 = tid / C4;
-  const int cabs = x.coff + 4 * c4;
+  const bool kok = 4 * c4 < x.C;                     // channel groups beyond the view are zero columns of the tile
+  const int cabs = x.coff + (kok ? 4 * c4 : 0);
   const Xf4 xf = lhn_load_xf(x, cabs);
   const int HoWo = y.H * y.W;
 
@@ -47,7 +79,7 @@ __global__ void __launch_bounds__(256, (CIN == 64 && NT == 2) || (CIN == 32 && N
     for (int p = 0; p < PF; ++p) {
       const int m = tile * 128 + row0 + p * RP;
       pre[p] = (f4){0.f, 0.f, 0.f, 0.f};
-      if (m < M) pre[p] = *reinterpret_cast<const f4*>(x.data + in_pix(m) * x.cstride + cabs);
+      if (m < M && kok) pre[p] = *reinterpret_cast<const f4*>(x.data + in_pix(m) * x.cstride + cabs);
     }
   };
   auto commit = [&](int tile) __attribute__((always_inline)) {
@@ -55,7 +87,7 @@ __global__ void __launch_bounds__(256, (CIN == 64 && NT == 2) || (CIN == 32 && N
     for (int p = 0; p < PF; ++p) {
       const int row = row0 + p * RP, m = tile * 128 + row;
       f4 v = (f4){0.f, 0.f, 0.f, 0.f};
-      if (m < M) {
+      if (m < M && kok) {
         v = lhn_apply_xf(pre[p], xf);
         if (x.gate) v *= *reinterpret_cast<const f4*>(x.gate + (int64_t)(m / HoWo) * x.cstride + cabs);
       }
@@ -68,7 +100,7 @@ __global__ void __launch_bounds__(256, (CIN == 64 && NT == 2) || (CIN == 32 && N
   for (int nt = 0; nt < NT; ++nt) {
     ssum[nt] = ssq[nt] = 0.f;
     const int ch = nt * 32 + l31;
-    bv[nt] = (bias && ch < cout) ? bias[ch] : 0.f;
+    bv[nt] = (bias && ch < geo.wrows) ? bias[ch] : 0.f;
   }
 
   int tile = blockIdx.x;
@@ -114,7 +146,9 @@ __global__ void __launch_bounds__(256, (CIN == 64 && NT == 2) || (CIN == 32 && N
             const int n = m0 / HoWo, p = m0 - n * HoWo;
             f4 o = (f4){acc[nt][4 * g] + bv[nt], acc[nt][4 * g + 1] + bv[nt], acc[nt][4 * g + 2] + bv[nt],
                         acc[nt][4 * g + 3] + bv[nt]};
-            *reinterpret_cast<f4*>(y_nchw + ((int64_t)n * cout + ch) * HoWo + p) = o;
+            f4* dst = reinterpret_cast<f4*>(y_nchw + (int64_t)n * geo.nchw_bstride + (int64_t)ch * HoWo + p);
+            if (geo.yacc) o += *dst;
+            *dst = o;
           }
         }
       } else {
@@ -122,8 +156,10 @@ __global__ void __launch_bounds__(256, (CIN == 64 && NT == 2) || (CIN == 32 && N
         for (int r = 0; r < 16; ++r) {
           const int m = mbase + (r & 3) + 8 * (r >> 2);
           if (m < M) {
-            const float v = acc[nt][r] + bv[nt];
-            y.data[(int64_t)m * y.cstride + y.coff + ch] = v;
+            float* dst = y.data + (int64_t)m * y.cstride + y.coff + ch;
+            float v = acc[nt][r] + bv[nt];
+            if (geo.yacc) v += *dst;
+            *dst = v;
             ssum[nt] += v;
             ssq[nt] += v * v;
           }
@@ -151,9 +187,9 @@ __global__ void __launch_bounds__(256, (CIN == 64 && NT == 2) || (CIN == 32 && N
         s += (double)red[(wv * 32 * NT + tid) * 2 + 0];
         q += (double)red[(wv * 32 * NT + tid) * 2 + 1];
       }
-      double* st = stats + (size_t)(blockIdx.x % LHN_STAT_REPLICAS) * 2 * cout;
+      double* st = stats + (size_t)(blockIdx.x % LHN_STAT_REPLICAS) * 2 * geo.statC;
       atomicAdd(st + tid, s);
-      atomicAdd(st + cout + tid, q);
+      atomicAdd(st + geo.statC + tid, q);
     }
     if (fin.counter && lhn_last_block(fin.counter)) lhn_bn_finalize_block(fin, stats);
   }
@@ -161,7 +197,7 @@ __global__ void __launch_bounds__(256, (CIN == 64 && NT == 2) || (CIN == 32 && N
 
 template <int CIN, int NT>
 static int launch_pw_fwd(const lhn_view* x, const float* w, const float* bias, const lhn_view* y, double* stats,
-                         int stride, float* y_nchw, int cout, const lhn_bnfin* fin, hipStream_t s) {
+                         int stride, float* y_nchw, int cout, const lhn_bnfin* fin, const PwGeom& geo, hipStream_t s) {
   lhn_bnfin f;
   if (fin && stats) f = *fin; else f.counter = nullptr;
   const int M = y->N * y->H * y->W;
@@ -176,44 +212,87 @@ static int launch_pw_fwd(const lhn_view* x, const float* w, const float* bias, c
   int grid = lhn_num_cus() * per_cu;
   if (grid > ntiles) grid = ntiles;
   hipLaunchKernelGGL((k_pw_fwd<CIN, NT>), dim3(grid), dim3(256), lds, s, *x, w, bias, *y, stats, stride, y_nchw, cout, M,
-                     ntiles, f);
+                     ntiles, f, geo);
   return 0;
 }
 
-extern "C" int lhn_conv_pw_fwd(const lhn_view* x, const float* w, const float* bias, const lhn_view* y, double* stats,
-                               int stride, float* y_nchw, const lhn_bnfin* fin, void* stream) {
+// smallest tile width (16/32/64/128) that holds `c` input channels; 0 = none
+static inline int pw_cin_tile(int c) { return c <= 16 ? 16 : c <= 32 ? 32 : c <= 64 ? 64 : c <= 128 ? 128 : 0; }
+
+// one (input slice, output slice) launch
+static int pw_fwd_slice(const lhn_view* x, const float* w, const float* bias, const lhn_view* y, double* stats, int stride,
+                        float* y_nchw, int cout, const lhn_bnfin* fin, const PwGeom& geo, hipStream_t s) {
+  const int ci = pw_cin_tile(x->C), nt = (cout + 31) / 32 == 3 ? 4 : (cout + 31) / 32;
+  int rc = -1;
+#define PW_CASE(CI, NTV) \
+  if (ci == CI && nt == NTV) rc = launch_pw_fwd<CI, NTV>(x, w, bias, y, stats, stride, y_nchw, cout, fin, geo, s);
+  PW_CASE(32, 1) PW_CASE(32, 2) PW_CASE(32, 4) PW_CASE(64, 1) PW_CASE(64, 2) PW_CASE(64, 4) PW_CASE(128, 1)
+  PW_CASE(128, 2) PW_CASE(128, 4) PW_CASE(16, 1) PW_CASE(16, 2) PW_CASE(16, 4)
+#undef PW_CASE
+  return rc;
+}
+
+extern "C" int lhn_conv_pw_fwd2(const lhn_view* x, const float* w, const float* bias, const lhn_view* y, double* stats,
+                                int stride, float* y_nchw, const lhn_bnfin* fin, const lhn_pw_opts* opts, void* stream) {
   LHN_CHECK_ARG(lhn_view_ok(x) && w && y, "lhn_conv_pw_fwd: bad input view / null pointer");
   LHN_CHECK_ARG(stride == 1 || stride == 2, "lhn_conv_pw_fwd: stride %d", stride);
   LHN_CHECK_ARG(y->N == x->N && y->H == (x->H + stride - 1) / stride && y->W == (x->W + stride - 1) / stride,
                 "lhn_conv_pw_fwd: output geometry %dx%dx%d does not match input %dx%dx%d / stride %d", y->N, y->H, y->W,
                 x->N, x->H, x->W, stride);
-  const int cout = y->C;
+  const int Cout = y->C, Cin = x->C, HoWo = y->H * y->W;
   if (y_nchw) {
-    LHN_CHECK_ARG((y->H * y->W) % 4 == 0 && cout > 0, "lhn_conv_pw_fwd: NCHW output needs H*W %% 4 == 0");
+    LHN_CHECK_ARG(HoWo % 4 == 0 && Cout > 0, "lhn_conv_pw_fwd: NCHW output needs H*W %% 4 == 0");
     LHN_CHECK_ARG(!stats, "lhn_conv_pw_fwd: no statistics on the NCHW head");
   } else {
     LHN_CHECK_ARG(lhn_view_ok(y), "lhn_conv_pw_fwd: bad output view");
   }
   LHN_CHECK_ARG((int64_t)y->N * y->H * y->W < (1ll << 31) - 256, "lhn_conv_pw_fwd: too many pixels");
-  const int nt = (cout + 31) / 32;
+  // weight tensor: [w_rows][w_cols], w_cols real input channels (<= Cin, the view may be padded to a multiple of 4),
+  // w_rows real output features (<= Cout)
+  const int wcols = (opts && opts->w_cols > 0) ? opts->w_cols : Cin, wrows = (opts && opts->w_rows > 0) ? opts->w_rows : Cout;
+  LHN_CHECK_ARG(wcols <= Cin && wcols > Cin - 4 && wrows <= Cout, "lhn_conv_pw_fwd: weight [%d][%d] does not fit views %d -> %d",
+                wrows, wcols, Cin, Cout);
+  const int64_t bstride = (opts && opts->nchw_batch_stride > 0) ? opts->nchw_batch_stride : (int64_t)Cout * HoWo;
   hipStream_t s = (hipStream_t)stream;
-  int rc = -1;
-#define PW_CASE(CI, NTV) \
-  if (x->C == CI && nt == NTV) rc = launch_pw_fwd<CI, NTV>(x, w, bias, y, stats, stride, y_nchw, cout, fin, s);
-  PW_CASE(32, 1) PW_CASE(32, 2) PW_CASE(32, 4) PW_CASE(64, 1) PW_CASE(64, 2) PW_CASE(64, 4) PW_CASE(128, 1)
-  PW_CASE(128, 2) PW_CASE(128, 4) PW_CASE(16, 1) PW_CASE(16, 2) PW_CASE(16, 4)
-#undef PW_CASE
-  if (nt == 3) {  // 96 output channels: run as 128 with zero rows
-#define PW_CASE3(CI) \
-  if (x->C == CI) rc = launch_pw_fwd<CI, 4>(x, w, bias, y, stats, stride, y_nchw, cout, fin, s);
-    PW_CASE3(16) PW_CASE3(32) PW_CASE3(64) PW_CASE3(128)
-#undef PW_CASE3
+  const bool single = Cin <= 128 && Cout <= 128;
+  for (int co0 = 0; co0 < Cout; co0 += 128) {
+    const int cc = Cout - co0 < 128 ? Cout - co0 : 128;
+    for (int k0 = 0; k0 < Cin; k0 += 128) {
+      const int kc = Cin - k0 < 128 ? Cin - k0 : 128;
+      const bool last = k0 + kc >= Cin;
+      lhn_view xv = *x, yv = *y;
+      xv.coff += k0;
+      xv.C = kc;
+      if (!y_nchw) {
+        yv.coff += co0;
+        yv.C = cc;
+      }
+      PwGeom g;
+      g.wstride = wcols;
+      g.kvalid = wcols - k0 < kc ? wcols - k0 : kc;
+      g.wrows = wrows - co0 < cc ? (wrows - co0 < 0 ? 0 : wrows - co0) : cc;
+      g.yacc = k0 > 0;
+      g.statC = Cout;
+      g.nchw_bstride = bstride;
+      const int rc = pw_fwd_slice(&xv, w + (int64_t)co0 * wcols + k0, (last && bias) ? bias + co0 : nullptr, &yv,
+                                  (last && stats) ? stats + co0 : nullptr, stride, y_nchw ? y_nchw + (int64_t)co0 * HoWo : nullptr,
+                                  cc, single ? fin : nullptr, g, s);
+      LHN_CHECK_ARG(rc != -1, "lhn_conv_pw_fwd: unsupported channels Cin=%d Cout=%d", Cin, Cout);
+      if (rc) return rc;
+    }
   }
-  LHN_CHECK_ARG(rc != -1, "lhn_conv_pw_fwd: unsupported channels Cin=%d Cout=%d (Cin in {16,32,64,128}, Cout<=128)", x->C,
-                cout);
-  if (rc) return rc;
   LHN_CHECK_LAUNCH("lhn_conv_pw_fwd");
+  if (!single && fin && stats) {   // fused finalize was requested: the sliced form runs it as its own launch
+    return lhn_bn_finalize(stats, fin->gamma, fin->beta, fin->running_mean, fin->running_var, fin->num_batches_tracked, fin->table,
+                           fin->cstride, fin->coff, fin->C, fin->save_mean_invstd, fin->count, fin->eps, fin->momentum, fin->slope,
+                           1, fin->conv_bias, stream);
+  }
   return 0;
+}
+
+extern "C" int lhn_conv_pw_fwd(const lhn_view* x, const float* w, const float* bias, const lhn_view* y, double* stats,
+                               int stride, float* y_nchw, const lhn_bnfin* fin, void* stream) {
+  return lhn_conv_pw_fwd2(x, w, bias, y, stats, stride, y_nchw, fin, nullptr, stream);
 }
 
 // =====================================================================================================
@@ -229,7 +308,7 @@ template <int CIN, int NTO, bool NCHW>
 __global__ void __launch_bounds__(256, (CIN == 32 && NTO == 1 && !NCHW) ? 4 : (CIN <= 64 && NTO <= 2 && !NCHW) ? 3 : 1) k_pw_bwd(lhn_view x, const float* __restrict__ w, lhn_view y, lhn_gradview gy,
                                                 float* __restrict__ dx, int dx_acc, float* __restrict__ dw,
                                                 float* __restrict__ dbias, int stride, const float* __restrict__ dy_nchw,
-                                                int cout, int M, int ntiles, int nrep, int64_t rep_stride) {
+                                                int cout, int M, int ntiles, int nrep, int64_t rep_stride, PwGeom geo) {
   constexpr int NTI = CIN / 32;
   constexpr int COP = 32 * NTO;
   constexpr int LDW = CIN + 4, LDY = COP + 4, LDX = CIN + 4;
@@ -249,17 +328,14 @@ __global__ void __launch_bounds__(256, (CIN == 32 && NTO == 1 && !NCHW) ? 4 : (C
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
   const int HoWo = y.H * y.W;
 
-  for (int i = tid; i < COP * (CIN / 4); i += 256) {
-    const int co = i / (CIN / 4), k4 = i % (CIN / 4);
-    f4 v = (f4){0.f, 0.f, 0.f, 0.f};
-    if (co < cout) v = *reinterpret_cast<const f4*>(w + (int64_t)co * CIN + k4 * 4);
-    *reinterpret_cast<f4*>(Ws + co * LDW + k4 * 4) = v;
-  }
+  pw_stage_w<CIN>(Ws, LDW, w, COP, geo);
 
   // loader geometry: X tile 64 x CIN/4 float4, dY tile 64 x COP/4 float4
   constexpr int XC4 = CIN / 4, XRP = 256 / XC4, XPF = 64 / XRP;
   constexpr int YC4 = COP / 4, YRP = 256 / YC4, YPF = 64 / YRP;
-  const int xc4 = tid % XC4, xr0 = tid / XC4, xabs = x.coff + 4 * xc4;
+  const int xc4 = tid % XC4, xr0 = tid / XC4;
+  const bool xok = 4 * xc4 < x.C;      // channel groups beyond the input slice are zero columns
+  const int xabs = x.coff + (xok ? 4 * xc4 : 0);
   const int yc4 = tid % YC4, yr0 = tid / YC4, yabs = y.coff + 4 * yc4;
   const Xf4 xxf = lhn_load_xf(x, xabs);
   const bool ych_ok = 4 * yc4 < cout;  // cout is a multiple of 4 on the NHWC path
@@ -295,7 +371,7 @@ __global__ void __launch_bounds__(256, (CIN == 32 && NTO == 1 && !NCHW) ? 4 : (C
       for (int k = 0; k < NCHW_PF; ++k) {
         const int i = tid + 256 * k, row = i & 63, co = i >> 6, m = min(tile * 64 + row, M - 1);
         const int n = m / HoWo, p = m - n * HoWo;
-        ynch[k] = co < cout ? dy_nchw[((int64_t)n * cout + co) * HoWo + p] : 0.f;
+        ynch[k] = co < cout ? dy_nchw[(int64_t)n * geo.nchw_bstride + (int64_t)co * HoWo + p] : 0.f;
       }
     }
 #pragma unroll
@@ -317,7 +393,7 @@ __global__ void __launch_bounds__(256, (CIN == 32 && NTO == 1 && !NCHW) ? 4 : (C
     for (int p = 0; p < XPF; ++p) {
       const int row = xr0 + p * XRP, m = tile * 64 + row;
       f4 v = (f4){0.f, 0.f, 0.f, 0.f};
-      if (m < M) {
+      if (m < M && xok) {
         v = lhn_apply_xf(xraw[p], xxf);
         if (x.gate) v *= *reinterpret_cast<const f4*>(x.gate + (int64_t)(m / HoWo) * x.cstride + xabs);
       }
@@ -402,7 +478,7 @@ __global__ void __launch_bounds__(256, (CIN == 32 && NTO == 1 && !NCHW) ? 4 : (C
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int m = tile * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (m < M) {
+            if (m < M && 32 * jt + l31 < x.C) {
               float* o = dx + in_pix(m) * x.cstride + x.coff + 32 * jt + l31;
               *o = dx_acc ? *o + accx[t][r] : accx[t][r];
             }
@@ -424,7 +500,7 @@ __global__ void __launch_bounds__(256, (CIN == 32 && NTO == 1 && !NCHW) ? 4 : (C
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = 32 * it + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (co < cout) atomicAdd(dw + (int64_t)co * CIN + 32 * jt + l31, accw[t][r]);
+        if (co < geo.wrows && 32 * jt + l31 < geo.kvalid) atomicAdd(dw + (int64_t)co * geo.wstride + 32 * jt + l31, accw[t][r]);
       }
     }
   }
@@ -432,21 +508,21 @@ __global__ void __launch_bounds__(256, (CIN == 32 && NTO == 1 && !NCHW) ? 4 : (C
     if (NCHW) {
       // head: few channels; recompute per-channel sums is cheap -- done by a separate tiny pass on the host side
     } else if (ych_ok) {
-      atomicAdd(dbias + 4 * yc4 + 0, bsum.x);
-      atomicAdd(dbias + 4 * yc4 + 1, bsum.y);
-      atomicAdd(dbias + 4 * yc4 + 2, bsum.z);
-      atomicAdd(dbias + 4 * yc4 + 3, bsum.w);
+      if (4 * yc4 + 0 < geo.wrows) atomicAdd(dbias + 4 * yc4 + 0, bsum.x);
+      if (4 * yc4 + 1 < geo.wrows) atomicAdd(dbias + 4 * yc4 + 1, bsum.y);
+      if (4 * yc4 + 2 < geo.wrows) atomicAdd(dbias + 4 * yc4 + 2, bsum.z);
+      if (4 * yc4 + 3 < geo.wrows) atomicAdd(dbias + 4 * yc4 + 3, bsum.w);
     }
   }
 }
 
 // bias gradient of the NCHW head: db[co] = sum_{n,p} dy[n,co,p]
 __global__ void __launch_bounds__(256) k_bias_grad_nchw(const float* __restrict__ dy, float* __restrict__ db, int N, int C,
-                                                        int HW) {
+                                                        int HW, int64_t bstride) {
   const int co = blockIdx.x;
   double s = 0;
   for (int n = blockIdx.y; n < N; n += gridDim.y) {
-    const float* p = dy + ((int64_t)n * C + co) * HW;
+    const float* p = dy + (int64_t)n * bstride + (int64_t)co * HW;
     float a = 0.f;
     for (int i = threadIdx.x; i < HW; i += blockDim.x) a += p[i];
     s += a;
@@ -461,7 +537,7 @@ __global__ void __launch_bounds__(256) k_bias_grad_nchw(const float* __restrict_
 template <int CIN, int NTO, bool NCHW>
 static int launch_pw_bwd_t(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx, int dx_acc,
                          float* dw, float* dbias, int stride, const float* dy_nchw, int cout, int nrep, int64_t rep_stride,
-                         hipStream_t s) {
+                         const PwGeom& geo, hipStream_t s) {
   const int M = y->N * y->H * y->W;
   const int ntiles = (M + 63) / 64;
   constexpr int COP = 32 * NTO;
@@ -476,50 +552,85 @@ static int launch_pw_bwd_t(const lhn_view* x, const float* w, const lhn_view* y,
   if (grid > ntiles) grid = ntiles;
   lhn_gradview g = *gy;
   hipLaunchKernelGGL((k_pw_bwd<CIN, NTO, NCHW>), dim3(grid), dim3(256), lds, s, *x, w, *y, g, dx, dx_acc, dw, dbias, stride, dy_nchw,
-                     cout, M, ntiles, nrep, rep_stride);
+                     cout, M, ntiles, nrep, rep_stride, geo);
   if (dbias && dy_nchw)
-    hipLaunchKernelGGL(k_bias_grad_nchw, dim3(cout, y->N < 16 ? y->N : 16), dim3(256), 0, s, dy_nchw, dbias, y->N, cout,
-                       y->H * y->W);
+    hipLaunchKernelGGL(k_bias_grad_nchw, dim3(geo.wrows, y->N < 16 ? y->N : 16), dim3(256), 0, s, dy_nchw, dbias, y->N, cout,
+                       y->H * y->W, geo.nchw_bstride);
   return 0;
 }
 
 template <int CIN, int NTO>
 static int launch_pw_bwd(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx, int dx_acc,
                          float* dw, float* dbias, int stride, const float* dy_nchw, int cout, int nrep, int64_t rep_stride,
-                         hipStream_t s) {
-  if (dy_nchw) return launch_pw_bwd_t<CIN, NTO, true>(x, w, y, gy, dx, dx_acc, dw, dbias, stride, dy_nchw, cout, nrep, rep_stride, s);
-  return launch_pw_bwd_t<CIN, NTO, false>(x, w, y, gy, dx, dx_acc, dw, dbias, stride, dy_nchw, cout, nrep, rep_stride, s);
+                         const PwGeom& geo, hipStream_t s) {
+  if (dy_nchw) return launch_pw_bwd_t<CIN, NTO, true>(x, w, y, gy, dx, dx_acc, dw, dbias, stride, dy_nchw, cout, nrep, rep_stride, geo, s);
+  return launch_pw_bwd_t<CIN, NTO, false>(x, w, y, gy, dx, dx_acc, dw, dbias, stride, dy_nchw, cout, nrep, rep_stride, geo, s);
 }
 
 int lhn_pw_bwd_split(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx, int dx_accumulate,
                      float* dw, int nrep, int64_t rep_stride, hipStream_t s);
 
-extern "C" int lhn_conv_pw_bwd(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx,
-                               int dx_accumulate, float* dw, float* dbias, int stride, const float* dy_nchw, int nrep,
-                               int64_t rep_stride, void* stream) {
+extern "C" int lhn_conv_pw_bwd2(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx,
+                                int dx_accumulate, float* dw, float* dbias, int stride, const float* dy_nchw, int nrep,
+                                int64_t rep_stride, const lhn_pw_opts* opts, void* stream) {
   if (nrep < 1) nrep = 1;
   LHN_CHECK_ARG(lhn_view_ok(x) && w && y && gy && dw, "lhn_conv_pw_bwd: bad view / null pointer");
   LHN_CHECK_ARG(stride == 1 || stride == 2, "lhn_conv_pw_bwd: stride %d", stride);
   LHN_CHECK_ARG(stride == 1 || !dx || dx_accumulate, "lhn_conv_pw_bwd: stride-2 dgrad only accumulates into a zeroed gradient");
   if (!dy_nchw) LHN_CHECK_ARG(lhn_view_ok(y) && gy->dz, "lhn_conv_pw_bwd: bad output view / missing dz");
-  const int cout = y->C, nto = (cout + 31) / 32;
+  const int Cout = y->C, Cin = x->C, HoWo = y->H * y->W;
+  const int wcols = (opts && opts->w_cols > 0) ? opts->w_cols : Cin, wrows = (opts && opts->w_rows > 0) ? opts->w_rows : Cout;
+  LHN_CHECK_ARG(wcols <= Cin && wcols > Cin - 4 && wrows <= Cout, "lhn_conv_pw_bwd: weight [%d][%d] does not fit views %d -> %d",
+                wrows, wcols, Cin, Cout);
+  const int64_t bstride = (opts && opts->nchw_batch_stride > 0) ? opts->nchw_batch_stride : (int64_t)Cout * HoWo;
   hipStream_t s = (hipStream_t)stream;
-  int rc = -1;
-  if (stride == 1 && !dy_nchw && !dbias && x->C * cout >= 64 * 128 && cout % 32 == 0) {
-    rc = lhn_pw_bwd_split(x, w, y, gy, dx, dx_accumulate, dw, nrep, rep_stride, s);
+  if (stride == 1 && !dy_nchw && !dbias && Cin * Cout >= 64 * 128 && Cout % 32 == 0 && Cin % 32 == 0 && wcols == Cin && wrows == Cout) {
+    const int rc = lhn_pw_bwd_split(x, w, y, gy, dx, dx_accumulate, dw, nrep, rep_stride, s);
     if (rc == 0) {
       LHN_CHECK_LAUNCH("lhn_conv_pw_bwd");
       return 0;
     }
     if (rc > 0) return rc;
   }
+  for (int co0 = 0; co0 < Cout; co0 += 128) {
+    const int cc = Cout - co0 < 128 ? Cout - co0 : 128, nto = (cc + 31) / 32 == 3 ? 4 : (cc + 31) / 32;
+    for (int k0 = 0; k0 < Cin; k0 += 128) {
+      const int kc = Cin - k0 < 128 ? Cin - k0 : 128, ci = kc <= 32 ? 32 : pw_cin_tile(kc);   // (no 16-wide backward tile)
+      lhn_view xv = *x, yv = *y;
+      xv.coff += k0;
+      xv.C = kc;
+      if (!dy_nchw) {
+        yv.coff += co0;
+        yv.C = cc;
+      }
+      PwGeom g;
+      g.wstride = wcols;
+      g.kvalid = wcols - k0 < kc ? wcols - k0 : kc;
+      g.wrows = wrows - co0 < cc ? (wrows - co0 < 0 ? 0 : wrows - co0) : cc;
+      g.yacc = 0;
+      g.statC = Cout;
+      g.nchw_bstride = bstride;
+      const float* wv = w + (int64_t)co0 * wcols + k0;
+      float* dwv = dw + (int64_t)co0 * wcols + k0;
+      float* dbv = (dbias && k0 == 0) ? dbias + co0 : nullptr;
+      const float* dyv = dy_nchw ? dy_nchw + (int64_t)co0 * HoWo : nullptr;
+      const int acc = dx_accumulate || co0 > 0;
+      int rc = -1;
 #define PWB_CASE(CI, NTV) \
-  if (x->C == CI && nto == NTV) rc = launch_pw_bwd<CI, NTV>(x, w, y, gy, dx, dx_accumulate, dw, dbias, stride, dy_nchw, cout, nrep, rep_stride, s);
-  PWB_CASE(32, 1) PWB_CASE(32, 2) PWB_CASE(32, 4) PWB_CASE(64, 1) PWB_CASE(64, 2) PWB_CASE(64, 4) PWB_CASE(128, 1)
-  PWB_CASE(128, 2) PWB_CASE(128, 4)
+  if (ci == CI && nto == NTV) rc = launch_pw_bwd<CI, NTV>(&xv, wv, &yv, gy, dx, acc, dwv, dbv, stride, dyv, cc, nrep, rep_stride, g, s);
+      PWB_CASE(32, 1) PWB_CASE(32, 2) PWB_CASE(32, 4) PWB_CASE(64, 1) PWB_CASE(64, 2) PWB_CASE(64, 4) PWB_CASE(128, 1)
+      PWB_CASE(128, 2) PWB_CASE(128, 4)
 #undef PWB_CASE
-  LHN_CHECK_ARG(rc != -1, "lhn_conv_pw_bwd: unsupported channels Cin=%d Cout=%d", x->C, cout);
-  if (rc) return rc;
+      LHN_CHECK_ARG(rc != -1, "lhn_conv_pw_bwd: unsupported channels Cin=%d Cout=%d", Cin, Cout);
+      if (rc) return rc;
+    }
+  }
   LHN_CHECK_LAUNCH("lhn_conv_pw_bwd");
   return 0;
+}
+
+extern "C" int lhn_conv_pw_bwd(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx,
+                               int dx_accumulate, float* dw, float* dbias, int stride, const float* dy_nchw, int nrep,
+                               int64_t rep_stride, void* stream) {
+  return lhn_conv_pw_bwd2(x, w, y, gy, dx, dx_accumulate, dw, dbias, stride, dy_nchw, nrep, rep_stride, nullptr, stream);
 }

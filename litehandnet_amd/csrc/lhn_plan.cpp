@@ -201,9 +201,18 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
           fin = mkfin(P, ws, o, params);
           fin.count *= cscale;
         }
-        if (h0) rc = lhn_conv_pw_fwd(&x, prm<const float>(params, o.p[0]), bn ? nullptr : prm<const float>(params, o.p[1]), &y,
-                             (training && o.ws[0] >= 0) ? reinterpret_cast<double*>(at(ws, o.ws[0])) : nullptr, o.i[0], nchw,
-                             (bn && training && fuse_finalize() && whole) ? &fin : nullptr, stream);
+        // i[2], i[3] = real rows / columns of the weight tensor when the views are padded to a multiple of 4 (0 = the views');
+        // i[4], i[5] = stack index / number of stacks of an NCHW output [N, S, K, H, W] (hourglassnet.py:136)
+        lhn_pw_opts po;
+        po.w_rows = o.i[2]; po.w_cols = o.i[3]; po.nchw_batch_stride = 0;
+        if (nchw && o.i[5] > 1) {
+          const int64_t khw = (int64_t)o.out_C * y.H * y.W;
+          nchw += (int64_t)o.i[4] * khw;
+          po.nchw_batch_stride = (int64_t)o.i[5] * khw;
+        }
+        if (h0) rc = lhn_conv_pw_fwd2(&x, prm<const float>(params, o.p[0]), bn ? nullptr : prm<const float>(params, o.p[1]), &y,
+                              (training && o.ws[0] >= 0) ? reinterpret_cast<double*>(at(ws, o.ws[0])) : nullptr, o.i[0], nchw,
+                              (bn && training && fuse_finalize() && whole) ? &fin : nullptr, &po, stream);
         if (!rc && bn && h1 && !skip_tables && !(training && fuse_finalize() && whole)) rc = sep_finalize(fin, reinterpret_cast<const double*>(at(ws, o.ws[0])), training, stream);
         break;
       }
@@ -328,8 +337,15 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
           g = mkgrad(P, ws, o.out_buf, o.i[5] != 0);
         }
         float* dx = o.i[2] ? reinterpret_cast<float*>(at(ws, P->bufs[o.in_buf[0]].grad_off)) : nullptr;
-        rc = lhn_conv_pw_bwd(&x, prm<const float>(params, o.p[0]), &y, &g, dx, o.i[2] == 2, prm<float>(grads, o.p[1]),
-                             prm<float>(grads, o.p[2]), o.i[0], nchw, nrep, rstr, stream);
+        lhn_pw_opts po;     // i[3], i[4] = weight rows / columns; i[6], i[7] = stack index / stacks (see OP_PW)
+        po.w_rows = o.i[3]; po.w_cols = o.i[4]; po.nchw_batch_stride = 0;
+        if (nchw && o.i[7] > 1) {
+          const int64_t khw = (int64_t)o.out_C * y.H * y.W;
+          nchw += (int64_t)o.i[6] * khw;
+          po.nchw_batch_stride = (int64_t)o.i[7] * khw;
+        }
+        rc = lhn_conv_pw_bwd2(&x, prm<const float>(params, o.p[0]), &y, &g, dx, o.i[2] == 2, prm<float>(grads, o.p[1]),
+                              prm<float>(grads, o.p[2]), o.i[0], nchw, nrep, rstr, &po, stream);
         break;
       }
       case OP_DW_BWD: {

@@ -46,8 +46,10 @@ class _PlanFn(torch.autograd.Function):
             plan.buf_data(plan.pb.in_ref).copy_(xc.permute(0, 2, 3, 1))
         out = None
         if plan.nchw_out:
-            out = torch.empty((x.shape[0], plan.pb.nchw_out_C, plan.out_hw[0], plan.out_hw[1]), dtype=torch.float32,
-                              device=x.device)
+            shape = (x.shape[0], plan.pb.nchw_out_C, plan.out_hw[0], plan.out_hw[1])
+            if getattr(plan, "stacked", False):        # hourglass: [N, num_stack, K, H, W] even for one stack
+                shape = (shape[0], plan.pb.nchw_stacks) + shape[1:]
+            out = torch.empty(shape, dtype=torch.float32, device=x.device)
         ctx.sync = eng.sync_config() if training else None
         plan.run(0, xc if eng.full else None, out, training, sync=ctx.sync)
         ctx.serial = plan.fwd_serial
@@ -223,6 +225,7 @@ class Engine:
             pb.set_output(y)
         plan = CompiledPlan(pb, tensors, x.device)
         plan.out_hw, plan.nchw_out = (y.H, y.W), nchw_out
+        plan.stacked = bool(getattr(self.module, "stacked_output", False))
         plan.mask_fn = self.mask_fn
         self.plans[key] = plan
         return plan

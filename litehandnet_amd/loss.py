@@ -36,11 +36,19 @@ class _BalancedMSE(torch.autograd.Function):
     @staticmethod
     def forward(ctx, output, target, weight, loss_weight, balance):
         _lib.require_device(output)
-        o, t = _lib.f32c(output), _lib.f32c(target)
+        o, t, weight = _lib.f32c(output), _lib.f32c(target), _lib.f32c(weight)
+        if o.dim() == 5 and t.dim() == 4:
+            # stacked hourglass output [N, S, K, H, W] (hourglassnet.py:136) against one target per sample: every stack is
+            # supervised by the same target and weights (intermediate supervision).  The reference's own broadcast of a 4-D
+            # target against the 5-D output is ill-formed (it needs N == S), see DESIGN.md.
+            S = o.shape[1]
+            t = t.unsqueeze(1).expand(-1, S, -1, -1, -1).contiguous()
+            weight = weight.reshape(o.shape[0], 1, o.shape[2]).expand(-1, S, -1).contiguous()
         if t.shape != o.shape:
             raise _lib.LhnError(f"target shape {tuple(t.shape)} != output shape {tuple(o.shape)}")
-        N, K, H, W = o.shape
-        w = _lib.f32c(weight).reshape(N, K)
+        H, W = o.shape[-2:]
+        N, K = o.numel() // (o.shape[-3] * H * W), o.shape[-3]      # leading dims fold into the sample count
+        w = weight.reshape(N, K)
         acc = torch.empty(68, dtype=torch.float64, device=o.device)
         loss = torch.empty(1, dtype=torch.float32, device=o.device)
         L = _lib.lib()
@@ -54,7 +62,8 @@ class _BalancedMSE(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dloss):
         o, t, w, acc = ctx.saved_tensors
-        N, K, H, W = o.shape
+        H, W = o.shape[-2:]
+        N, K = w.shape
         g = torch.empty_like(o)
         dl = _lib.f32c(dloss.reshape(1))
         L = _lib.lib()

@@ -1,6 +1,6 @@
 """Model registry -- models/__init__.py:11-26 restricted to the hot path."""
 
-__all__ = ["litehandnet", "litehourglass", "mynet"]
+__all__ = ["litehandnet", "litehourglass", "mynet", "hourglass"]
 
 
 def get_model(cfg):
@@ -12,5 +12,8 @@ def get_model(cfg):
     if name == "mynet":
         from .pose_hg_ms_att import MultiScaleAttentionHourglass
         return MultiScaleAttentionHourglass(cfg)
+    if name == "hourglass":
+        from .hourglassnet import HourglassNet
+        return HourglassNet(cfg)
     from .liteHandNet import LiteHandNet
     return LiteHandNet(cfg)

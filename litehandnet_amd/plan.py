@@ -111,6 +111,7 @@ class PlanBuilder:
         self.ar = {"zf": _Arena(), "zb": _Arena(), "mask": _Arena(), "misc": _Arena()}
         self.out_ref = None
         self.nchw_out_C = None
+        self.nchw_stacks = 1
         self.in_ref = None
 
     # ------------------------------------------------------------------ declarations
@@ -178,8 +179,11 @@ class PlanBuilder:
         return -1 if t is None else self.state_index[id(t)]
 
     # ------------------------------------------------------------------ forward emitters
-    def conv(self, x, conv, bn=None, slope=1.0, out=None, nchw_out=False):
-        """conv (+ train/eval BatchNorm + leaky slope as a pending transform).  Returns the output view."""
+    def conv(self, x, conv, bn=None, slope=1.0, out=None, nchw_out=False, stack=None):
+        """conv (+ train/eval BatchNorm + leaky slope as a pending transform).  Returns the output view.
+        1x1 convolutions take any channel counts: views are padded to multiples of 4 (a 21-feature head is a 24-channel
+        NHWC buffer whose last channels are exact zeros) and the library slices wide ones.  `stack = (i, S)`: the NCHW output
+        is slot i of an [N, S, K, H, W] tensor (hourglassnet.py:136)."""
         x = self.single(x)
         cout, cin_g, kh, kw = conv.weight.shape
         s, p, d, g = conv.stride[0], conv.padding[0], conv.dilation[0], conv.groups
@@ -196,17 +200,25 @@ class PlanBuilder:
             kind = KXK
         else:
             raise _lib.LhnError(f"unsupported convolution {tuple(conv.weight.shape)} groups={g}")
-        if kind != STEM and kind != DW:
+        cpad = cout
+        if kind == PW:
+            assert cin_g <= x.C < cin_g + 4, (cin_g, x.C)
+            if not nchw_out:
+                cpad = (cout + 3) // 4 * 4
+                assert cpad == cout or bn is None, "a padded output has no BatchNorm"
+        elif kind == KXK:
             assert cin_g == x.C, (cin_g, x.C)
         if nchw_out:
             assert kind == PW and bn is None and out is None
             out = TRef(-2, 0, cout, Ho, Wo)
             self.nchw_out_C = cout
+            self.nchw_stacks = 1 if stack is None else int(stack[1])
         elif out is None:
-            out = self.new(Ho, Wo, cout)
-        assert (out.H, out.W, out.C) == (Ho, Wo, cout), (out, Ho, Wo, cout)
+            out = self.new(Ho, Wo, cpad)
+        assert (out.H, out.W, out.C) == (Ho, Wo, cpad), (out, Ho, Wo, cpad)
         rec = dict(op=kind, x=x, out=out, conv=conv, bn=bn, slope=float(slope), k=kh, stride=s, pad=p, dil=d,
-                   nchw=nchw_out)
+                   nchw=nchw_out, stack=(0, 1) if stack is None else (int(stack[0]), int(stack[1])),
+                   wrc=(cout if cpad != cout else 0, cin_g if cin_g != x.C else 0))
         if kind == KXK:
             rec["wt"] = self._ws("misc", 9 * cout * cin_g * 4)      # tap-major weight scratch (lhn_conv_kxk_*: wt_scratch)
         if bn is not None:
@@ -444,7 +456,7 @@ class PlanBuilder:
                 elif k == PW:
                     o = TRef(-1, 0, out.C, out.H, out.W) if r["nchw"] else out
                     fwd.append(mk(PW, ins=(x,), out=o, p=(pw, self._p(conv.bias)) + pbn, ws=wsl,
-                                  i=(r["stride"], 1 if r["nchw"] else 0), f=fl))
+                                  i=(r["stride"], 1 if r["nchw"] else 0, r["wrc"][0], r["wrc"][1], r["stack"][0], r["stack"][1]), f=fl))
                 elif k == DW:
                     fwd.append(mk(DW, ins=(x,), out=out, p=(pw, cb) + pbn, ws=wsl, i=(r["k"], r["stride"], r["pad"], r["dil"]), f=fl))
                 else:
@@ -550,7 +562,8 @@ class PlanBuilder:
                         o = TRef(-1, 0, out.C, out.H, out.W) if r["nchw"] else out
                         # a bias in front of a train-mode BatchNorm has an identically zero gradient
                         body.append(mk(PW_BWD, ins=(x,), out=o, p=(pw, pw, self._p(conv.bias) if bn is None else -1),
-                                       i=(r["stride"], 1 if r["nchw"] else 0, mode, 0, 0, use_coef)))
+                                       i=(r["stride"], 1 if r["nchw"] else 0, mode, r["wrc"][0], r["wrc"][1], use_coef,
+                                          r["stack"][0], r["stack"][1])))
                     elif k == DW:
                         body.append(mk(DW_BWD, ins=(x,), out=out, p=(pw, pw),
                                        i=(r["k"], r["stride"], r["pad"], r["dil"], mode, use_coef)))

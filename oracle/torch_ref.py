@@ -207,6 +207,8 @@ def install_masks(model, masks):
             m.conv1x1[0] = FixedMask(mk)
         elif isinstance(m, ME_att):
             m.att[5] = FixedMask(mk)
+        elif isinstance(m, nn.Sequential) and len(m) > 5 and isinstance(m[5], (nn.Dropout, FixedMask)):
+            m[5] = FixedMask(mk)            # ME_att.att addressed directly (pose_hg_ms_att.py:165-174)
         else:
             raise TypeError(f"{name}: {type(m).__name__} has no dropout")
     return model
@@ -655,6 +657,103 @@ class MultiScaleAttentionHourglass(nn.Module):
                 nn.init.zeros_(m.bias)
 
 
+# --------------------------------------------------------------------------
+# hourglass baseline (models/pose_estimation/hourglassnet.py) -- BASELINE config 5
+# --------------------------------------------------------------------------
+class HGConv(nn.Module):
+    """hourglassnet.py:6-25: biased conv (pad (k-1)//2) [+ BatchNorm] [+ ReLU]."""
+
+    def __init__(self, inp_dim, out_dim, kernel_size=3, stride=1, bn=False, relu=True):
+        super().__init__()
+        self.inp_dim = inp_dim
+        self.conv = nn.Conv2d(inp_dim, out_dim, kernel_size, stride, padding=(kernel_size - 1) // 2, bias=True)
+        self.relu = nn.ReLU() if relu else None
+        self.bn = nn.BatchNorm2d(out_dim) if bn else None
+
+    def forward(self, x):
+        x = self.conv(x)
+        if self.bn is not None:
+            x = self.bn(x)
+        return self.relu(x) if self.relu is not None else x
+
+
+class HGResidual(nn.Module):
+    """hourglassnet.py:27-53: pre-activation bottleneck BN-ReLU-1x1, BN-ReLU-3x3, BN-ReLU-1x1, plus (projected) skip."""
+
+    def __init__(self, inp_dim, out_dim):
+        super().__init__()
+        self.relu = nn.ReLU()
+        self.bn1 = nn.BatchNorm2d(inp_dim)
+        self.conv1 = HGConv(inp_dim, out_dim // 2, 1, relu=False)
+        self.bn2 = nn.BatchNorm2d(out_dim // 2)
+        self.conv2 = HGConv(out_dim // 2, out_dim // 2, 3, relu=False)
+        self.bn3 = nn.BatchNorm2d(out_dim // 2)
+        self.conv3 = HGConv(out_dim // 2, out_dim, 1, relu=False)
+        self.skip_layer = nn.Identity() if inp_dim == out_dim else HGConv(inp_dim, out_dim, 1, relu=False)
+
+    def forward(self, x):
+        out = self.conv1(self.relu(self.bn1(x)))
+        out = self.conv2(self.relu(self.bn2(out)))
+        out = self.conv3(self.relu(self.bn3(out)))
+        return out + self.skip_layer(x)
+
+
+class HourglassModule(nn.Module):
+    """hourglassnet.py:55-81 (recursive)."""
+
+    def __init__(self, n, f, bn=None, increase=0):
+        super().__init__()
+        nf = f + increase
+        self.up1 = HGResidual(f, f)
+        self.pool1 = nn.MaxPool2d(2, 2)
+        self.low1 = HGResidual(f, nf)
+        self.n = n
+        self.low2 = HourglassModule(n - 1, nf, bn=bn) if n > 1 else HGResidual(nf, nf)
+        self.low3 = HGResidual(nf, f)
+        self.up2 = nn.Upsample(scale_factor=2, mode="nearest")
+
+    def forward(self, x):
+        return self.up1(x) + self.up2(self.low3(self.low2(self.low1(self.pool1(x)))))
+
+
+class HGMerge(nn.Module):
+    def __init__(self, x_dim, y_dim):
+        super().__init__()
+        self.conv = HGConv(x_dim, y_dim, 1, relu=False, bn=False)
+
+    def forward(self, x):
+        return self.conv(x)
+
+
+class HourglassNet(nn.Module):
+    """hourglassnet.py:90-136: stacked hourglass, output [N, num_stack, K, H/4, W/4]."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        M = cfg.MODEL
+        ns, nl = M.get("num_stack", 8), M.get("num_level", 4)
+        c, k = M.get("input_channel", 256), M.get("output_channel", 21)
+        self.num_stack = ns
+        self.pre = nn.Sequential(HGConv(3, 64, 7, 2, bn=True, relu=True), HGResidual(64, 128), nn.MaxPool2d(2, 2),
+                                 HGResidual(128, 128), HGResidual(128, c))
+        self.hgs = nn.ModuleList([nn.Sequential(HourglassModule(nl, c, bn=False, increase=0)) for _ in range(ns)])
+        self.features = nn.ModuleList([nn.Sequential(HGResidual(c, c), HGConv(c, c, 1, bn=True, relu=True)) for _ in range(ns)])
+        self.outs = nn.ModuleList([HGConv(c, k, 1, relu=False, bn=False) for _ in range(ns)])
+        self.merge_features = nn.ModuleList([HGMerge(c, c) for _ in range(ns - 1)])
+        self.merge_preds = nn.ModuleList([HGMerge(k, c) for _ in range(ns - 1)])
+
+    def forward(self, imgs):
+        x = self.pre(imgs)
+        outs = []
+        for i in range(self.num_stack):
+            feature = self.features[i](self.hgs[i](x))
+            preds = self.outs[i](feature)
+            outs.append(preds)
+            if i < self.num_stack - 1:
+                x = x + self.merge_preds[i](preds) + self.merge_features[i](feature)
+        return torch.stack(outs, dim=1)
+
+
 def get_model(cfg, p_drop=0.3):
     """Mirror of models/__init__.py:20-26 restricted to the hot path.
 
@@ -667,6 +766,8 @@ def get_model(cfg, p_drop=0.3):
         return LiteHourglassNet(cfg, p_drop)
     if name == "mynet":
         return MultiScaleAttentionHourglass(cfg, p_drop)
+    if name == "hourglass":
+        return HourglassNet(cfg)
     raise AssertionError(f"model <{name}> is outside the hot path")
 
 

@@ -163,7 +163,11 @@ def _model_case(dev, golden_dir, tag, variant="B", **kw):
     ref.load_state_dict(sd)
     ref = ref.double().train()
     y64 = ref(synth.synth_images(n, size, seed).double())
-    l64 = cfg.LOSS.loss_weight[0] * torch_ref.distance_loss(y64, torch.from_numpy(tgt).double(), tw.double())
+    t64, w64 = torch.from_numpy(tgt).double(), tw.double()
+    if y64.dim() == 5:         # stacked hourglass [N, S, K, H, W]: every stack supervised by the same target (see loss.py)
+        S = y64.shape[1]
+        t64, w64 = t64.unsqueeze(1).expand(-1, S, -1, -1, -1), w64.unsqueeze(1).expand(-1, S, -1, -1)
+    l64 = cfg.LOSS.loss_weight[0] * torch_ref.distance_loss(y64, t64, w64)
     l64.backward()
     l64 = l64.detach()
     y64n = y64.detach().numpy()
@@ -191,9 +195,10 @@ def _model_case(dev, golden_dir, tag, variant="B", **kw):
     rm64 = ref.state_dict()[bk].numpy()
     rm_tol = max(1e-5, 3 * np.abs(g["bn_running_mean"] - rm64).max())
     assert np.abs(m.state_dict()[bk].cpu().numpy() - rm64).max() <= rm_tol
-    p, _ = heatmap._get_max_preds(y.detach())
-    p64, _ = onp.get_max_preds(y64n.astype(np.float32))
-    p32, _ = onp.get_max_preds(g["heatmap"])
+    last = (lambda a: a[:, -1]) if y64n.ndim == 5 else (lambda a: a)       # hourglass: the last stack is the prediction
+    p, _ = heatmap._get_max_preds(last(y.detach()).contiguous())
+    p64, _ = onp.get_max_preds(np.ascontiguousarray(last(y64n)).astype(np.float32))
+    p32, _ = onp.get_max_preds(np.ascontiguousarray(last(g["heatmap"])))
     same32 = (p32 == p64).all(-1)
     assert (p.cpu().numpy() == p64).all(-1)[same32].all()
     print(f"[{tag}] heatmap err vs f64: hip {err:.2e} / reference-fp32 {ref32_err:.2e}; grad-norm err: hip {worst:.2e} / "

@@ -297,3 +297,19 @@ def test_decoder_result_fixture(golden_dir):
     sp = onp.keypoints_from_simdr(g["simdr_x"], g["simdr_y"], g["center"], g["scale"], 2)
     assert np.array_equal(sp.astype(np.float32), g["simdr_preds"])
     assert g["bbox_ids"].tolist() == g["bbox_id"].tolist()
+
+
+def test_hourglass_fixtures(golden_dir):
+    """oracle.torch_ref.HourglassNet against the REAL reference's vectors (make_golden_r2_models.py): forward heat maps
+    [N, S, K, H, W] bit-for-bit, known parameter count 3,427,733 (debug_litehandnet.ipynb:542)."""
+    for tag, ns in (("H1_128", 1), ("H2_128", 2)):
+        g = np.load(os.path.join(golden_dir, f"model_{tag}.npz"))
+        cfg = litehandnet_cfg("H", num_stack=ns)
+        m = torch_ref.get_model(cfg)
+        if ns == 1:
+            assert sum(p.numel() for p in m.parameters()) == 3427733
+        m.load_state_dict(synth.synth_state_dict(m, int(g["seed"])))
+        m.train()
+        y = m(synth.synth_images(int(g["n"]), int(g["size"]), int(g["seed"])))
+        assert tuple(y.shape) == g["heatmap"].shape and y.shape[1] == ns
+        assert np.abs(y.detach().numpy() - g["heatmap"]).max() <= 1e-5 * np.abs(g["heatmap"]).max()
