@@ -162,11 +162,20 @@ int lhn_conv_pw_fwd(const lhn_view* x, const float* w /*[Cout,Cin]*/, const floa
 typedef struct lhn_pw_opts {
   int32_t w_cols, w_rows;
   int64_t nchw_batch_stride;
+  /* forward only: the consumed input is coef[0]*value(x) + sum_e coef[e+1]*value(extra[e]) -- residual sums taken on load
+   * (litehourglass.py:41-49) instead of being materialised by lhn_ew_fwd.  Same geometry and channel count as x. */
+  int32_t n_extra;              /* 0..2 */
+  const lhn_view* extra;
+  float coef[3];
 } lhn_pw_opts;
 int lhn_conv_pw_fwd2(const lhn_view* x, const float* w, const float* bias, const lhn_view* y, double* stats, int stride,
                      float* y_nchw, const lhn_bnfin* fin, const lhn_pw_opts* opts, void* stream);
 int lhn_conv_dw_fwd(const lhn_view* x, const float* w /*[C,1,k,k]*/, const lhn_view* y, double* stats,
                     int k, int stride, int pad, int dil, const lhn_bnfin* fin, void* stream);
+/* depthwise 3x3 (stride 1, 'same' padding, dilation 1/2) over coef2[0]*value(x) + coef2[1]*value(extra): MSRB's second
+ * round reads `out + ca(cat)` (litehourglass.py:41-45) without an elementwise pass in between.  extra == NULL: lhn_conv_dw_fwd. */
+int lhn_conv_dw_fwd2(const lhn_view* x, const float* w, const lhn_view* y, double* stats, int k, int stride, int pad, int dil,
+                     const lhn_bnfin* fin, const lhn_view* extra, const float* coef2 /*host, 2 floats*/, void* stream);
 int lhn_conv_stem_fwd(const float* img /*[N,3,Hi,Wi]*/, const float* w /*[Cout,3,k,k]*/, const lhn_view* y,
                       double* stats, int Hi, int Wi, int k, int stride, int pad, const lhn_bnfin* fin, void* stream);
 /* wt_scratch: optional 9*Cout*Cin floats of caller-owned scratch; the call re-lays the OIHW weights tap-major into it
@@ -199,6 +208,8 @@ int lhn_fold_bn(const float* w, int kb, const float* gamma, const float* beta, c
  * BN -> SiLU -> conv pre-activation unit of models/pose_hg_ms_att.py:76-90; single same-size source in backward) */
 #define LHN_SLOPE_SILU 2.0f
 int lhn_ew_fwd(const lhn_view* srcs, int nsrc, const lhn_view* dst, float out_slope, void* stream);
+/* dst = act(sum_i coef[i] * value_i); coef == NULL: all ones (host pointer, nsrc floats) */
+int lhn_ew_fwd2(const lhn_view* srcs, int nsrc, const float* coef, const lhn_view* dst, float out_slope, void* stream);
 int lhn_maxpool2_fwd(const lhn_view* x, const lhn_view* y, void* stream);
 int lhn_avgpool_fwd(const lhn_view* x, float* out /*[N,OH,OW,x.C]*/, int OH, int OW, void* stream);
 /* gamma == NULL: deployed attention, `beta` is the bias of the fused depthwise conv, no BatchNorm (eval only) */
@@ -291,7 +302,7 @@ typedef struct lhn_op {
   int32_t p[12];       /* parameter / state indices into the params array, -1 = none              */
   int64_t ws[6];       /* byte offsets into the workspace, -1 = none                               */
   int32_t i[8];
-  float   f[4];
+  float   f[8];        /* [0..3] op scalars (eps, momentum, slope, ..); [4..6] coefficients of summed input sources */
 } lhn_op;
 
 typedef struct lhn_buf {

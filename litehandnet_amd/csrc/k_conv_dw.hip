@@ -173,8 +173,9 @@ static inline int grid_for(int64_t items_per_block_total, int per_block, int cap
 }
 static inline bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
+struct DwExtra;
 int lhn_dwk_fwd_lds(const lhn_view* x, const float* w, const lhn_view* y, double* stats, int k, int dil, lhn_bnfin fin,
-                    hipStream_t s);
+                    hipStream_t s, const DwExtra* ex);
 int lhn_dwk_bwd_lds(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx, int dx_acc,
                     float* dw, int k, int dil, int nrep, int64_t rep_stride, hipStream_t s);
 static bool lhn_dw_force_gather() {
@@ -184,6 +185,24 @@ static bool lhn_dw_force_gather() {
     v = (e && e[0] == '1') ? 1 : 0;
   }
   return v == 1;
+}
+
+static int dw_fwd_extra(const lhn_view* x, const float* w, const lhn_view* y, double* stats, int k, int stride, int pad, int dil,
+                        lhn_bnfin fin, const lhn_view* extra, const float* coef, hipStream_t s);
+
+extern "C" int lhn_conv_dw_fwd2(const lhn_view* x, const float* w, const lhn_view* y, double* stats, int k, int stride,
+                                int pad, int dil, const lhn_bnfin* finp, const lhn_view* extra, const float* coef2, void* stream) {
+  if (!extra) return lhn_conv_dw_fwd(x, w, y, stats, k, stride, pad, dil, finp, stream);
+  lhn_bnfin fin;
+  if (finp && stats) fin = *finp; else fin.counter = nullptr;
+  LHN_CHECK_ARG(lhn_view_ok(x) && lhn_view_ok(y) && lhn_view_ok(extra) && w && coef2, "lhn_conv_dw_fwd2: bad view / null pointer");
+  LHN_CHECK_ARG(extra->C == x->C && extra->N == x->N && extra->H == x->H && extra->W == x->W, "lhn_conv_dw_fwd2: extra source geometry");
+  LHN_CHECK_ARG(x->C == y->C && y->N == x->N && y->H == x->H && y->W == x->W, "lhn_conv_dw_fwd2: same-size output");
+  const int rc = dw_fwd_extra(x, w, y, stats, k, stride, pad, dil, fin, extra, coef2, (hipStream_t)stream);
+  LHN_CHECK_ARG(rc == 1, "lhn_conv_dw_fwd2: a second source needs k=3, stride 1, 'same' padding, C %% 32 == 0, W >= 8 (got k=%d s=%d C=%d W=%d)",
+                k, stride, x->C, y->W);
+  LHN_CHECK_LAUNCH("lhn_conv_dw_fwd2");
+  return 0;
 }
 
 extern "C" int lhn_conv_dw_fwd(const lhn_view* x, const float* w, const lhn_view* y, double* stats, int k, int stride,
@@ -199,7 +218,7 @@ extern "C" int lhn_conv_dw_fwd(const lhn_view* x, const float* w, const lhn_view
   const int grid = grid_for((int64_t)y->N * Ho, 1, 8);
   hipStream_t s = (hipStream_t)stream;
   if (w && stride == 1 && pad == dil * (k - 1) / 2 && x->C % 32 == 0 && y->W >= 8 && !lhn_dw_force_gather() &&
-      lhn_dwk_fwd_lds(x, w, y, stats, k, dil, fin, s)) {
+      lhn_dwk_fwd_lds(x, w, y, stats, k, dil, fin, s, nullptr)) {
   } else if (k == 3)
     hipLaunchKernelGGL((k_dw_fwd<3>), dim3(grid), dim3(256), lds, s, *x, w, *y, stats, stride, pad, dil, fin);
   else if (k == 7)
@@ -489,10 +508,18 @@ struct DwTile {
   static constexpr int P = DIL * (K - 1) / 2, HH = TH + 2 * P, WW = TW + 2 * P, PIX = HH * WW;
 };
 
-template <int K, int DIL>
+// One extra input source: the consumed input is coef[0]*value(x) + coef[1]*value(ex.v) (MSRB's `out + ca(cat)`,
+// litehourglass.py:41-45, summed while the halo tile is staged instead of being written by an elementwise pass).
+struct DwExtra {
+  lhn_view v;
+  float coef[2];
+  int n;             // 0 or 1
+};
+
+template <int K, int DIL, int NS = 1>
 __global__ void __launch_bounds__(256) k_dwk_fwd_lds(lhn_view x, const float* __restrict__ w, lhn_view y,
                                                      double* __restrict__ stats, int tiles_h, int tiles_w, int cgroups,
-                                                     lhn_bnfin fin, int ps) {
+                                                     lhn_bnfin fin, int ps, DwExtra ex) {
   constexpr int TH = 8, TW = 32, KK = K * K;
   using T = DwTile<K, DIL, TH, TW>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -507,6 +534,9 @@ __global__ void __launch_bounds__(256) k_dwk_fwd_lds(lhn_view x, const float* __
   const int cg = blockIdx.x % cgroups;                     // grid % cgroups == 0 (host): fixed per block
   const int cin = x.coff + cg * 32 + 4 * c4, cout = y.coff + cg * 32 + 4 * c4;
   const Xf4 xf = lhn_load_xf(x, cin);
+  const int cin2 = NS > 1 ? ex.v.coff + cg * 32 + 4 * c4 : 0;
+  Xf4 xf2;
+  if (NS > 1) xf2 = lhn_load_xf(ex.v, cin2);
   for (int i = tid; i < KK * 8; i += 256) {
     const int k = i >> 3, cc = cg * 32 + 4 * (i & 7);
     wl[i] = (f4){w[(cc + 0) * KK + k], w[(cc + 1) * KK + k], w[(cc + 2) * KK + k], w[(cc + 3) * KK + k]};
@@ -515,7 +545,7 @@ __global__ void __launch_bounds__(256) k_dwk_fwd_lds(lhn_view x, const float* __
   // halo staging in two phases: issue() sends every global load of a tile (clamped coordinates, no branches, so they
   // are all in flight together) into registers one tile AHEAD; commit() transforms, zeroes the padding and writes LDS
   constexpr int NIT = (T::PIX + 31) / 32;
-  f4 raw[NIT];
+  f4 raw[NIT], raw2[NS > 1 ? NIT : 1];
   auto issue = [&](int t) __attribute__((always_inline)) {
     int r = t / cgroups;
     const int tw = r % tiles_w;
@@ -526,12 +556,15 @@ __global__ void __launch_bounds__(256) k_dwk_fwd_lds(lhn_view x, const float* __
     const int SH = (x.H - pa + ps - 1) / ps, SW = (x.W - pb + ps - 1) / ps;     // sub-lattice extent
     const int h0 = th * TH - T::P, w0 = tw * TW - T::P;
     const float* xin = x.data + (size_t)n * x.H * x.W * x.cstride + cin;
+    const float* xin2 = NS > 1 ? ex.v.data + (size_t)n * x.H * x.W * ex.v.cstride + cin2 : nullptr;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int i = min(pl + 32 * it, T::PIX - 1);
       const int ph = i / T::WW, pw = i - ph * T::WW;
       const int ih = pa + ps * min(max(h0 + ph, 0), max(SH - 1, 0)), iw = pb + ps * min(max(w0 + pw, 0), max(SW - 1, 0));
-      raw[it] = *reinterpret_cast<const f4*>(xin + ((size_t)min(ih, x.H - 1) * x.W + min(iw, x.W - 1)) * x.cstride);
+      const size_t pix = (size_t)min(ih, x.H - 1) * x.W + min(iw, x.W - 1);
+      raw[it] = *reinterpret_cast<const f4*>(xin + pix * x.cstride);
+      if (NS > 1) raw2[it] = *reinterpret_cast<const f4*>(xin2 + pix * ex.v.cstride);
     }
   };
   int t = blockIdx.x;
@@ -544,7 +577,12 @@ __global__ void __launch_bounds__(256) k_dwk_fwd_lds(lhn_view x, const float* __
     r /= tiles_h;
     const int par = r % (ps * ps), n = r / (ps * ps), pa = par / ps, pb = par % ps;
     const int SH = (x.H - pa + ps - 1) / ps, SW = (x.W - pb + ps - 1) / ps;
-    const f4 gate = x.gate ? *reinterpret_cast<const f4*>(x.gate + (size_t)n * x.cstride + cin) : (f4){1.f, 1.f, 1.f, 1.f};
+    f4 gate = x.gate ? *reinterpret_cast<const f4*>(x.gate + (size_t)n * x.cstride + cin) : (f4){1.f, 1.f, 1.f, 1.f};
+    f4 gate2 = (f4){0.f, 0.f, 0.f, 0.f};
+    if (NS > 1) {
+      gate *= ex.coef[0];
+      gate2 = (ex.v.gate ? *reinterpret_cast<const f4*>(ex.v.gate + (size_t)n * ex.v.cstride + cin2) : (f4){1.f, 1.f, 1.f, 1.f}) * ex.coef[1];
+    }
     const int h0 = th * TH - T::P, w0 = tw * TW - T::P;
     __syncthreads();   // previous tile fully consumed (and wl visible)
 #pragma unroll
@@ -554,7 +592,8 @@ __global__ void __launch_bounds__(256) k_dwk_fwd_lds(lhn_view x, const float* __
         const int ph = i / T::WW, pw = i - ph * T::WW;
         const int ih = h0 + ph, iw = w0 + pw;
         const bool inb = ih >= 0 && ih < SH && iw >= 0 && iw < SW;
-        const f4 v = lhn_apply_xf(raw[it], xf) * gate;
+        f4 v = lhn_apply_xf(raw[it], xf) * gate;
+        if (NS > 1) v += lhn_apply_xf(raw2[it], xf2) * gate2;
         tile[i * 8 + c4] = inb ? v : (f4){0.f, 0.f, 0.f, 0.f};
       }
     }
@@ -823,8 +862,11 @@ static int dw3_grid(int ntile, int cgroups, int per_cu) {
   return g;
 }
 
-template <int K, int DIL>
-static void launch_dwk_fwd(const lhn_view* x, const float* w, const lhn_view* y, double* stats, lhn_bnfin fin, hipStream_t s, int ps = 1) {
+template <int K, int DIL, int NS = 1>
+static void launch_dwk_fwd(const lhn_view* x, const float* w, const lhn_view* y, double* stats, lhn_bnfin fin, hipStream_t s, int ps = 1,
+                           const DwExtra* exp = nullptr) {
+  DwExtra ex;
+  if (exp) ex = *exp; else ex.n = 0;
   constexpr int TH = 8, TW = 32, P = DIL * (K - 1) / 2;
   const int cg = x->C / 32;
   const int sh = (y->H + ps - 1) / ps, sw = (y->W + ps - 1) / ps;       // largest parity sub-lattice
@@ -832,8 +874,8 @@ static void launch_dwk_fwd(const lhn_view* x, const float* w, const lhn_view* y,
   const size_t lds = (size_t)((TH + 2 * P) * (TW + 2 * P) * 8 + 512 + K * K * 8) * 16;
   const int per_cu = lds > 80 * 1024 ? 1 : (lds > 52 * 1024 ? 2 : 3);
   static LhnKernelCfg cfg;
-  (void)lhn_kernel_cfg(cfg, &k_dwk_fwd_lds<K, DIL>, lds, 4, nullptr);
-  hipLaunchKernelGGL((k_dwk_fwd_lds<K, DIL>), dim3(dw3_grid(ntile, cg, per_cu * 2)), dim3(256), lds, s, *x, w, *y, stats, th, tw, cg, fin, ps);
+  (void)lhn_kernel_cfg(cfg, &k_dwk_fwd_lds<K, DIL, NS>, lds, 4, nullptr);
+  hipLaunchKernelGGL((k_dwk_fwd_lds<K, DIL, NS>), dim3(dw3_grid(ntile, cg, per_cu * 2)), dim3(256), lds, s, *x, w, *y, stats, th, tw, cg, fin, ps, ex);
 }
 template <int K, int DIL>
 static void launch_dwk_bwd(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx, int dx_acc,
@@ -851,7 +893,13 @@ static void launch_dwk_bwd(const lhn_view* x, const float* w, const lhn_view* y,
 
 // returns 1 if an LDS-tiled kernel was launched
 int lhn_dwk_fwd_lds(const lhn_view* x, const float* w, const lhn_view* y, double* stats, int k, int dil, lhn_bnfin fin,
-                    hipStream_t s) {
+                    hipStream_t s, const DwExtra* ex) {
+  if (ex && ex->n > 0) {     // two summed sources: 3x3, dilation 1 or 2 (parity sub-lattices) -- MSRB's second round
+    if (k == 3 && dil == 1) launch_dwk_fwd<3, 1, 2>(x, w, y, stats, fin, s, 1, ex);
+    else if (k == 3 && dil == 2 && y->W >= 16) launch_dwk_fwd<3, 1, 2>(x, w, y, stats, fin, s, 2, ex);
+    else return 0;
+    return 1;
+  }
   if (k == 3 && dil == 1) launch_dwk_fwd<3, 1>(x, w, y, stats, fin, s);
   else if (k == 3 && dil == 2 && y->W >= 16) launch_dwk_fwd<3, 1>(x, w, y, stats, fin, s, 2);    // parity sub-lattices
   else if (k == 3 && dil == 2) launch_dwk_fwd<3, 2>(x, w, y, stats, fin, s);
@@ -867,4 +915,15 @@ int lhn_dwk_bwd_lds(const lhn_view* x, const float* w, const lhn_view* y, const 
   else if (k == 7 && dil == 1) launch_dwk_bwd<7, 1>(x, w, y, gy, dx, dx_acc, dw, nrep, rep_stride, s);
   else return 0;
   return 1;
+}
+
+static int dw_fwd_extra(const lhn_view* x, const float* w, const lhn_view* y, double* stats, int k, int stride, int pad, int dil,
+                        lhn_bnfin fin, const lhn_view* extra, const float* coef, hipStream_t s) {
+  if (!(stride == 1 && pad == dil * (k - 1) / 2 && x->C % 32 == 0 && y->W >= 8)) return 0;
+  DwExtra ex;
+  ex.v = *extra;
+  ex.coef[0] = coef[0];
+  ex.coef[1] = coef[1];
+  ex.n = 1;
+  return lhn_dwk_fwd_lds(x, w, y, stats, k, dil, fin, s, &ex);
 }

@@ -43,11 +43,20 @@ __device__ __forceinline__ void pw_stage_w(float* Ws, int LDA, const float* __re
   }
 }
 
-template <int CIN, int NT>
-__global__ void __launch_bounds__(256, (CIN == 64 && NT == 2) || (CIN == 32 && NT == 4) ? 3 : (CIN == 64 && NT == 4) ? 2 : 1) k_pw_fwd(lhn_view x, const float* __restrict__ w, const float* __restrict__ bias,
+// Extra input sources: the consumed input is  sum_s coef[s] * value_s  (value = gate * act(BN(raw)) of source s; source 0 is
+// `x`).  This is how the residual sums of MSRB (litehourglass.py:41-49: out + ca(cat), then out + x) reach the 1x1 without
+// ever being written to HBM: summed on load.  All sources share x's geometry and channel range width.
+struct PwExtra {
+  lhn_view v[2];
+  float coef[3];
+  int n;             // number of EXTRA sources in v (0..2)
+};
+
+template <int CIN, int NT, int NS = 1>
+__global__ void __launch_bounds__(256, NS > 1 ? 1 : ((CIN == 64 && NT == 2) || (CIN == 32 && NT == 4) ? 3 : (CIN == 64 && NT == 4) ? 2 : 1)) k_pw_fwd(lhn_view x, const float* __restrict__ w, const float* __restrict__ bias,
                                                 lhn_view y, double* __restrict__ stats, int stride,
                                                 float* __restrict__ y_nchw, int cout, int M, int ntiles, lhn_bnfin fin,
-                                                PwGeom geo) {
+                                                PwGeom geo, PwExtra ex) {
   constexpr int LDA = CIN + 4;
   constexpr int PF = CIN / 8;   // float4 loads per thread per 128-pixel tile
   constexpr int C4 = CIN / 4;   // float4 per pixel row
@@ -66,6 +75,18 @@ __global__ void __launch_bounds__(256, (CIN == 64 && NT == 2) || (CIN == 32 && N
   const int cabs = x.coff + (kok ? 4 * c4 : 0);
   const Xf4 xf = lhn_load_xf(x, cabs);
   const int HoWo = y.H * y.W;
+  // extra sources (NS > 1): own buffer, table, gate, channel offset
+  int ecabs[NS > 1 ? NS - 1 : 1];
+  Xf4 exf[NS > 1 ? NS - 1 : 1];
+  f4 epre[NS > 1 ? NS - 1 : 1][PF];
+  if (NS > 1) {
+#pragma unroll
+    for (int e = 0; e < NS - 1; ++e)
+      if (e < ex.n) {
+        ecabs[e] = ex.v[e].coff + (kok ? 4 * c4 : 0);
+        exf[e] = lhn_load_xf(ex.v[e], ecabs[e]);
+      }
+  }
 
   f4 pre[PF];
   auto in_pix = [&](int m) __attribute__((always_inline)) -> int64_t {
@@ -80,6 +101,12 @@ __global__ void __launch_bounds__(256, (CIN == 64 && NT == 2) || (CIN == 32 && N
       const int m = tile * 128 + row0 + p * RP;
       pre[p] = (f4){0.f, 0.f, 0.f, 0.f};
       if (m < M && kok) pre[p] = *reinterpret_cast<const f4*>(x.data + in_pix(m) * x.cstride + cabs);
+      if (NS > 1) {
+#pragma unroll
+        for (int e = 0; e < NS - 1; ++e)
+          if (e < ex.n && m < M && kok)
+            epre[e][p] = *reinterpret_cast<const f4*>(ex.v[e].data + (int64_t)m * ex.v[e].cstride + ecabs[e]);
+      }
     }
   };
   auto commit = [&](int tile) __attribute__((always_inline)) {
@@ -90,6 +117,16 @@ __global__ void __launch_bounds__(256, (CIN == 64 && NT == 2) || (CIN == 32 && N
       if (m < M && kok) {
         v = lhn_apply_xf(pre[p], xf);
         if (x.gate) v *= *reinterpret_cast<const f4*>(x.gate + (int64_t)(m / HoWo) * x.cstride + cabs);
+        if (NS > 1) {
+          v *= ex.coef[0];
+#pragma unroll
+          for (int e = 0; e < NS - 1; ++e)
+            if (e < ex.n) {
+              f4 u = lhn_apply_xf(epre[e][p], exf[e]);
+              if (ex.v[e].gate) u *= *reinterpret_cast<const f4*>(ex.v[e].gate + (int64_t)(m / HoWo) * ex.v[e].cstride + ecabs[e]);
+              v += u * ex.coef[e + 1];
+            }
+        }
       }
       *reinterpret_cast<f4*>(As + row * LDA + 4 * c4) = v;
     }
@@ -195,9 +232,12 @@ __global__ void __launch_bounds__(256, (CIN == 64 && NT == 2) || (CIN == 32 && N
   }
 }
 
-template <int CIN, int NT>
+template <int CIN, int NT, int NS = 1>
 static int launch_pw_fwd(const lhn_view* x, const float* w, const float* bias, const lhn_view* y, double* stats,
-                         int stride, float* y_nchw, int cout, const lhn_bnfin* fin, const PwGeom& geo, hipStream_t s) {
+                         int stride, float* y_nchw, int cout, const lhn_bnfin* fin, const PwGeom& geo, hipStream_t s,
+                         const PwExtra* exp = nullptr) {
+  PwExtra ex;
+  if (exp) ex = *exp; else ex.n = 0;
   lhn_bnfin f;
   if (fin && stats) f = *fin; else f.counter = nullptr;
   const int M = y->N * y->H * y->W;
@@ -205,14 +245,14 @@ static int launch_pw_fwd(const lhn_view* x, const float* w, const float* bias, c
   const size_t lds = (size_t)((32 * NT + 128) * (CIN + 4)) * sizeof(float);
   static LhnKernelCfg cfg;
   int per_cu = 1;
-  if (!lhn_kernel_cfg(cfg, &k_pw_fwd<CIN, NT>, lds, 4, &per_cu)) {
+  if (!lhn_kernel_cfg(cfg, &k_pw_fwd<CIN, NT, NS>, lds, 4, &per_cu)) {
     lhn_set_error("lhn_conv_pw_fwd: cannot reserve %zu B of LDS", lds);
     return 2;
   }
   int grid = lhn_num_cus() * per_cu;
   if (grid > ntiles) grid = ntiles;
-  hipLaunchKernelGGL((k_pw_fwd<CIN, NT>), dim3(grid), dim3(256), lds, s, *x, w, bias, *y, stats, stride, y_nchw, cout, M,
-                     ntiles, f, geo);
+  hipLaunchKernelGGL((k_pw_fwd<CIN, NT, NS>), dim3(grid), dim3(256), lds, s, *x, w, bias, *y, stats, stride, y_nchw, cout, M,
+                     ntiles, f, geo, ex);
   return 0;
 }
 
@@ -221,9 +261,14 @@ static inline int pw_cin_tile(int c) { return c <= 16 ? 16 : c <= 32 ? 32 : c <=
 
 // one (input slice, output slice) launch
 static int pw_fwd_slice(const lhn_view* x, const float* w, const float* bias, const lhn_view* y, double* stats, int stride,
-                        float* y_nchw, int cout, const lhn_bnfin* fin, const PwGeom& geo, hipStream_t s) {
+                        float* y_nchw, int cout, const lhn_bnfin* fin, const PwGeom& geo, hipStream_t s, const PwExtra* ex = nullptr) {
   const int ci = pw_cin_tile(x->C), nt = (cout + 31) / 32 == 3 ? 4 : (cout + 31) / 32;
   int rc = -1;
+  if (ex && ex->n > 0) {      // summed-on-load sources: the square 1x1 of MSRB (litehourglass.py:30,49), C = 64 / 128
+    if (ci == 128 && nt == 4) rc = launch_pw_fwd<128, 4, 3>(x, w, bias, y, stats, stride, y_nchw, cout, fin, geo, s, ex);
+    else if (ci == 64 && nt == 2) rc = launch_pw_fwd<64, 2, 3>(x, w, bias, y, stats, stride, y_nchw, cout, fin, geo, s, ex);
+    return rc;
+  }
 #define PW_CASE(CI, NTV) \
   if (ci == CI && nt == NTV) rc = launch_pw_fwd<CI, NTV>(x, w, bias, y, stats, stride, y_nchw, cout, fin, geo, s);
   PW_CASE(32, 1) PW_CASE(32, 2) PW_CASE(32, 4) PW_CASE(64, 1) PW_CASE(64, 2) PW_CASE(64, 4) PW_CASE(128, 1)
@@ -255,6 +300,18 @@ extern "C" int lhn_conv_pw_fwd2(const lhn_view* x, const float* w, const float* 
   const int64_t bstride = (opts && opts->nchw_batch_stride > 0) ? opts->nchw_batch_stride : (int64_t)Cout * HoWo;
   hipStream_t s = (hipStream_t)stream;
   const bool single = Cin <= 128 && Cout <= 128;
+  PwExtra ex;
+  ex.n = 0;
+  if (opts && opts->n_extra > 0) {
+    LHN_CHECK_ARG(opts->n_extra <= 2 && opts->extra && single && stride == 1, "lhn_conv_pw_fwd: extra sources need stride 1 and <= 128 channels");
+    ex.n = opts->n_extra;
+    for (int e = 0; e < ex.n; ++e) {
+      const lhn_view* v = &opts->extra[e];
+      LHN_CHECK_ARG(lhn_view_ok(v) && v->C == Cin && v->N == x->N && v->H == x->H && v->W == x->W, "lhn_conv_pw_fwd: extra source %d geometry", e);
+      ex.v[e] = *v;
+    }
+    for (int e = 0; e < 3; ++e) ex.coef[e] = opts->coef[e];
+  }
   for (int co0 = 0; co0 < Cout; co0 += 128) {
     const int cc = Cout - co0 < 128 ? Cout - co0 : 128;
     for (int k0 = 0; k0 < Cin; k0 += 128) {
@@ -276,8 +333,8 @@ extern "C" int lhn_conv_pw_fwd2(const lhn_view* x, const float* w, const float* 
       g.nchw_bstride = bstride;
       const int rc = pw_fwd_slice(&xv, w + (int64_t)co0 * wcols + k0, (last && bias) ? bias + co0 : nullptr, &yv,
                                   (last && stats) ? stats + co0 : nullptr, stride, y_nchw ? y_nchw + (int64_t)co0 * HoWo : nullptr,
-                                  cc, single ? fin : nullptr, g, s);
-      LHN_CHECK_ARG(rc != -1, "lhn_conv_pw_fwd: unsupported channels Cin=%d Cout=%d", Cin, Cout);
+                                  cc, single ? fin : nullptr, g, s, ex.n ? &ex : nullptr);
+      LHN_CHECK_ARG(rc != -1, "lhn_conv_pw_fwd: unsupported channels Cin=%d Cout=%d (%d extra sources)", Cin, Cout, ex.n);
       if (rc) return rc;
     }
   }

@@ -74,6 +74,7 @@ __global__ void k_table_bias(float* __restrict__ table, int cs, int coff, int C,
 // dst = lrelu_{out_slope}( sum_i value_i(nearest-resampled to dst geometry) ), dst stored plain.
 struct EwSrcs {
   lhn_view v[3];
+  float coef[3];     // dst = act(sum_i coef[i] * value_i)
 };
 __device__ __forceinline__ int nearest_src(int d, int in, int out) {
   if (in == out) return d;
@@ -111,7 +112,7 @@ __global__ void __launch_bounds__(256) k_ew_fwd(EwSrcs S, int nsrc, lhn_view dst
       for (int k = 0; k < 3; ++k)
         if (k < nsrc) {
           const int ws = nearest_src(w, S.v[k].W, dst.W);
-          acc += lhn_apply_xf(*reinterpret_cast<const f4*>(base[k] + (size_t)ws * S.v[k].cstride), xf[k]) * gate[k];
+          acc += lhn_apply_xf(*reinterpret_cast<const f4*>(base[k] + (size_t)ws * S.v[k].cstride), xf[k]) * (gate[k] * S.coef[k]);
         }
       if (out_slope == LHN_SLOPE_SILU) {
         acc.x = lhn_silu(acc.x);
@@ -711,12 +712,16 @@ int lhn_table_bias(float* table, int cstride, int coff, int C, const float* bias
 }
 
 int lhn_ew_fwd(const lhn_view* srcs, int nsrc, const lhn_view* dst, float out_slope, void* stream) {
+  return lhn_ew_fwd2(srcs, nsrc, nullptr, dst, out_slope, stream);
+}
+int lhn_ew_fwd2(const lhn_view* srcs, int nsrc, const float* coef, const lhn_view* dst, float out_slope, void* stream) {
   LHN_CHECK_ARG(srcs && nsrc >= 1 && nsrc <= 3 && lhn_view_ok(dst), "lhn_ew_fwd: 1..3 sources, valid dst");
   EwSrcs S;
   memset(&S, 0, sizeof(S));
   for (int i = 0; i < nsrc; ++i) {
     LHN_CHECK_ARG(lhn_view_ok(&srcs[i]) && srcs[i].C == dst->C && srcs[i].N == dst->N, "lhn_ew_fwd: source %d mismatch", i);
     S.v[i] = srcs[i];
+    S.coef[i] = coef ? coef[i] : 1.f;
   }
   LHN_CHECK_ARG(pow2i(dst->C / 4) && dst->C <= 1024, "lhn_ew_fwd: C=%d", dst->C);
   hipLaunchKernelGGL(k_ew_fwd, dim3(grid_cap((int64_t)dst->N * dst->H, 8)), dim3(256), 0, (hipStream_t)stream, S, nsrc, *dst, out_slope);

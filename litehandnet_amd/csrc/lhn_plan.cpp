@@ -3,6 +3,7 @@
 // this file only resolves offsets into the workspace arena / parameter array and calls the launchers.
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 #include <vector>
 #include "lhn_common.h"
 
@@ -204,7 +205,15 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
         // i[2], i[3] = real rows / columns of the weight tensor when the views are padded to a multiple of 4 (0 = the views');
         // i[4], i[5] = stack index / number of stacks of an NCHW output [N, S, K, H, W] (hourglassnet.py:136)
         lhn_pw_opts po;
-        po.w_rows = o.i[2]; po.w_cols = o.i[3]; po.nchw_batch_stride = 0;
+        memset(&po, 0, sizeof(po));
+        po.w_rows = o.i[2]; po.w_cols = o.i[3];
+        lhn_view extra[2];
+        if (o.i[6] > 1) {      // i[6] sources summed on load: in_buf[1..], coefficients f[4..6]
+          po.n_extra = o.i[6] - 1;
+          for (int e = 0; e < po.n_extra; ++e) extra[e] = mkview(P, ws, o.in_buf[e + 1], o.in_coff[e + 1], o.in_C[e + 1]);
+          po.extra = extra;
+          for (int e = 0; e < 3; ++e) po.coef[e] = o.f[4 + e];
+        }
         if (nchw && o.i[5] > 1) {
           const int64_t khw = (int64_t)o.out_C * y.H * y.W;
           nchw += (int64_t)o.i[4] * khw;
@@ -225,9 +234,12 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
           fin = mkfin(P, ws, o, params);
           fin.count *= cscale;
         }
-        if (h0) rc = lhn_conv_dw_fwd(&x, prm<const float>(params, o.p[0]), &y,
-                             (training && o.ws[0] >= 0) ? reinterpret_cast<double*>(at(ws, o.ws[0])) : nullptr, o.i[0], o.i[1], o.i[2], o.i[3],
-                             (bn && training && fuse_finalize() && whole) ? &fin : nullptr, stream);
+        lhn_view extra;
+        const float coef2[2] = {o.f[4], o.f[5]};
+        if (o.i[6] > 1) extra = mkview(P, ws, o.in_buf[1], o.in_coff[1], o.in_C[1]);      // second source summed on load
+        if (h0) rc = lhn_conv_dw_fwd2(&x, prm<const float>(params, o.p[0]), &y,
+                              (training && o.ws[0] >= 0) ? reinterpret_cast<double*>(at(ws, o.ws[0])) : nullptr, o.i[0], o.i[1], o.i[2], o.i[3],
+                              (bn && training && fuse_finalize() && whole) ? &fin : nullptr, o.i[6] > 1 ? &extra : nullptr, coef2, stream);
         if (!rc && bn && h1 && !skip_tables && !(training && fuse_finalize() && whole)) rc = sep_finalize(fin, reinterpret_cast<const double*>(at(ws, o.ws[0])), training, stream);
         break;
       }
@@ -263,7 +275,8 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
         lhn_view srcs[3];
         for (int k = 0; k < o.i[0]; ++k) srcs[k] = mkview(P, ws, o.in_buf[k], o.in_coff[k], o.in_C[k]);
         lhn_view d = mkview(P, ws, o.out_buf, o.out_coff, o.out_C);
-        rc = lhn_ew_fwd(srcs, o.i[0], &d, o.f[0], stream);
+        const float coef[3] = {o.f[4], o.f[5], o.f[6]};
+        rc = lhn_ew_fwd2(srcs, o.i[0], o.i[1] ? coef : nullptr, &d, o.f[0], stream);      // i[1]: coefficients given
         break;
       }
       case OP_MAXPOOL: {
@@ -338,7 +351,8 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
         }
         float* dx = o.i[2] ? reinterpret_cast<float*>(at(ws, P->bufs[o.in_buf[0]].grad_off)) : nullptr;
         lhn_pw_opts po;     // i[3], i[4] = weight rows / columns; i[6], i[7] = stack index / stacks (see OP_PW)
-        po.w_rows = o.i[3]; po.w_cols = o.i[4]; po.nchw_batch_stride = 0;
+        memset(&po, 0, sizeof(po));
+        po.w_rows = o.i[3]; po.w_cols = o.i[4];
         if (nchw && o.i[7] > 1) {
           const int64_t khw = (int64_t)o.out_C * y.H * y.W;
           nchw += (int64_t)o.i[6] * khw;

@@ -109,7 +109,7 @@ class MSAB(PlanModule):
                 t = branch[0].emit(pb, m)
                 branch[1].emit(pb, t, out=pb.slice(cat, j * half, half))
             m = cat
-        y = self.conv2.emit(pb, pb.ew([m, x]))
+        y = self.conv2.emit(pb, pb.ew([m, x], lazy=True))      # `m + x` is summed on load by the 1x1 (never written in forward)
         if isinstance(self.ca, (ChannelAttension, SEBlock)):
             y = self.ca.emit(pb, y)
         return y

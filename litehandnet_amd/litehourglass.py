@@ -36,7 +36,9 @@ class MSRB(PlanModule):
             b2.emit(pb, pb.slice(acc, h, h), out=pb.slice(lr, h, h))
             if isinstance(ca, (ChannelAttension, SEBlock)):
                 lr = ca.emit(pb, lr)
-            acc = pb.ew([acc, lr] + ([x] if r == 1 else []))     # the last add also folds `out + x`
+            # `out + ca(cat)` (and `out + x` on the last round) are never written in forward: the next round's depthwise
+            # kernels and the closing 1x1 add the operands while loading them
+            acc = pb.ew([acc, lr] + ([x] if r == 1 else []), lazy=True)
         return self.conv.emit(pb, acc, out=out)
 
 

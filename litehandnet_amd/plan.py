@@ -77,6 +77,7 @@ class _BufRec:
     gate: bool = False
     coef: bool = False
     dpool: bool = False
+    lazy: object = None      # the EW record of a sum that is taken ON LOAD by its consumers (never written in forward)
     off: dict = field(default_factory=dict)
 
 
@@ -156,6 +157,7 @@ class PlanBuilder:
         """True when x is the whole of an ungated buffer that is not the block's input (a gate attaches to a buffer)."""
         if isinstance(x, TCat):
             return False
+        self.real(x)
         b = self.bufs[x.buf]
         return x.coff == 0 and x.C == b.C and not b.gate and not (self.in_ref is not None and x.buf == self.in_ref.buf)
 
@@ -208,6 +210,14 @@ class PlanBuilder:
                 assert cpad == cout or bn is None, "a padded output has no BatchNorm"
         elif kind == KXK:
             assert cin_g == x.C, (cin_g, x.C)
+        xs = self.lazy_sources(x)
+        if xs is not None:
+            ok = (kind == DW and len(xs) <= 2 and kh == 3 and s == 1 and p == d and d in (1, 2) and x.C % 32 == 0 and x.W >= (8 if d == 1 else 16)
+                  and conv.weight is not None) or \
+                 (kind == PW and s == 1 and not nchw_out and x.C == cout and x.C in self.LAZY_PW and cin_g == x.C)
+            if not ok:
+                self.real(x)
+                xs = None
         if nchw_out:
             assert kind == PW and bn is None and out is None
             out = TRef(-2, 0, cout, Ho, Wo)
@@ -216,9 +226,11 @@ class PlanBuilder:
         elif out is None:
             out = self.new(Ho, Wo, cpad)
         assert (out.H, out.W, out.C) == (Ho, Wo, cpad), (out, Ho, Wo, cpad)
+        if out.buf >= 0:
+            self.real(out)
         rec = dict(op=kind, x=x, out=out, conv=conv, bn=bn, slope=float(slope), k=kh, stride=s, pad=p, dil=d,
                    nchw=nchw_out, stack=(0, 1) if stack is None else (int(stack[0]), int(stack[1])),
-                   wrc=(cout if cpad != cout else 0, cin_g if cin_g != x.C else 0))
+                   wrc=(cout if cpad != cout else 0, cin_g if cin_g != x.C else 0), xs=xs)
         if kind == KXK:
             rec["wt"] = self._ws("misc", 9 * cout * cin_g * 4)      # tap-major weight scratch (lhn_conv_kxk_*: wt_scratch)
         if bn is not None:
@@ -244,7 +256,7 @@ class PlanBuilder:
         """BatchNorm applied straight to a tensor (RepBlock.rbr_identity, repblocks.py:113-114): lowered as an
         identity depthwise 1x1 (weights = NULL = ones), which copies the consumed value, takes the batch
         statistics in its epilogue and leaves the normalisation pending like any other conv+BN."""
-        x = self.single(x)
+        x = self.real(self.single(x))
         out = self.new(x.H, x.W, x.C)
         rec = dict(op=DW, x=x, out=out, conv=_IDENT, bn=bn, slope=float(slope), k=1, stride=1, pad=0, dil=1, nchw=False)
         rec["stats"] = self._ws("zf", STAT_REPLICAS * 2 * x.C * 8)
@@ -257,9 +269,53 @@ class PlanBuilder:
         self.recs.append(rec)
         return out
 
-    def ew(self, srcs, out_slope=1.0, out=None):
-        """out = lrelu_{out_slope}(sum of sources); smaller sources are nearest-upsampled.  Plain output."""
+    # Residual sums whose readers can add the operands while loading them (the 3x3 depthwise LDS kernel: 2 operands, the
+    # square 64/128-channel 1x1: 3) are "lazy": the combine is recorded but not launched in forward; the backward pass
+    # materialises it once (weight gradients need the value) and distributes its gradient like any other combine.
+    LAZY_PW = (64, 128)
+
+    def lazy_sources(self, x):
+        """[(TRef, coef)] behind a lazy view x (same channel slice of every operand), or None."""
+        if isinstance(x, TCat) or x.buf < 0:
+            return None
+        rec = self.bufs[x.buf].lazy
+        if rec is None:
+            return None
+        return [(TRef(t.buf, t.coff + x.coff, x.C, t.H, t.W), c) for t, c in rec["flat"]]
+
+    def real(self, x):
+        """x as something every kernel can read: a lazy sum is materialised where it was recorded."""
+        for p in _parts(x):
+            if p.buf >= 0 and self.bufs[p.buf].lazy is not None:
+                self.bufs[p.buf].lazy["lazy"] = False
+                self.bufs[p.buf].lazy = None
+        return x
+
+    def ew(self, srcs, out_slope=1.0, out=None, lazy=False):
+        """out = lrelu_{out_slope}(sum of sources); smaller sources are nearest-upsampled.  Plain output.
+        lazy=True (plain same-size sum into a fresh buffer): see lazy_sources()."""
         assert 1 <= len(srcs) <= 3
+        if lazy and out is None and out_slope == 1.0 and not any(isinstance(t, TCat) for t in srcs) and \
+                all((t.H, t.W, t.C) == (srcs[0].H, srcs[0].W, srcs[0].C) and t.buf >= 0 for t in srcs):
+            flat = []
+            for t in srcs:
+                inner = self.lazy_sources(t)
+                for u, c in (inner if inner is not None else [(t, 1.0)]):
+                    for j, (v, cv) in enumerate(flat):
+                        if (v.buf, v.coff, v.C) == (u.buf, u.coff, u.C):
+                            flat[j] = (v, cv + c)
+                            break
+                    else:
+                        flat.append((u, c))
+            if len(flat) <= 3:
+                out = self.new(srcs[0].H, srcs[0].W, srcs[0].C)
+                rec = dict(op=EW, srcs=list(srcs), out=out, slope=1.0, lazy=True, flat=flat)
+                self.bufs[out.buf].lazy = rec
+                self.recs.append(rec)
+                return out
+        srcs = [self.real(t) for t in srcs]
+        if out is not None:
+            self.real(out)
         if out_slope == SLOPE_SILU and len(srcs) > 1:
             # the SiLU backward recomputes the pre-activation from its (single, same-size) source: sum first
             return self.ew([self.ew(srcs, 1.0)], SLOPE_SILU, out)
@@ -275,6 +331,7 @@ class PlanBuilder:
         return out
 
     def maxpool(self, x, out=None):
+        x = self.real(x)
         Ho, Wo = (x.H + 1) // 2, (x.W + 1) // 2
         if out is None:
             out = self.new(Ho, Wo, x.C)
@@ -287,6 +344,7 @@ class PlanBuilder:
 
     def avgpool(self, x, OH, OW):
         """adaptive_avg_pool2d of the consumed value -> a plain [N,OH,OW,C] buffer (one per part of a multi-part x)."""
+        x = self.real(x)
         if isinstance(x, TCat):
             return TCat([self.avgpool(p, OH, OW) for p in x.parts])
         out = self.new(OH, OW, x.C)
@@ -374,7 +432,8 @@ class PlanBuilder:
                 base += _al(N * 25 * b.C * 4)      # LHN_DPOOL_SLOTS: 5 x 5 bin-overlap segments
         for b in self.bufs:
             b.off["data"] = base
-            base += _al(N * b.H * b.W * b.C * 4)
+            if b.lazy is None or self.with_backward:      # a lazy sum is only ever written by the backward pass
+                base += _al(N * b.H * b.W * b.C * 4)
         self.act_bytes = base
         if self.with_backward:
             for b in self.bufs:
@@ -403,9 +462,19 @@ class PlanBuilder:
             o.ws[k] = ws[k] if k < len(ws) else -1
         for k in range(8):
             o.i[k] = i[k] if k < len(i) else 0
-        for k in range(4):
+        for k in range(8):
             o.f[k] = f[k] if k < len(f) else 0.0
         return o
+
+    def _xs(self, r):
+        """(input views, number of sources, coefficient slots f[4..6]) of a convolution record: the operands of a lazy sum
+        when the input still is one, else the input itself."""
+        x = r["x"]
+        if r.get("xs") is not None and x.buf >= 0 and self.bufs[x.buf].lazy is not None:
+            views = [t for t, _ in r["xs"]]
+            coefs = [c for _, c in r["xs"]]
+            return views, len(views), coefs + [0.0] * (3 - len(coefs))
+        return [x], 1, [1.0, 0.0, 0.0]
 
     def _grad_mode(self, written, t):
         """1 = store, 2 = accumulate for a write of d(value) into view t; updates the tracker."""
@@ -455,15 +524,20 @@ class PlanBuilder:
                     fwd.append(mk(STEM, out=out, p=(pw, cb) + pbn, ws=wsl, i=(r["k"], r["stride"], r["pad"], x.H, x.W), f=fl))
                 elif k == PW:
                     o = TRef(-1, 0, out.C, out.H, out.W) if r["nchw"] else out
-                    fwd.append(mk(PW, ins=(x,), out=o, p=(pw, self._p(conv.bias)) + pbn, ws=wsl,
-                                  i=(r["stride"], 1 if r["nchw"] else 0, r["wrc"][0], r["wrc"][1], r["stack"][0], r["stack"][1]), f=fl))
+                    xv, nx, cf = self._xs(r)
+                    fwd.append(mk(PW, ins=xv, out=o, p=(pw, self._p(conv.bias)) + pbn, ws=wsl,
+                                  i=(r["stride"], 1 if r["nchw"] else 0, r["wrc"][0], r["wrc"][1], r["stack"][0], r["stack"][1], nx),
+                                  f=(tuple(fl) + (0.0,) * 4)[:4] + tuple(cf)))
                 elif k == DW:
-                    fwd.append(mk(DW, ins=(x,), out=out, p=(pw, cb) + pbn, ws=wsl, i=(r["k"], r["stride"], r["pad"], r["dil"]), f=fl))
+                    xv, nx, cf = self._xs(r)
+                    fwd.append(mk(DW, ins=xv, out=out, p=(pw, cb) + pbn, ws=wsl, i=(r["k"], r["stride"], r["pad"], r["dil"], 0, 0, nx),
+                                  f=(tuple(fl) + (0.0,) * 4)[:4] + tuple(cf)))
                 else:
                     fwd.append(mk(KXK, ins=(x,), out=out, p=(pw, cb) + pbn, ws=(tuple(wsl) + (-1, -1, -1))[:3] + (self._abs(r["wt"]),),
                                   i=(r["stride"],), f=fl))
             elif k == EW:
-                fwd.append(mk(EW, ins=r["srcs"], out=r["out"], i=(len(r["srcs"]),), f=(r["slope"],)))
+                if not r.get("lazy"):
+                    fwd.append(mk(EW, ins=r["srcs"], out=r["out"], i=(len(r["srcs"]),), f=(r["slope"],)))
             elif k == MAXPOOL:
                 fwd.append(mk(MAXPOOL, ins=(r["x"],), out=r["out"]))
             elif k == AVGPOOL:
@@ -541,12 +615,20 @@ class PlanBuilder:
                     tb.off["grad"] = ob.off["grad"]
                     aliased.add(t.buf)
             self.grad_aliases = len(aliased)
+            materialised = set()
             for r in reversed(self.recs):
                 k = r["op"]
                 if k in (STEM, PW, DW, KXK):
                     conv, bn, x, out = r["conv"], r["bn"], r["x"], r["out"]
                     pw = self._p(conv.weight)
                     use_coef = 1 if bn is not None else 0
+                    lz = self.bufs[x.buf].lazy if x.buf >= 0 else None
+                    if lz is not None and x.buf not in materialised:
+                        # the weight gradient needs the summed input: written once per backward, whole buffer
+                        materialised.add(x.buf)
+                        fl = lz["flat"]
+                        body.append(mk(EW, ins=[t for t, _ in fl], out=lz["out"], i=(len(fl), 1),
+                                       f=(1.0, 0.0, 0.0, 0.0) + tuple(c for _, c in fl)))
                     if bn is not None:
                         body.append(mk(BN_BWD, out=out, p=(self._p(bn.weight), self._p(bn.weight), self._p(bn.bias)),
                                        ws=(self._abs(r["sums"]), self._abs(r["save"]), self._abs(r["bcnt"]))))

@@ -17,8 +17,12 @@ for r in pb.recs:
     k = r["op"]
     if k in (STEM, PW, DW, KXK):
         x, o = r["x"], r["out"]
-        mb = N * 4 * (x.H * x.W * x.C + o.H * o.W * o.C) / 1e6
+        nsrc = pb._xs(r)[1] if k in (PW, DW) else 1
+        mb = N * 4 * (nsrc * x.H * x.W * x.C + o.H * o.W * o.C) / 1e6
         print(f"{names[k]:8s} in b{x.buf}[{x.coff}:{x.coff + x.C}] {x.H}x{x.W} -> b{o.buf}[{o.coff}:{o.coff + o.C}] {o.H}x{o.W} k{r['k']} s{r['stride']} d{r['dil']} bn={r['bn'] is not None} slope={r['slope']} {mb:.1f}MB")
+    elif k == EW and r.get("lazy"):
+        print(f"{'ew(lazy)':8s} " + " + ".join(f"{c:g}*b{t.buf}[{t.coff}:{t.coff + t.C}]" for t, c in r["flat"]) + f" -> b{r['out'].buf} (summed on load)")
+        continue
     elif k == EW:
         o = r["out"]
         mb = N * 4 * o.H * o.W * o.C * (1 + len(r["srcs"])) / 1e6

@@ -479,21 +479,29 @@ def test_model_224_input(dev, variant):
 def test_sync_batchnorm_two_emulated_ranks(dev, variant):
     """cfg.TRAIN.syncBN (train/spawn_dist.py:37-38): two replicas, each with half of a batch of 8, run in lockstep on one
     GPU (two host threads; the all-reduce of every statistics buffer is emulated by summing the two replicas' buffers).
-    SyncBatchNorm over the halves must reproduce plain BatchNorm over the whole batch: outputs, running statistics, and
-    the SUM of the two ranks' parameter gradients (DDP would average them)."""
+    SyncBatchNorm over the halves must equal plain BatchNorm over the WHOLE batch as computed by the float64 ORACLE (not
+    by this library): outputs, running statistics, and the SUM of the two ranks' parameter gradients (DDP would average
+    them).  Yardstick: the oracle's own fp32 CPU run of the whole batch."""
     import threading
     from litehandnet_amd import get_model
     cfg = litehandnet_cfg(variant)
     cfg.MODEL["ca_dropout"] = 0.0
-    full = get_model(cfg)
-    sd = synth.synth_state_dict(full, 17)
-    full.load_state_dict(sd)
-    full.to(dev).train()
-    x = synth.synth_images(8, 64, 5).to(dev)
-    g = torch.from_numpy(np.random.Generator(np.random.PCG64(9)).standard_normal((8, 21, 16, 16)).astype(np.float32)).to(dev)
-    yf = full(x)
-    yf.backward(g)
-    gf = {k: p.grad.clone() for k, p in full.named_parameters()}
+    ref = torch_ref.get_model(cfg, p_drop=0.0)
+    sd = synth.synth_state_dict(ref, 17)
+    ref.load_state_dict(sd)
+    ref.train()
+    x = synth.synth_images(8, 64, 5)
+    g = torch.from_numpy(np.random.Generator(np.random.PCG64(9)).standard_normal((8, 21, 16, 16)).astype(np.float32))
+    ref32 = copy.deepcopy(ref)
+    y32 = ref32(x)
+    y32.backward(g)
+    ref = ref.double()
+    yf = ref(x.double())
+    yf.backward(g.double())
+    gf = {k: p.grad.clone() for k, p in ref.named_parameters()}
+    g32 = {k: p.grad.clone() for k, p in ref32.named_parameters()}
+    full = ref
+    x, g = x.to(dev), g.to(dev)
 
     world = 2
     reps = []
@@ -536,16 +544,17 @@ def test_sync_batchnorm_two_emulated_ranks(dev, variant):
         t.join(timeout=240)
     assert not errors, errors
     y2 = torch.cat(outs)
-    assert _rel(y2, yf) < 2e-4, _rel(y2, yf)
+    assert _rel(y2, yf) < max(FWD_TOL, 3 * _rel(y32, yf)), (_rel(y2, yf), _rel(y32, yf))
     pa, pb2 = dict(reps[0].named_parameters()), dict(reps[1].named_parameters())
     floor = 1e-3 * max(float(v.double().norm()) for v in gf.values())
+    e32s = {k: float((g32[k].double() - v).norm() / (v.norm() + floor)) for k, v in gf.items()}
     for k, v in gf.items():
-        tot = pa[k].grad.double() + pb2[k].grad.double()
-        e = float((tot - v.double()).norm() / (v.double().norm() + floor))
-        assert e < 2e-3, (k, e)
+        tot = pa[k].grad.cpu().double() + pb2[k].grad.cpu().double()
+        e = float((tot - v).norm() / (v.norm() + floor))
+        assert e < max(GRAD_TOL, 3 * e32s[k], 1.5 * max(e32s.values())), (k, e, e32s[k])
     for (k, a), (_, b) in zip(reps[0].state_dict().items(), full.state_dict().items()):
         if k.endswith("running_mean") or k.endswith("running_var"):
-            assert torch.allclose(a, b, rtol=1e-4, atol=1e-6), k
+            assert torch.allclose(a.cpu().double(), b, rtol=1e-4, atol=1e-6), k
 
 
 # ---------------------------------------------------------------- squeeze-and-excitation gates ('se')

@@ -130,3 +130,32 @@ def test_two_part_pass_through():
     assert sum(1 for r in pb.recs if r["op"] == MAXPOOL) == 1 + 2 * 3     # stem pool + three two-part encoder pools
     pb.finalize()
     assert not pb._needs_zero_grad
+
+
+def test_lazy_sums_are_summed_on_load():
+    """MSRB's residual sums (litehourglass.py:41-49) and MSAB's `m + x` (liteHandNet.py:164) are not launched in forward:
+    their readers list the operands (2 for the depthwise 3x3, 3 with a doubled coefficient for the closing 1x1); the
+    backward list materialises each of them exactly once before the first reader's backward op."""
+    from litehandnet_amd.plan import DW, EW, PW
+    _, pb, _ = _build("B", backward=True)
+    lazy = [r for r in pb.recs if r["op"] == EW and r.get("lazy")]
+    assert len(lazy) == 4                                           # 2 MSRBs x 2 rounds
+    cb, cf, cbw, nf, nb = pb.finalize()
+    fwd = [cf[i] for i in range(nf)]
+    assert sum(1 for o in fwd if o.kind == EW) == sum(1 for r in pb.recs if r["op"] == EW and not r.get("lazy"))
+    two = [o for o in fwd if o.kind == DW and o.i[6] == 2]
+    three = [o for o in fwd if o.kind == PW and o.i[6] == 3]
+    assert len(two) == 4 and len(three) == 2
+    for o in three:
+        assert sorted(o.f[4:7]) == [1.0, 1.0, 2.0]                  # out + ca(cat2) + x with out = x + ca(cat1)
+    bwd = [cbw[i] for i in range(nb)]
+    mats = [o for o in bwd if o.kind == EW]
+    assert len(mats) == 4 and all(o.i[1] == 1 for o in mats)
+    # inference plans do not even allocate the sums
+    _, pf, _ = _build("B", backward=False)
+    pf.finalize()
+    lz = [b for b in pf.bufs if b.lazy is not None]
+    assert len(lz) == 4 and len({b.off["data"] for b in lz} | {pf.act_bytes}) <= 5
+    # variant A: the sum in front of MSAB's closing 1x1
+    _, pa, _ = _build("A", backward=False)
+    assert sum(1 for r in pa.recs if r["op"] == EW and r.get("lazy")) == 2

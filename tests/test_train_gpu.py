@@ -219,7 +219,7 @@ def _dp_worker(rank, world, port, outdir):
 
 def test_two_rank_syncbn_data_parallel(dev, tmp_path):
     """Two real processes (gloo, both on cuda:0), cfg.TRAIN.syncBN=True, half a batch each: heatmaps, all-reduced flat
-    gradient and running statistics equal ONE process running plain BatchNorm over the whole batch."""
+    gradient and running statistics equal plain BatchNorm over the whole batch as computed by the float64 oracle on the CPU."""
     import socket
 
     import torch.multiprocessing as mp
@@ -231,37 +231,42 @@ def test_two_rank_syncbn_data_parallel(dev, tmp_path):
     port = s.getsockname()[1]
     s.close()
     mp.spawn(_dp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    # arbiter: the float64 ORACLE on the whole batch with plain BatchNorm (not this library); yardstick: its fp32 CPU run
     cfg = litehandnet_cfg("B")
     cfg.MODEL["ca_dropout"] = 0.0
-    model = get_model(cfg)
-    model.load_state_dict(synth.synth_state_dict(torch_ref.get_model(cfg, p_drop=0.0), 80))
-    model.to(dev).train()
-    eng = Engine(model)
-    eng.grads_via_autograd = False
-    model.__dict__["_engine"] = eng
-    x = synth.synth_images(8, 64, 81).to(dev)
-    g = torch.from_numpy(np.random.Generator(np.random.PCG64(82)).standard_normal((8, 21, 16, 16)).astype(np.float32)).to(dev)
-    y = model(x)
-    ((y * g).sum() / 8).backward()
-    ref_y, ref_g = y.detach().cpu().numpy(), eng.flat_grads.cpu().numpy()
-    sd = model.state_dict()
+    ref = torch_ref.get_model(cfg, p_drop=0.0)
+    ref.load_state_dict(synth.synth_state_dict(ref, 80))
+    ref.train()
+    x = synth.synth_images(8, 64, 81)
+    g = torch.from_numpy(np.random.Generator(np.random.PCG64(82)).standard_normal((8, 21, 16, 16)).astype(np.float32))
+    import copy
+    ref32 = copy.deepcopy(ref)
+    y32 = ref32(x)
+    ((y32 * g).sum() / 8).backward()
+    ref = ref.double()
+    y = ref(x.double())
+    ((y * g.double()).sum() / 8).backward()
+    ref_y = y.detach().numpy()
+    sd = ref.state_dict()
     k = sorted(k for k in sd if k.endswith("running_var"))[3]
     r = [np.load(os.path.join(str(tmp_path), f"r{i}.npz")) for i in range(2)]
     ys = np.concatenate([r[0]["y"], r[1]["y"]])
-    assert np.abs(ys - ref_y).max() <= 2e-4 * np.abs(ref_y).max()
+    e32y = np.abs(y32.detach().numpy() - ref_y).max() / np.abs(ref_y).max()
+    assert np.abs(ys - ref_y).max() <= max(1e-4, 3 * e32y) * np.abs(ref_y).max()
     assert np.array_equal(r[0]["grads"], r[1]["grads"])                  # every rank holds the same reduced gradient
-    errs, off = {}, 0
-    for kk, p in model.named_parameters():                              # flat layout: tensors padded to 4 floats
-        a, b = r[0]["grads"][off:off + p.numel()], ref_g[off:off + p.numel()]
-        errs[kk] = float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-3 * np.linalg.norm(ref_g) / 20))
+    p32 = dict(ref32.named_parameters())
+    gnorm = float(sum(float(p.grad.norm()) ** 2 for p in ref.parameters()) ** 0.5)
+    errs, e32s, off = {}, {}, 0
+    for kk, p in ref.named_parameters():                                # flat layout: tensors padded to 4 floats
+        a, b = r[0]["grads"][off:off + p.numel()].astype(np.float64), p.grad.numpy().reshape(-1)
+        den = np.linalg.norm(b) + 1e-3 * gnorm / 20
+        errs[kk] = float(np.linalg.norm(a - b) / den)
+        e32s[kk] = float(np.linalg.norm(p32[kk].grad.numpy().reshape(-1) - b) / den)
         off += (p.numel() + 3) // 4 * 4
-    worst = sorted(errs.items(), key=lambda t: -t[1])[:5]
-    # N = 8 with a BatchNorm over 8 values inside every attention block: fp32 summation-order differences between the
-    # split and the whole batch reach a few 1e-3 of a gradient's norm (measured 2.0e-3 overall, 3.5e-3 worst tensor; a
-    # wrong count / scale anywhere in the exchange would show as tens of percent)
-    assert max(errs.values()) < 2e-2 and np.linalg.norm(r[0]["grads"] - ref_g) <= 1e-2 * np.linalg.norm(ref_g), (
-        float(np.linalg.norm(r[0]["grads"] - ref_g) / np.linalg.norm(ref_g)), worst)
-    assert np.allclose(r[0]["rv"], sd[k].cpu().numpy(), rtol=1e-4, atol=1e-6)
+    worst32 = max(e32s.values())
+    bad = {kk: (e, e32s[kk]) for kk, e in errs.items() if e >= max(2e-3, 3 * e32s[kk], 1.5 * worst32)}
+    assert not bad, sorted(bad.items(), key=lambda t: -t[1][0])[:5]
+    assert np.allclose(r[0]["rv"], sd[k].numpy(), rtol=1e-4, atol=1e-6)
     assert np.array_equal(r[0]["rv"], r[1]["rv"])
 
 
