@@ -127,6 +127,28 @@ class Trainer:
         else:
             self.opt = torch.optim.SGD([self.fp.leaf], lr=lr, momentum=0.9)
         self.loss_sum = torch.zeros((), device=self.fp.flat.device)
+        # the gradient exchange runs on its own stream, ordered by events: it starts when the last weight-gradient kernel
+        # (lhn_reduce_replicas) has landed and the optimizer step waits for it; whatever the compute stream still has queued
+        # (loss bookkeeping, the next step's input staging) overlaps with the collective
+        self.comm_stream = torch.cuda.Stream(device=self.fp.flat.device) if self._distributed() else None
+
+    @staticmethod
+    def _distributed():
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+    def _exchange_begin(self, g):
+        """Start the all-reduce of the flat gradient on the communication stream; returns the event that marks its end."""
+        if self.comm_stream is None:
+            return None
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream())
+        with torch.cuda.stream(self.comm_stream):
+            self.comm_stream.wait_event(ready)
+            allreduce_mean_(g)
+            done = torch.cuda.Event()
+            done.record(self.comm_stream)
+        g.record_stream(self.comm_stream)
+        return done
 
     def step(self, img, meta):
         out = self.model(img)
@@ -134,9 +156,11 @@ class Trainer:
         self.opt.zero_grad(set_to_none=True)
         loss.backward()
         g = self.engine.flat_grads
-        allreduce_mean_(g)
+        done = self._exchange_begin(g)
+        self.loss_sum += loss.detach()                 # queued behind the backward, runs while the collective is in flight
+        if done is not None:
+            torch.cuda.current_stream().wait_event(done)
         self.fp.leaf.grad = g
         self.opt.step()
         invalidate_tables()            # the fused step writes the flat leaf: per-parameter version counters do not move
-        self.loss_sum += loss.detach()
         return loss

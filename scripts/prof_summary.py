@@ -1,5 +1,6 @@
 """Summarise rocprofv3 CSV output.  Usage:
   prof_summary.py stats <dir> <steps> <out.md> <title>        (--kernel-trace --stats: *_kernel_stats.csv)
+  prof_summary.py steady <dir> <out.md> <title>               (--kernel-trace: *_kernel_trace.csv; steady-state per-step table)
   prof_summary.py pmc <dir> <passes> <counter>               (--pmc X --kernel-trace: *_counter_collection.csv) -> prints sum/pass
 """
 import csv, glob, os, sys
@@ -10,6 +11,38 @@ def find(d, suffix):
     if not f:
         sys.exit(f"no *{suffix} under {d}")
     return f[-1]
+
+
+def steady(d, out, title, marker="k_stem_fwd"):
+    """Per-step kernel table from the kernel TRACE, steady state only: the trace is cut at every launch of `marker` (one per
+    forward); the first step (module upload = hundreds of __amd_rocclr_copyBuffer launches, kernel attribute setup, plan
+    build) is dropped, the rest averaged.  Replaces `stats` for anything quoted per step."""
+    rows = list(csv.DictReader(open(find(d, "kernel_trace.csv"))))
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    cuts = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith(marker)]
+    if len(cuts) < 3:
+        sys.exit(f"need >= 3 steps, found {len(cuts)} {marker} launches")
+    # a step begins a few setup launches (memset / dropout masks) before its stem: attribute those to the step they precede
+    body = rows[cuts[1]:cuts[-1]]
+    steps = len(cuts) - 2
+    by = {}
+    for r in body:
+        k = r["Kernel_Name"][:70]
+        t = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        a = by.setdefault(k, [0, 0])
+        a[0] += 1
+        a[1] += t
+    tot = sum(v[1] for v in by.values())
+    span = (int(body[-1]["End_Timestamp"]) - int(body[0]["Start_Timestamp"])) / steps
+    with open(out, "w") as f:
+        f.write(f"# {title}\n\nsteady state, {steps} steps (first step dropped): kernel time {tot / steps / 1e6:.3f} ms per step, "
+                f"{sum(v[0] for v in by.values()) / steps:.1f} launches per step, wall span {span / 1e6:.3f} ms per step\n\n"
+                "| kernel | calls/step | ms/step | avg us | % |\n|---|---|---|---|---|\n")
+        for k, (n, t) in sorted(by.items(), key=lambda kv: -kv[1][1]):
+            if t / tot < 0.002:
+                continue
+            f.write(f"| `{k}` | {n / steps:g} | {t / steps / 1e6:.3f} | {t / n / 1e3:.1f} | {100 * t / tot:.1f} |\n")
+    print(open(out).read()[:3500])
 
 
 def stats(d, steps, out, title):
@@ -39,7 +72,9 @@ def pmc(d, passes, counter):
 
 
 if __name__ == "__main__":
-    if sys.argv[1] == "stats":
+    if sys.argv[1] == "steady":
+        steady(sys.argv[2], sys.argv[3], sys.argv[4])
+    elif sys.argv[1] == "stats":
         stats(sys.argv[2], int(sys.argv[3]), sys.argv[4], sys.argv[5])
     else:
         pmc(sys.argv[2], int(sys.argv[3]), sys.argv[4])
