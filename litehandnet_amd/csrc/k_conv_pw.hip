@@ -6,6 +6,7 @@
 // row pad so that every ds_read_b128 is conflict-free (row stride = odd number of 16-B slots).
 // K order inside an 8-wide chunk is permuted (lane half h supplies k = 8*kc + 4*h + j at step j); both
 // operands use the same permutation, so only the fp32 summation order differs from a sequential loop.
+#include <stdlib.h>
 #include "lhn_common.h"
 
 // Runtime geometry of ONE launch.  Wide or odd channel counts (hourglass C = 256, lite-hrnet 40/80/160/320) are run by the
@@ -256,6 +257,183 @@ static int launch_pw_fwd(const lhn_view* x, const float* w, const float* bias, c
   return 0;
 }
 
+// =====================================================================================================
+// Forward, weights in REGISTERS (the fast path: stride 1, NHWC output, one input slice, Cout <= 128).
+// A wave owns ONE 32-feature tile of W for the whole launch: its MFMA B fragments (CIN/2 VGPRs: lane = feature, lane half
+// = k parity group) are loaded once from global memory.  LDS then only holds the pixel tile (double buffered, BM = 32..128
+// pixels), 17..37 KB per block instead of 70..135 KB, so 2-3 blocks share a CU and one block's loads / LDS commit / stores
+// run under another block's MFMA phase (the LDS-resident-W kernel above sits at ONE block per CU for 128 -> 128 and adds its
+// phases up: 126 us against a 55 us MFMA bound).  Waves: NCOT feature tiles x (4 / NCOT) pixel sub-tiles of 32.
+// Statistics need no cross-wave reduction: each wave owns its features.
+template <int CIN, int NCOT, int NS>
+__global__ void __launch_bounds__(256, (NS > 1 || CIN == 128) ? 2 : 3)
+k_pw_fwd_wr(lhn_view x, const float* __restrict__ w, const float* __restrict__ bias, lhn_view y, double* __restrict__ stats,
+            int cout, int M, int ntiles, PwExtra ex) {
+  constexpr int LDA = CIN + 4, PXW = 4 / NCOT, BM = 32 * PXW;
+  constexpr int C4 = CIN / 4, RP = 256 / C4, PF = BM / RP;      // float4 loads per thread, tile and source
+  static_assert(PF >= 1, "tile too small for the loader");
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // [2][BM][LDA]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int cot = wave % NCOT, pxs = wave / NCOT;
+  const int co = cot * 32 + l31;
+  // ---- B fragments: wreg[kc*4 + j] = W[co][8*kc + 4*lh + j]  (same K permutation as the A reads below)
+  float wreg[CIN / 2];
+#pragma unroll
+  for (int kc = 0; kc < CIN / 8; ++kc) {
+    f4 v = (f4){0.f, 0.f, 0.f, 0.f};
+    if (co < cout) v = *reinterpret_cast<const f4*>(w + (int64_t)co * CIN + kc * 8 + 4 * lh);
+    wreg[kc * 4 + 0] = v.x; wreg[kc * 4 + 1] = v.y; wreg[kc * 4 + 2] = v.z; wreg[kc * 4 + 3] = v.w;
+  }
+  const float bv = (bias && co < cout) ? bias[co] : 0.f;
+  // ---- loader geometry
+  const int c4 = tid % C4, row0 = tid / C4;
+  const int cabs = x.coff + 4 * c4;
+  const Xf4 xf = lhn_load_xf(x, cabs);
+  const int HoWo = y.H * y.W;
+  int ecabs[NS > 1 ? NS - 1 : 1];
+  Xf4 exf[NS > 1 ? NS - 1 : 1];
+  if (NS > 1) {
+#pragma unroll
+    for (int e = 0; e < NS - 1; ++e)
+      if (e < ex.n) {
+        ecabs[e] = ex.v[e].coff + 4 * c4;
+        exf[e] = lhn_load_xf(ex.v[e], ecabs[e]);
+      }
+  }
+  f4 pre[PF], epre[NS > 1 ? NS - 1 : 1][PF];
+  auto issue = [&](int tile) __attribute__((always_inline)) {
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {
+      const int m = min(tile * BM + row0 + p * RP, M - 1);      // clamped: rows >= M are zeroed at commit
+      pre[p] = *reinterpret_cast<const f4*>(x.data + (int64_t)m * x.cstride + cabs);
+      if (NS > 1) {
+#pragma unroll
+        for (int e = 0; e < NS - 1; ++e)
+          if (e < ex.n) epre[e][p] = *reinterpret_cast<const f4*>(ex.v[e].data + (int64_t)m * ex.v[e].cstride + ecabs[e]);
+      }
+    }
+  };
+  auto commit = [&](int tile, float* As) __attribute__((always_inline)) {
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {
+      const int row = row0 + p * RP, m = tile * BM + row;
+      f4 v = (f4){0.f, 0.f, 0.f, 0.f};
+      if (m < M) {
+        const int n = m / HoWo;
+        v = lhn_apply_xf(pre[p], xf);
+        if (x.gate) v *= *reinterpret_cast<const f4*>(x.gate + (int64_t)n * x.cstride + cabs);
+        if (NS > 1) {
+          v *= ex.coef[0];
+#pragma unroll
+          for (int e = 0; e < NS - 1; ++e)
+            if (e < ex.n) {
+              f4 u = lhn_apply_xf(epre[e][p], exf[e]);
+              if (ex.v[e].gate) u *= *reinterpret_cast<const f4*>(ex.v[e].gate + (int64_t)n * ex.v[e].cstride + ecabs[e]);
+              v += u * ex.coef[e + 1];
+            }
+        }
+      }
+      *reinterpret_cast<f4*>(As + row * LDA + 4 * c4) = v;
+    }
+  };
+
+  float ssum = 0.f, ssq = 0.f;
+  int tile = blockIdx.x, buf = 0;
+  if (tile < ntiles) {
+    issue(tile);
+    commit(tile, smem);
+    if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x);
+  }
+  __syncthreads();
+  for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+    const float* As = smem + buf * BM * LDA;
+    f16v acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const float* arow = As + (pxs * 32 + l31) * LDA + 4 * lh;
+#pragma unroll
+    for (int kc = 0; kc < CIN / 8; ++kc) {
+      const f4 a = *reinterpret_cast<const f4*>(arow + kc * 8);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, wreg[kc * 4 + 0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, wreg[kc * 4 + 1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, wreg[kc * 4 + 2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, wreg[kc * 4 + 3], acc, 0, 0, 0);
+    }
+    // next tile: registers -> the other LDS buffer (nobody reads it during this iteration), then the loads of the tile after
+    const int next = tile + gridDim.x;
+    if (next < ntiles) {
+      commit(next, smem + (buf ^ 1) * BM * LDA);
+      if (next + (int)gridDim.x < ntiles) issue(next + gridDim.x);
+    }
+    // epilogue: C/D layout col = lane&31 (feature), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel)
+    if (co < cout) {
+      const int mbase = tile * BM + pxs * 32 + 4 * lh;
+      float* yo = y.data + y.coff + co;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mbase + (r & 3) + 8 * (r >> 2);
+        if (m < M) {
+          const float v = acc[r] + bv;
+          yo[(int64_t)m * y.cstride] = v;
+          ssum += v;
+          ssq += v * v;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (stats && co < cout) {
+    const float s = ssum + __shfl_xor(ssum, 32, 64), q = ssq + __shfl_xor(ssq, 32, 64);
+    if (lh == 0) {
+      double* st = stats + (size_t)(blockIdx.x % LHN_STAT_REPLICAS) * 2 * cout;
+      atomicAdd(st + co, (double)s);
+      atomicAdd(st + cout + co, (double)q);
+    }
+  }
+}
+
+template <int CIN, int NCOT, int NS>
+static int launch_pw_fwd_wr(const lhn_view* x, const float* w, const float* bias, const lhn_view* y, double* stats, int cout,
+                            hipStream_t s, const PwExtra* exp) {
+  PwExtra ex;
+  if (exp) ex = *exp; else ex.n = 0;
+  constexpr int BM = 32 * (4 / NCOT);
+  const int M = y->N * y->H * y->W, ntiles = (M + BM - 1) / BM;
+  const size_t lds = (size_t)2 * BM * (CIN + 4) * sizeof(float);
+  static LhnKernelCfg cfg;
+  int per_cu = 1;
+  if (!lhn_kernel_cfg(cfg, &k_pw_fwd_wr<CIN, NCOT, NS>, lds, 4, &per_cu)) {
+    lhn_set_error("lhn_conv_pw_fwd: cannot reserve %zu B of LDS", lds);
+    return 2;
+  }
+  int grid = lhn_num_cus() * per_cu;
+  if (grid > ntiles) grid = ntiles;
+  hipLaunchKernelGGL((k_pw_fwd_wr<CIN, NCOT, NS>), dim3(grid), dim3(256), lds, s, *x, w, bias, *y, stats, cout, M, ntiles, ex);
+  return 0;
+}
+
+// returns -1 when the register-resident-weights kernel has no instance for the shape
+static int pw_fwd_wr(const lhn_view* x, const float* w, const float* bias, const lhn_view* y, double* stats, int cout, hipStream_t s,
+                     const PwExtra* ex) {
+  static int off = -1;
+  if (off < 0) {
+    const char* e = getenv("LHN_PW_LDSW");      // 1 = always take the LDS-resident-W kernel (A/B comparisons)
+    off = (e && e[0] == '1') ? 1 : 0;
+  }
+  if (off) return -1;
+  const int ci = x->C, ncot = cout <= 32 ? 1 : cout <= 64 ? 2 : 4;
+  const bool ms = ex && ex->n > 0;
+  if (ms) {
+    if (ci == 128 && ncot == 4) return launch_pw_fwd_wr<128, 4, 3>(x, w, bias, y, stats, cout, s, ex);
+    if (ci == 64 && ncot == 2) return launch_pw_fwd_wr<64, 2, 3>(x, w, bias, y, stats, cout, s, ex);
+    return -1;
+  }
+#define WR(CI, NC) if (ci == CI && ncot == NC) return launch_pw_fwd_wr<CI, NC, 1>(x, w, bias, y, stats, cout, s, nullptr);
+  WR(128, 4) WR(128, 2) WR(64, 4) WR(64, 2) WR(64, 1) WR(32, 4) WR(32, 2) WR(32, 1)
+#undef WR
+  return -1;
+}
+
 // smallest tile width (16/32/64/128) that holds `c` input channels; 0 = none
 static inline int pw_cin_tile(int c) { return c <= 16 ? 16 : c <= 32 ? 32 : c <= 64 ? 64 : c <= 128 ? 128 : 0; }
 
@@ -264,6 +442,12 @@ static int pw_fwd_slice(const lhn_view* x, const float* w, const float* bias, co
                         float* y_nchw, int cout, const lhn_bnfin* fin, const PwGeom& geo, hipStream_t s, const PwExtra* ex = nullptr) {
   const int ci = pw_cin_tile(x->C), nt = (cout + 31) / 32 == 3 ? 4 : (cout + 31) / 32;
   int rc = -1;
+  // fast path: whole-K slice with full-width rows, plain NHWC store, no fused finalize
+  if (stride == 1 && !y_nchw && !geo.yacc && x->C == ci && geo.kvalid == ci && geo.wstride == ci && geo.wrows == cout &&
+      geo.statC == cout && !(fin && stats) && (reinterpret_cast<uintptr_t>(w) & 15) == 0) {
+    rc = pw_fwd_wr(x, w, bias, y, stats, cout, s, ex);
+    if (rc != -1) return rc;
+  }
   if (ex && ex->n > 0) {      // summed-on-load sources: the square 1x1 of MSRB (litehourglass.py:30,49), C = 64 / 128
     if (ci == 128 && nt == 4) rc = launch_pw_fwd<128, 4, 3>(x, w, bias, y, stats, stride, y_nchw, cout, fin, geo, s, ex);
     else if (ci == 64 && nt == 2) rc = launch_pw_fwd<64, 2, 3>(x, w, bias, y, stats, stride, y_nchw, cout, fin, geo, s, ex);
