@@ -20,7 +20,7 @@ class LhnError(RuntimeError):
 class View(C.Structure):
     _fields_ = [("data", C.c_void_p), ("table", C.c_void_p), ("gate", C.c_void_p),
                 ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
-                ("cstride", C.c_int32), ("coff", C.c_int32), ("C", C.c_int32)]
+                ("cstride", C.c_int32), ("coff", C.c_int32), ("C", C.c_int32), ("pend", C.c_void_p)]
 
 
 class GradView(C.Structure):
@@ -29,7 +29,7 @@ class GradView(C.Structure):
 
 class Op(C.Structure):
     _fields_ = [("kind", C.c_int32),
-                ("in_buf", C.c_int32 * 3), ("in_coff", C.c_int32 * 3), ("in_C", C.c_int32 * 3),
+                ("in_buf", C.c_int32 * 3), ("in_coff", C.c_int32 * 3), ("in_C", C.c_int32 * 3), ("pend", (C.c_int32 * 2) * 3),
                 ("out_buf", C.c_int32), ("out_coff", C.c_int32), ("out_C", C.c_int32),
                 ("p", C.c_int32 * 12), ("ws", C.c_int64 * 6), ("i", C.c_int32 * 8), ("f", C.c_float * 8)]
 

@@ -10,21 +10,24 @@
 // row/tap validity is block-uniform; a wave reads 64/C4 neighbouring pixels x C*4 contiguous bytes per tap.
 template <int K>
 __global__ void __launch_bounds__(256) k_dw_fwd(lhn_view x, const float* __restrict__ w, lhn_view y,
-                                                double* __restrict__ stats, int stride, int pad, int dil, lhn_bnfin fin) {
+                                                double* __restrict__ stats, int stride, int pad, int dil, lhn_bnfin fin,
+                                                lhn_pends px) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int C = x.C, C4 = C >> 2;
   constexpr int KK = K * K;
   float* Ws = smem;                                   // [KK][C]
   f4* red = reinterpret_cast<f4*>(smem + KK * C);     // [256][2]
   const int tid = threadIdx.x;
+  const int c4 = tid % C4, pl = tid / C4, PL = 256 / C4;
+  const int cin = x.coff + 4 * c4, cout = y.coff + 4 * c4;
+  lhn_resolve_table(x, px, smem);                     // pending BatchNorm of the input (LDS: >= 8 KB, weights staged after)
+  const Xf4 xf = lhn_load_xf(x, cin);
+  if (px.n > 0) __syncthreads();
   for (int i = tid; i < KK * C; i += 256) {
     const int c = i / KK, t = i - c * KK;
     Ws[t * C + c] = w ? w[i] : 1.f;
   }
   __syncthreads();
-  const int c4 = tid % C4, pl = tid / C4, PL = 256 / C4;
-  const int cin = x.coff + 4 * c4, cout = y.coff + 4 * c4;
-  const Xf4 xf = lhn_load_xf(x, cin);
   f4 wt[KK];
 #pragma unroll
   for (int t = 0; t < KK; ++t) wt[t] = *reinterpret_cast<const f4*>(Ws + t * C + 4 * c4);
@@ -173,7 +176,15 @@ static inline int grid_for(int64_t items_per_block_total, int per_block, int cap
 }
 static inline bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
-struct DwExtra;
+// One extra input source: the consumed input is coef[0]*value(x) + coef[1]*value(ex.v) (MSRB's `out + ca(cat)`,
+// litehourglass.py:41-45, summed while the halo tile is staged instead of being written by an elementwise pass).
+struct DwExtra {
+  lhn_view v;
+  float coef[2];
+  int n;             // 0 or 1
+  lhn_pends pend[2]; // BatchNorms to finalize first: [0] = x, [1] = v (see lhn_pend)
+};
+
 int lhn_dwk_fwd_lds(const lhn_view* x, const float* w, const lhn_view* y, double* stats, int k, int dil, lhn_bnfin fin,
                     hipStream_t s, const DwExtra* ex);
 int lhn_dwk_bwd_lds(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx, int dx_acc,
@@ -217,16 +228,22 @@ extern "C" int lhn_conv_dw_fwd(const lhn_view* x, const float* w, const lhn_view
   const size_t lds = (size_t)(k * k * x->C) * 4 + 256 * 2 * 16;
   const int grid = grid_for((int64_t)y->N * Ho, 1, 8);
   hipStream_t s = (hipStream_t)stream;
+  LHN_CHECK_ARG(lhn_pend_ok(x), "lhn_conv_dw_fwd: bad pending BatchNorm on the input view");
+  const lhn_pends px = lhn_pends_of(x);
+  DwExtra ex0;
+  ex0.n = 0;
+  ex0.pend[0] = px;
+  ex0.pend[1].n = 0;
   if (w && stride == 1 && pad == dil * (k - 1) / 2 && x->C % 32 == 0 && y->W >= 8 && !lhn_dw_force_gather() &&
-      lhn_dwk_fwd_lds(x, w, y, stats, k, dil, fin, s, nullptr)) {
+      lhn_dwk_fwd_lds(x, w, y, stats, k, dil, fin, s, &ex0)) {
   } else if (k == 3)
-    hipLaunchKernelGGL((k_dw_fwd<3>), dim3(grid), dim3(256), lds, s, *x, w, *y, stats, stride, pad, dil, fin);
+    hipLaunchKernelGGL((k_dw_fwd<3>), dim3(grid), dim3(256), lds, s, *x, w, *y, stats, stride, pad, dil, fin, px);
   else if (k == 7)
-    hipLaunchKernelGGL((k_dw_fwd<7>), dim3(grid), dim3(256), lds, s, *x, w, *y, stats, stride, pad, dil, fin);
+    hipLaunchKernelGGL((k_dw_fwd<7>), dim3(grid), dim3(256), lds, s, *x, w, *y, stats, stride, pad, dil, fin, px);
   else if (k == 1)
-    hipLaunchKernelGGL((k_dw_fwd<1>), dim3(grid), dim3(256), lds, s, *x, w, *y, stats, stride, pad, dil, fin);
+    hipLaunchKernelGGL((k_dw_fwd<1>), dim3(grid), dim3(256), lds, s, *x, w, *y, stats, stride, pad, dil, fin, px);
   else if (k == 5)
-    hipLaunchKernelGGL((k_dw_fwd<5>), dim3(grid), dim3(256), lds, s, *x, w, *y, stats, stride, pad, dil, fin);
+    hipLaunchKernelGGL((k_dw_fwd<5>), dim3(grid), dim3(256), lds, s, *x, w, *y, stats, stride, pad, dil, fin, px);
   LHN_CHECK_LAUNCH("lhn_conv_dw_fwd");
   return 0;
 }
@@ -446,7 +463,7 @@ extern "C" int lhn_conv_dw_bwd(const lhn_view* x, const float* w, const lhn_view
                                int dx_accumulate, float* dw, int k, int stride, int pad, int dil, int nrep, int64_t rep_stride,
                                void* stream) {
   if (nrep < 1) nrep = 1;
-  LHN_CHECK_ARG(lhn_view_ok(x) && lhn_view_ok(y) && gy && gy->dz && ((w && dw) || k == 1), "lhn_conv_dw_bwd: bad view / null pointer");
+  LHN_CHECK_ARG(lhn_view_ok(x) && lhn_view_ok(y) && gy && gy->dz && ((w && dw) || k == 1) && lhn_no_pend(x) && lhn_no_pend(y), "lhn_conv_dw_bwd: bad view / null pointer");
   LHN_CHECK_ARG(x->C == y->C && pow2(x->C) && x->C <= 256, "lhn_conv_dw_bwd: channels");
   LHN_CHECK_ARG(k == 1 || k == 3 || k == 7, "lhn_conv_dw_bwd: k=%d (1, 3 or 7)", k);
   hipStream_t s = (hipStream_t)stream;
@@ -508,14 +525,6 @@ struct DwTile {
   static constexpr int P = DIL * (K - 1) / 2, HH = TH + 2 * P, WW = TW + 2 * P, PIX = HH * WW;
 };
 
-// One extra input source: the consumed input is coef[0]*value(x) + coef[1]*value(ex.v) (MSRB's `out + ca(cat)`,
-// litehourglass.py:41-45, summed while the halo tile is staged instead of being written by an elementwise pass).
-struct DwExtra {
-  lhn_view v;
-  float coef[2];
-  int n;             // 0 or 1
-};
-
 template <int K, int DIL, int NS = 1>
 __global__ void __launch_bounds__(256) k_dwk_fwd_lds(lhn_view x, const float* __restrict__ w, lhn_view y,
                                                      double* __restrict__ stats, int tiles_h, int tiles_w, int cgroups,
@@ -533,10 +542,15 @@ __global__ void __launch_bounds__(256) k_dwk_fwd_lds(lhn_view x, const float* __
   const int ntile = y.N * ps * ps * tiles_h * tiles_w * cgroups;
   const int cg = blockIdx.x % cgroups;                     // grid % cgroups == 0 (host): fixed per block
   const int cin = x.coff + cg * 32 + 4 * c4, cout = y.coff + cg * 32 + 4 * c4;
+  lhn_resolve_table(x, ex.pend[0], smem);       // (the tile region is free until the first commit, which follows a barrier)
   const Xf4 xf = lhn_load_xf(x, cin);
   const int cin2 = NS > 1 ? ex.v.coff + cg * 32 + 4 * c4 : 0;
   Xf4 xf2;
-  if (NS > 1) xf2 = lhn_load_xf(ex.v, cin2);
+  if (NS > 1) {
+    if (ex.pend[0].n > 0 && ex.pend[1].n > 0) __syncthreads();
+    lhn_resolve_table(ex.v, ex.pend[1], smem);
+    xf2 = lhn_load_xf(ex.v, cin2);
+  }
   for (int i = tid; i < KK * 8; i += 256) {
     const int k = i >> 3, cc = cg * 32 + 4 * (i & 7);
     wl[i] = (f4){w[(cc + 0) * KK + k], w[(cc + 1) * KK + k], w[(cc + 2) * KK + k], w[(cc + 3) * KK + k]};
@@ -866,7 +880,7 @@ template <int K, int DIL, int NS = 1>
 static void launch_dwk_fwd(const lhn_view* x, const float* w, const lhn_view* y, double* stats, lhn_bnfin fin, hipStream_t s, int ps = 1,
                            const DwExtra* exp = nullptr) {
   DwExtra ex;
-  if (exp) ex = *exp; else ex.n = 0;
+  if (exp) ex = *exp; else { ex.n = 0; ex.pend[0].n = ex.pend[1].n = 0; }
   constexpr int TH = 8, TW = 32, P = DIL * (K - 1) / 2;
   const int cg = x->C / 32;
   const int sh = (y->H + ps - 1) / ps, sw = (y->W + ps - 1) / ps;       // largest parity sub-lattice
@@ -900,10 +914,10 @@ int lhn_dwk_fwd_lds(const lhn_view* x, const float* w, const lhn_view* y, double
     else return 0;
     return 1;
   }
-  if (k == 3 && dil == 1) launch_dwk_fwd<3, 1>(x, w, y, stats, fin, s);
-  else if (k == 3 && dil == 2 && y->W >= 16) launch_dwk_fwd<3, 1>(x, w, y, stats, fin, s, 2);    // parity sub-lattices
-  else if (k == 3 && dil == 2) launch_dwk_fwd<3, 2>(x, w, y, stats, fin, s);
-  else if (k == 7 && dil == 1) launch_dwk_fwd<7, 1>(x, w, y, stats, fin, s);
+  if (k == 3 && dil == 1) launch_dwk_fwd<3, 1>(x, w, y, stats, fin, s, 1, ex);
+  else if (k == 3 && dil == 2 && y->W >= 16) launch_dwk_fwd<3, 1>(x, w, y, stats, fin, s, 2, ex);    // parity sub-lattices
+  else if (k == 3 && dil == 2) launch_dwk_fwd<3, 2>(x, w, y, stats, fin, s, 1, ex);
+  else if (k == 7 && dil == 1) launch_dwk_fwd<7, 1>(x, w, y, stats, fin, s, 1, ex);
   else return 0;
   return 1;
 }
@@ -920,10 +934,13 @@ int lhn_dwk_bwd_lds(const lhn_view* x, const float* w, const lhn_view* y, const 
 static int dw_fwd_extra(const lhn_view* x, const float* w, const lhn_view* y, double* stats, int k, int stride, int pad, int dil,
                         lhn_bnfin fin, const lhn_view* extra, const float* coef, hipStream_t s) {
   if (!(stride == 1 && pad == dil * (k - 1) / 2 && x->C % 32 == 0 && y->W >= 8)) return 0;
+  if (!lhn_pend_ok(x) || !lhn_pend_ok(extra)) return 0;
   DwExtra ex;
   ex.v = *extra;
   ex.coef[0] = coef[0];
   ex.coef[1] = coef[1];
   ex.n = 1;
+  ex.pend[0] = lhn_pends_of(x);
+  ex.pend[1] = lhn_pends_of(extra);
   return lhn_dwk_fwd_lds(x, w, y, stats, k, dil, fin, s, &ex);
 }

@@ -518,7 +518,7 @@ static int kxk_nt_block(int M, int nt) {
 
 extern "C" int lhn_conv_kxk_fwd(const lhn_view* x, const float* w, const lhn_view* y, double* stats, int stride,
                                 const lhn_bnfin* fin, float* wt_scratch, void* stream) {
-  LHN_CHECK_ARG(lhn_view_ok(x) && lhn_view_ok(y) && w, "lhn_conv_kxk_fwd: bad view / null pointer");
+  LHN_CHECK_ARG(lhn_view_ok(x) && lhn_view_ok(y) && w && lhn_no_pend(x), "lhn_conv_kxk_fwd: bad view / null pointer (no pending BatchNorm here)");
   LHN_CHECK_ARG((stride == 1 || stride == 2) && kxk_geometry_ok(x, y, stride), "lhn_conv_kxk_fwd: geometry / stride %d", stride);
   const int ntot = (y->C + 31) / 32, nt = (ntot == 1 || ntot == 2 || ntot == 4) ? kxk_nt_block(y->N * y->H * y->W, ntot) : ntot;
   hipStream_t s = (hipStream_t)stream;
@@ -536,7 +536,7 @@ extern "C" int lhn_conv_kxk_fwd(const lhn_view* x, const float* w, const lhn_vie
 extern "C" int lhn_conv_kxk_bwd(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx,
                                 int dx_accumulate, float* dw, int stride, int nrep, int64_t rep_stride, float* wt_scratch,
                                 void* stream) {
-  LHN_CHECK_ARG(lhn_view_ok(x) && lhn_view_ok(y) && w && gy && gy->dz && dw, "lhn_conv_kxk_bwd: bad view / null pointer");
+  LHN_CHECK_ARG(lhn_view_ok(x) && lhn_view_ok(y) && w && gy && gy->dz && dw && lhn_no_pend(x) && lhn_no_pend(y), "lhn_conv_kxk_bwd: bad view / null pointer");
   LHN_CHECK_ARG((stride == 1 || stride == 2) && kxk_geometry_ok(x, y, stride), "lhn_conv_kxk_bwd: geometry / stride %d", stride);
   if (nrep < 1) nrep = 1;
   hipStream_t s = (hipStream_t)stream;

@@ -51,6 +51,7 @@ struct PwExtra {
   lhn_view v[2];
   float coef[3];
   int n;             // number of EXTRA sources in v (0..2)
+  lhn_pends pend[3]; // BatchNorms to finalize first: [0] = x, [1..2] = v[0..1] (see lhn_pend)
 };
 
 template <int CIN, int NT, int NS = 1>
@@ -69,11 +70,11 @@ __global__ void __launch_bounds__(256, NS > 1 ? 1 : ((CIN == 64 && NT == 2) || (
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
 
-  pw_stage_w<CIN>(Ws, LDA, w, 32 * NT, geo);
-
   const int c4 = tid % C4, row0 = tid / C4;
   const bool kok = 4 * c4 < x.C;                     // channel groups beyond the view are zero columns of the tile
   const int cabs = x.coff + (kok ? 4 * c4 : 0);
+  const bool pending = ex.pend[0].n > 0 || (NS > 1 && (ex.pend[1].n > 0 || ex.pend[2].n > 0));
+  lhn_resolve_table(x, ex.pend[0], smem);
   const Xf4 xf = lhn_load_xf(x, cabs);
   const int HoWo = y.H * y.W;
   // extra sources (NS > 1): own buffer, table, gate, channel offset
@@ -85,9 +86,13 @@ __global__ void __launch_bounds__(256, NS > 1 ? 1 : ((CIN == 64 && NT == 2) || (
     for (int e = 0; e < NS - 1; ++e)
       if (e < ex.n) {
         ecabs[e] = ex.v[e].coff + (kok ? 4 * c4 : 0);
+        if (pending) __syncthreads();               // the previous table copy has been read by everybody
+        lhn_resolve_table(ex.v[e], ex.pend[e + 1], smem);
         exf[e] = lhn_load_xf(ex.v[e], ecabs[e]);
       }
   }
+  if (pending) __syncthreads();
+  pw_stage_w<CIN>(Ws, LDA, w, 32 * NT, geo);
 
   f4 pre[PF];
   auto in_pix = [&](int m) __attribute__((always_inline)) -> int64_t {
@@ -238,7 +243,7 @@ static int launch_pw_fwd(const lhn_view* x, const float* w, const float* bias, c
                          int stride, float* y_nchw, int cout, const lhn_bnfin* fin, const PwGeom& geo, hipStream_t s,
                          const PwExtra* exp = nullptr) {
   PwExtra ex;
-  if (exp) ex = *exp; else ex.n = 0;
+  if (exp) ex = *exp; else { ex.n = 0; ex.pend[0].n = ex.pend[1].n = ex.pend[2].n = 0; }
   lhn_bnfin f;
   if (fin && stats) f = *fin; else f.counter = nullptr;
   const int M = y->N * y->H * y->W;
@@ -288,6 +293,8 @@ k_pw_fwd_wr(lhn_view x, const float* __restrict__ w, const float* __restrict__ b
   // ---- loader geometry
   const int c4 = tid % C4, row0 = tid / C4;
   const int cabs = x.coff + 4 * c4;
+  const bool pending = ex.pend[0].n > 0 || (NS > 1 && (ex.pend[1].n > 0 || ex.pend[2].n > 0));
+  lhn_resolve_table(x, ex.pend[0], smem);
   const Xf4 xf = lhn_load_xf(x, cabs);
   const int HoWo = y.H * y.W;
   int ecabs[NS > 1 ? NS - 1 : 1];
@@ -297,9 +304,12 @@ k_pw_fwd_wr(lhn_view x, const float* __restrict__ w, const float* __restrict__ b
     for (int e = 0; e < NS - 1; ++e)
       if (e < ex.n) {
         ecabs[e] = ex.v[e].coff + 4 * c4;
+        if (pending) __syncthreads();
+        lhn_resolve_table(ex.v[e], ex.pend[e + 1], smem);
         exf[e] = lhn_load_xf(ex.v[e], ecabs[e]);
       }
   }
+  if (pending) __syncthreads();               // the table copies lived in the pixel-tile buffers
   f4 pre[PF], epre[NS > 1 ? NS - 1 : 1][PF];
   auto issue = [&](int tile) __attribute__((always_inline)) {
 #pragma unroll
@@ -396,7 +406,7 @@ template <int CIN, int NCOT, int NS>
 static int launch_pw_fwd_wr(const lhn_view* x, const float* w, const float* bias, const lhn_view* y, double* stats, int cout,
                             hipStream_t s, const PwExtra* exp) {
   PwExtra ex;
-  if (exp) ex = *exp; else ex.n = 0;
+  if (exp) ex = *exp; else { ex.n = 0; ex.pend[0].n = ex.pend[1].n = ex.pend[2].n = 0; }
   constexpr int BM = 32 * (4 / NCOT);
   const int M = y->N * y->H * y->W, ntiles = (M + BM - 1) / BM;
   const size_t lds = (size_t)2 * BM * (CIN + 4) * sizeof(float);
@@ -428,7 +438,7 @@ static int pw_fwd_wr(const lhn_view* x, const float* w, const float* bias, const
     if (ci == 64 && ncot == 2) return launch_pw_fwd_wr<64, 2, 3>(x, w, bias, y, stats, cout, s, ex);
     return -1;
   }
-#define WR(CI, NC) if (ci == CI && ncot == NC) return launch_pw_fwd_wr<CI, NC, 1>(x, w, bias, y, stats, cout, s, nullptr);
+#define WR(CI, NC) if (ci == CI && ncot == NC) return launch_pw_fwd_wr<CI, NC, 1>(x, w, bias, y, stats, cout, s, ex);
   WR(128, 4) WR(128, 2) WR(64, 4) WR(64, 2) WR(64, 1) WR(32, 4) WR(32, 2) WR(32, 1)
 #undef WR
   return -1;
@@ -454,7 +464,7 @@ static int pw_fwd_slice(const lhn_view* x, const float* w, const float* bias, co
     return rc;
   }
 #define PW_CASE(CI, NTV) \
-  if (ci == CI && nt == NTV) rc = launch_pw_fwd<CI, NTV>(x, w, bias, y, stats, stride, y_nchw, cout, fin, geo, s);
+  if (ci == CI && nt == NTV) rc = launch_pw_fwd<CI, NTV>(x, w, bias, y, stats, stride, y_nchw, cout, fin, geo, s, ex);
   PW_CASE(32, 1) PW_CASE(32, 2) PW_CASE(32, 4) PW_CASE(64, 1) PW_CASE(64, 2) PW_CASE(64, 4) PW_CASE(128, 1)
   PW_CASE(128, 2) PW_CASE(128, 4) PW_CASE(16, 1) PW_CASE(16, 2) PW_CASE(16, 4)
 #undef PW_CASE
@@ -486,13 +496,18 @@ extern "C" int lhn_conv_pw_fwd2(const lhn_view* x, const float* w, const float* 
   const bool single = Cin <= 128 && Cout <= 128;
   PwExtra ex;
   ex.n = 0;
+  LHN_CHECK_ARG(lhn_pend_ok(x), "lhn_conv_pw_fwd: bad pending BatchNorm on the input view");
+  ex.pend[0] = lhn_pends_of(x);
+  ex.pend[1].n = ex.pend[2].n = 0;
+  LHN_CHECK_ARG(ex.pend[0].n == 0 || Cin <= 128, "lhn_conv_pw_fwd: a pending BatchNorm needs an unsliced input (<= 128 channels)");
   if (opts && opts->n_extra > 0) {
     LHN_CHECK_ARG(opts->n_extra <= 2 && opts->extra && single && stride == 1, "lhn_conv_pw_fwd: extra sources need stride 1 and <= 128 channels");
     ex.n = opts->n_extra;
     for (int e = 0; e < ex.n; ++e) {
       const lhn_view* v = &opts->extra[e];
-      LHN_CHECK_ARG(lhn_view_ok(v) && v->C == Cin && v->N == x->N && v->H == x->H && v->W == x->W, "lhn_conv_pw_fwd: extra source %d geometry", e);
+      LHN_CHECK_ARG(lhn_view_ok(v) && v->C == Cin && v->N == x->N && v->H == x->H && v->W == x->W && lhn_pend_ok(v), "lhn_conv_pw_fwd: extra source %d geometry", e);
       ex.v[e] = *v;
+      ex.pend[e + 1] = lhn_pends_of(v);
     }
     for (int e = 0; e < 3; ++e) ex.coef[e] = opts->coef[e];
   }
@@ -517,7 +532,7 @@ extern "C" int lhn_conv_pw_fwd2(const lhn_view* x, const float* w, const float* 
       g.nchw_bstride = bstride;
       const int rc = pw_fwd_slice(&xv, w + (int64_t)co0 * wcols + k0, (last && bias) ? bias + co0 : nullptr, &yv,
                                   (last && stats) ? stats + co0 : nullptr, stride, y_nchw ? y_nchw + (int64_t)co0 * HoWo : nullptr,
-                                  cc, single ? fin : nullptr, g, s, ex.n ? &ex : nullptr);
+                                  cc, single ? fin : nullptr, g, s, &ex);
       LHN_CHECK_ARG(rc != -1, "lhn_conv_pw_fwd: unsupported channels Cin=%d Cout=%d (%d extra sources)", Cin, Cout, ex.n);
       if (rc) return rc;
     }
@@ -815,7 +830,7 @@ extern "C" int lhn_conv_pw_bwd2(const lhn_view* x, const float* w, const lhn_vie
                                 int dx_accumulate, float* dw, float* dbias, int stride, const float* dy_nchw, int nrep,
                                 int64_t rep_stride, const lhn_pw_opts* opts, void* stream) {
   if (nrep < 1) nrep = 1;
-  LHN_CHECK_ARG(lhn_view_ok(x) && w && y && gy && dw, "lhn_conv_pw_bwd: bad view / null pointer");
+  LHN_CHECK_ARG(lhn_view_ok(x) && w && y && gy && dw && lhn_no_pend(x) && lhn_no_pend(y), "lhn_conv_pw_bwd: bad view / null pointer");
   LHN_CHECK_ARG(stride == 1 || stride == 2, "lhn_conv_pw_bwd: stride %d", stride);
   LHN_CHECK_ARG(stride == 1 || !dx || dx_accumulate, "lhn_conv_pw_bwd: stride-2 dgrad only accumulates into a zeroed gradient");
   if (!dy_nchw) LHN_CHECK_ARG(lhn_view_ok(y) && gy->dz, "lhn_conv_pw_bwd: bad output view / missing dz");

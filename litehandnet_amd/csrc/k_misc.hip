@@ -75,6 +75,7 @@ __global__ void k_table_bias(float* __restrict__ table, int cs, int coff, int C,
 struct EwSrcs {
   lhn_view v[3];
   float coef[3];     // dst = act(sum_i coef[i] * value_i)
+  lhn_pends pend[3]; // BatchNorms to finalize first (see lhn_pend)
 };
 __device__ __forceinline__ int nearest_src(int d, int in, int out) {
   if (in == out) return d;
@@ -83,14 +84,18 @@ __device__ __forceinline__ int nearest_src(int d, int in, int out) {
   return s < in - 1 ? s : in - 1;
 }
 __global__ void __launch_bounds__(256) k_ew_fwd(EwSrcs S, int nsrc, lhn_view dst, float out_slope) {
+  __shared__ __attribute__((aligned(16))) float s_res[LHN_RESOLVE_FLOATS];
   const int C4 = dst.C >> 2, c4 = threadIdx.x % C4, pl = threadIdx.x / C4, PL = 256 / C4;
   const int rows = dst.N * dst.H;
   Xf4 xf[3];
   int ca[3];
+  const bool pending = S.pend[0].n > 0 || S.pend[1].n > 0 || S.pend[2].n > 0;
 #pragma unroll
   for (int k = 0; k < 3; ++k)
     if (k < nsrc) {
       ca[k] = S.v[k].coff + 4 * c4;
+      if (pending && k > 0) __syncthreads();       // the previous table copy has been read by everybody
+      lhn_resolve_table(S.v[k], S.pend[k], s_res);
       xf[k] = lhn_load_xf(S.v[k], ca[k]);
     }
   for (int row = blockIdx.x; row < rows; row += gridDim.x) {
@@ -178,9 +183,11 @@ __global__ void __launch_bounds__(256) k_ew_bwd_src(lhn_view src, lhn_view dst, 
 }
 
 // ------------------------------------------------------------------ 2x2 stride-2 max pool (ceil_mode)
-__global__ void __launch_bounds__(256) k_maxpool2_fwd(lhn_view x, lhn_view y) {
+__global__ void __launch_bounds__(256) k_maxpool2_fwd(lhn_view x, lhn_view y, lhn_pends px) {
+  __shared__ __attribute__((aligned(16))) float s_res[LHN_RESOLVE_FLOATS];
   const int C4 = y.C >> 2, c4 = threadIdx.x % C4, pl = threadIdx.x / C4, PL = 256 / C4;
   const int ca = x.coff + 4 * c4;
+  lhn_resolve_table(x, px, s_res);
   const Xf4 xf = lhn_load_xf(x, ca);
   const int rows = y.N * y.H;
   for (int row = blockIdx.x; row < rows; row += gridDim.x) {
@@ -245,8 +252,10 @@ __global__ void __launch_bounds__(256) k_maxpool2_bwd(lhn_view x, lhn_view y, co
 }
 
 // ------------------------------------------------------------------ adaptive average pool -> dense [N,OH,OW,C]
-__global__ void __launch_bounds__(256) k_avgpool_fwd(lhn_view x, float* __restrict__ out, int OH, int OW) {
+__global__ void __launch_bounds__(256) k_avgpool_fwd(lhn_view x, float* __restrict__ out, int OH, int OW, lhn_pends px) {
   __shared__ f4 red[256];
+  __shared__ __attribute__((aligned(16))) float s_res[LHN_RESOLVE_FLOATS];
+  lhn_resolve_table(x, px, s_res);
   const int C4 = x.C >> 2, PL = 256 / C4;
   const int b = blockIdx.x;
   const int ow = b % OW, oh = (b / OW) % OH, n = b / (OW * OH);
@@ -719,9 +728,10 @@ int lhn_ew_fwd2(const lhn_view* srcs, int nsrc, const float* coef, const lhn_vie
   EwSrcs S;
   memset(&S, 0, sizeof(S));
   for (int i = 0; i < nsrc; ++i) {
-    LHN_CHECK_ARG(lhn_view_ok(&srcs[i]) && srcs[i].C == dst->C && srcs[i].N == dst->N, "lhn_ew_fwd: source %d mismatch", i);
+    LHN_CHECK_ARG(lhn_view_ok(&srcs[i]) && srcs[i].C == dst->C && srcs[i].N == dst->N && lhn_pend_ok(&srcs[i]), "lhn_ew_fwd: source %d mismatch", i);
     S.v[i] = srcs[i];
     S.coef[i] = coef ? coef[i] : 1.f;
+    S.pend[i] = lhn_pends_of(&srcs[i]);
   }
   LHN_CHECK_ARG(pow2i(dst->C / 4) && dst->C <= 1024, "lhn_ew_fwd: C=%d", dst->C);
   hipLaunchKernelGGL(k_ew_fwd, dim3(grid_cap((int64_t)dst->N * dst->H, 8)), dim3(256), 0, (hipStream_t)stream, S, nsrc, *dst, out_slope);
@@ -748,7 +758,7 @@ int lhn_ew_bwd(const lhn_view* srcs, int nsrc, const lhn_view* dst, const float*
 // variant used by the plan: dst may carry a channel-attention gate and its pooled-gradient (dpool)
 int lhn_ew_bwd2(const lhn_view* src, const lhn_view* dst, const float* ddst, const float* dst_dpool, float out_slope,
                 float* dsrc, int accumulate, void* stream) {
-  LHN_CHECK_ARG(lhn_view_ok(src) && lhn_view_ok(dst) && ddst && dsrc && src->C == dst->C, "lhn_ew_bwd2: bad args");
+  LHN_CHECK_ARG(lhn_view_ok(src) && lhn_view_ok(dst) && ddst && dsrc && src->C == dst->C && lhn_no_pend(src) && lhn_no_pend(dst), "lhn_ew_bwd2: bad args");
   LHN_CHECK_ARG(dst->H % src->H == 0 && dst->W % src->W == 0, "lhn_ew_bwd2: non-integer upsample");
   LHN_CHECK_ARG(out_slope != LHN_SLOPE_SILU || (dst->H == src->H && dst->W == src->W), "lhn_ew_bwd2: SiLU needs a single same-size source");
   LHN_CHECK_ARG(pow2i(src->C / 4) && src->C <= 1024, "lhn_ew_bwd2: C=%d", src->C);
@@ -762,12 +772,13 @@ int lhn_maxpool2_fwd(const lhn_view* x, const lhn_view* y, void* stream) {
   LHN_CHECK_ARG(lhn_view_ok(x) && lhn_view_ok(y) && x->C == y->C, "lhn_maxpool2_fwd: bad views");
   LHN_CHECK_ARG(y->H == (x->H + 1) / 2 && y->W == (x->W + 1) / 2 && y->N == x->N, "lhn_maxpool2_fwd: geometry");
   LHN_CHECK_ARG(pow2i(y->C / 4) && y->C <= 1024, "lhn_maxpool2_fwd: C=%d", y->C);
-  hipLaunchKernelGGL(k_maxpool2_fwd, dim3(grid_cap((int64_t)y->N * y->H, 8)), dim3(256), 0, (hipStream_t)stream, *x, *y);
+  LHN_CHECK_ARG(lhn_pend_ok(x), "lhn_maxpool2_fwd: bad pending BatchNorm");
+  hipLaunchKernelGGL(k_maxpool2_fwd, dim3(grid_cap((int64_t)y->N * y->H, 8)), dim3(256), 0, (hipStream_t)stream, *x, *y, lhn_pends_of(x));
   LHN_CHECK_LAUNCH("lhn_maxpool2_fwd");
   return 0;
 }
 int lhn_maxpool2_bwd(const lhn_view* x, const lhn_view* y, const float* dy, float* dx, int dx_accumulate, void* stream) {
-  LHN_CHECK_ARG(lhn_view_ok(x) && lhn_view_ok(y) && dy && dx && x->C == y->C, "lhn_maxpool2_bwd: bad args");
+  LHN_CHECK_ARG(lhn_view_ok(x) && lhn_view_ok(y) && dy && dx && x->C == y->C && lhn_no_pend(x), "lhn_maxpool2_bwd: bad args");
   LHN_CHECK_ARG(pow2i(y->C / 4) && y->C <= 1024, "lhn_maxpool2_bwd: C=%d", y->C);
   hipLaunchKernelGGL(k_maxpool2_bwd, dim3(grid_cap((int64_t)y->N * y->H, 8)), dim3(256), 0, (hipStream_t)stream, *x, *y, dy, dx, dx_accumulate);
   LHN_CHECK_LAUNCH("lhn_maxpool2_bwd");
@@ -777,7 +788,8 @@ int lhn_maxpool2_bwd(const lhn_view* x, const lhn_view* y, const float* dy, floa
 int lhn_avgpool_fwd(const lhn_view* x, float* out, int OH, int OW, void* stream) {
   LHN_CHECK_ARG(lhn_view_ok(x) && out && OH > 0 && OW > 0, "lhn_avgpool_fwd: bad args");
   LHN_CHECK_ARG(pow2i(x->C / 4) && x->C <= 1024, "lhn_avgpool_fwd: C=%d", x->C);
-  hipLaunchKernelGGL(k_avgpool_fwd, dim3(x->N * OH * OW), dim3(256), 0, (hipStream_t)stream, *x, out, OH, OW);
+  LHN_CHECK_ARG(lhn_pend_ok(x), "lhn_avgpool_fwd: bad pending BatchNorm");
+  hipLaunchKernelGGL(k_avgpool_fwd, dim3(x->N * OH * OW), dim3(256), 0, (hipStream_t)stream, *x, out, OH, OW, lhn_pends_of(x));
   LHN_CHECK_LAUNCH("lhn_avgpool_fwd");
   return 0;
 }
@@ -805,7 +817,7 @@ int lhn_ca_mlp_fwd(const float* pooled, const float* w3, const float* gamma, con
 }
 
 int lhn_gate_bwd_reduce(const lhn_view* y, const float* dz, float* dgate, void* stream) {
-  LHN_CHECK_ARG(lhn_view_ok(y) && dz && dgate && pow2i(y->C / 4), "lhn_gate_bwd_reduce: bad args");
+  LHN_CHECK_ARG(lhn_view_ok(y) && dz && dgate && pow2i(y->C / 4) && lhn_no_pend(y), "lhn_gate_bwd_reduce: bad args");
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(dgate, 0, (size_t)y->N * y->C * 4, s) != hipSuccess) {
     lhn_set_error("lhn_gate_bwd_reduce: memset failed");
@@ -841,7 +853,7 @@ int lhn_bn_bwd_reduce(const lhn_view* y, const lhn_gradview* g, const float* sav
                       void* stream) {
   lhn_bnbwdfin fin;
   if (finp) fin = *finp; else fin.counter = nullptr;
-  LHN_CHECK_ARG(lhn_view_ok(y) && g && g->dz && save && sums && pow2i(y->C / 4) && y->C <= 1024, "lhn_bn_bwd_reduce: bad args");
+  LHN_CHECK_ARG(lhn_view_ok(y) && g && g->dz && save && sums && pow2i(y->C / 4) && y->C <= 1024 && lhn_no_pend(y), "lhn_bn_bwd_reduce: bad args");
   hipLaunchKernelGGL(k_bn_bwd_reduce, dim3(grid_cap((int64_t)y->N * y->H, 8)), dim3(256), 0, (hipStream_t)stream, *y, *g, save, sums, fin);
   LHN_CHECK_LAUNCH("lhn_bn_bwd_reduce");
   return 0;

@@ -40,6 +40,7 @@ static inline char* at(void* ws, int64_t off) { return off < 0 ? nullptr : stati
 static lhn_view mkview(const Plan* P, void* ws, int buf, int coff, int C, bool with_gate = true) {
   const lhn_buf& b = P->bufs[buf];
   lhn_view v;
+  v.pend = nullptr;
   v.data = reinterpret_cast<float*>(at(ws, b.data_off));
   v.table = reinterpret_cast<const float*>(at(ws, b.table_off));
   v.gate = with_gate ? reinterpret_cast<const float*>(at(ws, b.gate_off)) : nullptr;
@@ -97,6 +98,26 @@ static int sep_finalize(const lhn_bnfin& f, const double* stats, int training, v
                          training ? f.save_mean_invstd : nullptr, f.count, f.eps, f.momentum, f.slope, training, f.conv_bias, stream);
 }
 
+// Deferred BatchNorm finalize (see lhn_pend): in a plain training run a convolution flagged i[7] leaves its statistics to
+// the first reader of its output, whose op lists it in pend[slot][]; eval / SyncBatchNorm / fused-finalize runs keep the
+// separate launch.
+static void mkpends(const Plan* P, void* ws, const std::vector<lhn_op>& ops, const lhn_op& o, int slot, void* const* params,
+                    double cscale, lhn_pends* out) {
+  out->n = 0;
+  for (int k = 0; k < 2; ++k) {
+    const int pi = o.pend[slot][k];
+    if (pi < 0) continue;
+    const lhn_op& po = ops[pi];
+    const lhn_bnfin f = mkfin(P, ws, po, params);
+    lhn_pend& p = out->p[out->n++];
+    p.stats = reinterpret_cast<const double*>(at(ws, po.ws[0]));
+    p.gamma = f.gamma; p.beta = f.beta; p.running_mean = f.running_mean; p.running_var = f.running_var;
+    p.num_batches_tracked = f.num_batches_tracked; p.save_mean_invstd = f.save_mean_invstd; p.conv_bias = f.conv_bias;
+    p.count = f.count * cscale; p.eps = f.eps; p.momentum = f.momentum; p.slope = f.slope;
+    p.coff = f.coff; p.C = f.C;
+  }
+}
+
 extern "C" {
 
 void* lhn_plan_create(const lhn_buf* bufs, int nbufs, const lhn_op* fwd, int nfwd, const lhn_op* bwd, int nbwd) {
@@ -145,8 +166,21 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
   hipStream_t s = static_cast<hipStream_t>(stream);
   int rc = 0;
   const bool whole = (sb == 0 && se >= 2 * ops.size());
+  const bool defer_ok = training && whole && phase == 0 && !fuse_finalize();     // consumers finalize flagged BatchNorms
+  lhn_pends pd[3];
   for (size_t oi = 0; oi < ops.size() && rc == 0; ++oi) {
     const lhn_op& o = ops[oi];
+    const bool deferred = defer_ok && o.i[7] == 1 && (o.kind == OP_STEM || o.kind == OP_PW || o.kind == OP_DW || o.kind == OP_KXK);
+    bool has_pend = false;
+    if (defer_ok && phase == 0)
+      for (int k = 0; k < 3; ++k) {
+        pd[k].n = 0;
+        if (o.pend[k][0] >= 0 || o.pend[k][1] >= 0) {
+          mkpends(P, ws, ops, o, k, params, cscale, &pd[k]);
+          has_pend = true;
+        }
+      }
+    (void)has_pend;
     const bool h0 = 2 * oi >= sb && 2 * oi < se, h1 = 2 * oi + 1 >= sb && 2 * oi + 1 < se;
     if (!h0 && !h1) continue;
     const bool two_half = o.kind == OP_STEM || o.kind == OP_PW || o.kind == OP_DW || o.kind == OP_KXK || o.kind == OP_CA_MLP ||
@@ -181,16 +215,17 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
         if (h0) rc = lhn_conv_stem_fwd(static_cast<const float*>(io[0]), prm<const float>(params, o.p[0]), &y,
                                (training && o.ws[0] >= 0) ? reinterpret_cast<double*>(at(ws, o.ws[0])) : nullptr, o.i[3], o.i[4], o.i[0], o.i[1],
                                o.i[2], (bn && training && fuse_finalize() && whole) ? &fin : nullptr, stream);
-        if (!rc && bn && h1 && !skip_tables && !(training && fuse_finalize() && whole)) rc = sep_finalize(fin, reinterpret_cast<const double*>(at(ws, o.ws[0])), training, stream);
+        if (!rc && bn && h1 && !skip_tables && !deferred && !(training && fuse_finalize() && whole)) rc = sep_finalize(fin, reinterpret_cast<const double*>(at(ws, o.ws[0])), training, stream);
         break;
       }
       case OP_PW: {
         lhn_view x = mkview(P, ws, o.in_buf[0], o.in_coff[0], o.in_C[0]);
+        if (has_pend && pd[0].n) x.pend = &pd[0];
         lhn_view y;
         float* nchw = nullptr;
         if (o.i[1]) {  // NCHW head: geometry from the input, channels from out_C
           y = x;
-          y.data = nullptr; y.table = nullptr; y.gate = nullptr;
+          y.data = nullptr; y.table = nullptr; y.gate = nullptr; y.pend = nullptr;
           y.cstride = o.out_C; y.coff = 0; y.C = o.out_C;
           nchw = static_cast<float*>(io[1]);
         } else {
@@ -210,7 +245,10 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
         lhn_view extra[2];
         if (o.i[6] > 1) {      // i[6] sources summed on load: in_buf[1..], coefficients f[4..6]
           po.n_extra = o.i[6] - 1;
-          for (int e = 0; e < po.n_extra; ++e) extra[e] = mkview(P, ws, o.in_buf[e + 1], o.in_coff[e + 1], o.in_C[e + 1]);
+          for (int e = 0; e < po.n_extra; ++e) {
+            extra[e] = mkview(P, ws, o.in_buf[e + 1], o.in_coff[e + 1], o.in_C[e + 1]);
+            if (has_pend && pd[e + 1].n) extra[e].pend = &pd[e + 1];
+          }
           po.extra = extra;
           for (int e = 0; e < 3; ++e) po.coef[e] = o.f[4 + e];
         }
@@ -222,11 +260,12 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
         if (h0) rc = lhn_conv_pw_fwd2(&x, prm<const float>(params, o.p[0]), bn ? nullptr : prm<const float>(params, o.p[1]), &y,
                               (training && o.ws[0] >= 0) ? reinterpret_cast<double*>(at(ws, o.ws[0])) : nullptr, o.i[0], nchw,
                               (bn && training && fuse_finalize() && whole) ? &fin : nullptr, &po, stream);
-        if (!rc && bn && h1 && !skip_tables && !(training && fuse_finalize() && whole)) rc = sep_finalize(fin, reinterpret_cast<const double*>(at(ws, o.ws[0])), training, stream);
+        if (!rc && bn && h1 && !skip_tables && !deferred && !(training && fuse_finalize() && whole)) rc = sep_finalize(fin, reinterpret_cast<const double*>(at(ws, o.ws[0])), training, stream);
         break;
       }
       case OP_DW: {
         lhn_view x = mkview(P, ws, o.in_buf[0], o.in_coff[0], o.in_C[0]);
+        if (has_pend && pd[0].n) x.pend = &pd[0];
         lhn_view y = mkview(P, ws, o.out_buf, o.out_coff, o.out_C);
         const bool bn = conv_has_bn(o);
         lhn_bnfin fin;
@@ -236,11 +275,14 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
         }
         lhn_view extra;
         const float coef2[2] = {o.f[4], o.f[5]};
-        if (o.i[6] > 1) extra = mkview(P, ws, o.in_buf[1], o.in_coff[1], o.in_C[1]);      // second source summed on load
+        if (o.i[6] > 1) {                                                                 // second source summed on load
+          extra = mkview(P, ws, o.in_buf[1], o.in_coff[1], o.in_C[1]);
+          if (has_pend && pd[1].n) extra.pend = &pd[1];
+        }
         if (h0) rc = lhn_conv_dw_fwd2(&x, prm<const float>(params, o.p[0]), &y,
                               (training && o.ws[0] >= 0) ? reinterpret_cast<double*>(at(ws, o.ws[0])) : nullptr, o.i[0], o.i[1], o.i[2], o.i[3],
                               (bn && training && fuse_finalize() && whole) ? &fin : nullptr, o.i[6] > 1 ? &extra : nullptr, coef2, stream);
-        if (!rc && bn && h1 && !skip_tables && !(training && fuse_finalize() && whole)) rc = sep_finalize(fin, reinterpret_cast<const double*>(at(ws, o.ws[0])), training, stream);
+        if (!rc && bn && h1 && !skip_tables && !deferred && !(training && fuse_finalize() && whole)) rc = sep_finalize(fin, reinterpret_cast<const double*>(at(ws, o.ws[0])), training, stream);
         break;
       }
       case OP_KXK: {
@@ -256,7 +298,7 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
                               (training && o.ws[0] >= 0) ? reinterpret_cast<double*>(at(ws, o.ws[0])) : nullptr, o.i[0],
                               (bn && training && fuse_finalize() && whole) ? &fin : nullptr,
                               o.ws[3] >= 0 ? reinterpret_cast<float*>(at(ws, o.ws[3])) : nullptr, stream);
-        if (!rc && bn && h1 && !skip_tables && !(training && fuse_finalize() && whole)) rc = sep_finalize(fin, reinterpret_cast<const double*>(at(ws, o.ws[0])), training, stream);
+        if (!rc && bn && h1 && !skip_tables && !deferred && !(training && fuse_finalize() && whole)) rc = sep_finalize(fin, reinterpret_cast<const double*>(at(ws, o.ws[0])), training, stream);
         break;
       }
       case OP_FINALIZE: {
@@ -273,7 +315,10 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
       }
       case OP_EW: {
         lhn_view srcs[3];
-        for (int k = 0; k < o.i[0]; ++k) srcs[k] = mkview(P, ws, o.in_buf[k], o.in_coff[k], o.in_C[k]);
+        for (int k = 0; k < o.i[0]; ++k) {
+          srcs[k] = mkview(P, ws, o.in_buf[k], o.in_coff[k], o.in_C[k]);
+          if (has_pend && pd[k].n) srcs[k].pend = &pd[k];
+        }
         lhn_view d = mkview(P, ws, o.out_buf, o.out_coff, o.out_C);
         const float coef[3] = {o.f[4], o.f[5], o.f[6]};
         rc = lhn_ew_fwd2(srcs, o.i[0], o.i[1] ? coef : nullptr, &d, o.f[0], stream);      // i[1]: coefficients given
@@ -281,12 +326,14 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
       }
       case OP_MAXPOOL: {
         lhn_view x = mkview(P, ws, o.in_buf[0], o.in_coff[0], o.in_C[0]);
+        if (has_pend && pd[0].n) x.pend = &pd[0];
         lhn_view y = mkview(P, ws, o.out_buf, o.out_coff, o.out_C);
         rc = lhn_maxpool2_fwd(&x, &y, stream);
         break;
       }
       case OP_AVGPOOL: {
         lhn_view x = mkview(P, ws, o.in_buf[0], o.in_coff[0], o.in_C[0], o.i[2] == 0);
+        if (has_pend && pd[0].n) x.pend = &pd[0];
         rc = lhn_avgpool_fwd(&x, reinterpret_cast<float*>(at(ws, o.ws[0])), o.i[0], o.i[1], stream);
         break;
       }

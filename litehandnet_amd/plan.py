@@ -15,6 +15,7 @@ Conventions
     channel ranges have been written (store) or must be accumulated.
 """
 import ctypes as C
+import os
 from dataclasses import dataclass, field
 
 import torch
@@ -464,7 +465,43 @@ class PlanBuilder:
             o.i[k] = i[k] if k < len(i) else 0
         for k in range(8):
             o.f[k] = f[k] if k < len(f) else 0.0
+        for k in range(3):
+            o.pend[k][0] = o.pend[k][1] = -1
         return o
+
+    DEFER_READERS = {PW: 3, DW: 2, EW: 3, MAXPOOL: 1, AVGPOOL: 1}      # op kind -> input slots whose kernels take lhn_pend
+
+    def _defer_finalizes(self, fwd):
+        """Hand every train-mode BatchNorm finalize to the FIRST forward reader of the convolution's output when that reader's
+        kernel can do it in its prologue (include/lhn.h: lhn_pend): the producer gets i[7] = 1 (no finalize launch in a plain
+        training run), the reader lists the producer in pend[slot].  Anything else keeps the separate launch."""
+        self.deferred = 0
+        for i, o in enumerate(fwd):
+            if o.kind not in (STEM, PW, DW, KXK) or o.p[2] < 0 or o.out_buf < 0 or o.ws[0] < 0 or o.out_C > 256:
+                continue
+            lo, hi = o.out_coff, o.out_coff + o.out_C
+            if self.bufs[o.out_buf].C > 256:
+                continue
+            for r in fwd[i + 1:]:
+                slots = [k for k in range(3) if r.in_buf[k] == o.out_buf and r.in_coff[k] < hi and lo < r.in_coff[k] + r.in_C[k]]
+                if r.kind in (PW, DW):
+                    slots = [k for k in slots if k < max(1, r.i[6])]      # in_buf[1..] only count for multi-source ops
+                elif r.kind in (MAXPOOL, AVGPOOL, KXK):
+                    slots = [k for k in slots if k == 0]
+                elif r.kind == EW:
+                    slots = [k for k in slots if k < r.i[0]]
+                elif r.kind not in (PW, DW, KXK):
+                    slots = []
+                if not slots:
+                    continue
+                k = slots[0]
+                ok = r.kind in self.DEFER_READERS and k < self.DEFER_READERS[r.kind] and len(slots) == 1 and \
+                    not (r.kind == PW and (r.in_C[k] > 128 or r.i[1])) and r.pend[k][1] < 0
+                if ok:
+                    r.pend[k][0 if r.pend[k][0] < 0 else 1] = i
+                    o.i[7] = 1
+                    self.deferred += 1
+                break
 
     def _xs(self, r):
         """(input views, number of sources, coefficient slots f[4..6]) of a convolution record: the operands of a lazy sum
@@ -584,6 +621,8 @@ class PlanBuilder:
                               f=(bn.eps, bn.momentum)))
             else:
                 raise AssertionError(k)
+        if os.environ.get("LHN_DEFER_FINALIZE", "1") != "0":
+            self._defer_finalizes(fwd)
         # ---------------- backward
         if self.with_backward:
             written = {}

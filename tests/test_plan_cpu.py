@@ -159,3 +159,32 @@ def test_lazy_sums_are_summed_on_load():
     # variant A: the sum in front of MSAB's closing 1x1
     _, pa, _ = _build("A", backward=False)
     assert sum(1 for r in pa.recs if r["op"] == EW and r.get("lazy")) == 2
+
+
+def test_deferred_finalizes(monkeypatch):
+    """Every train-mode BatchNorm of variant B is finalized by the first reader of its convolution's output (lhn_pend): the
+    producer is flagged, exactly one later op lists it, readers are kernels that can do it and hold at most two; the
+    switch LHN_DEFER_FINALIZE=0 restores the separate launches."""
+    from litehandnet_amd.plan import AVGPOOL, DW, EW, KXK, MAXPOOL, PW, STEM
+    _, pb, _ = _build("B", backward=True)
+    cb, cf, cbw, nf, nb = pb.finalize()
+    fwd = [cf[i] for i in range(nf)]
+    prod = [i for i, o in enumerate(fwd) if o.kind in (STEM, PW, DW, KXK) and o.p[2] >= 0]
+    assert len(prod) == 52 and pb.deferred == 52 and all(fwd[i].i[7] == 1 for i in prod)
+    listed = {}
+    for j, o in enumerate(fwd):
+        for k in range(3):
+            for e in range(2):
+                if o.pend[k][e] >= 0:
+                    assert o.kind in (PW, DW, EW, MAXPOOL, AVGPOOL) and o.pend[k][e] < j
+                    assert o.in_buf[k] == fwd[o.pend[k][e]].out_buf
+                    listed[o.pend[k][e]] = listed.get(o.pend[k][e], 0) + 1
+    assert sorted(listed) == prod and set(listed.values()) == {1}
+    # variant A keeps separate launches where the first reader is the dense 3x3 kernel
+    _, pa, _ = _build("A", backward=False)
+    pa.finalize()
+    assert 0 < pa.deferred < sum(1 for r in pa.recs if r["op"] in (STEM, PW, DW, KXK) and r["bn"] is not None)
+    monkeypatch.setenv("LHN_DEFER_FINALIZE", "0")
+    _, p0, _ = _build("B", backward=False)
+    cb, cf, _, nf, _ = p0.finalize()
+    assert all(cf[i].i[7] == 0 and all(cf[i].pend[k][e] == -1 for k in range(3) for e in range(2)) for i in range(nf))
