@@ -20,8 +20,8 @@ __global__ void __launch_bounds__(256) k_dw_fwd(lhn_view x, const float* __restr
   const int tid = threadIdx.x;
   const int c4 = tid % C4, pl = tid / C4, PL = 256 / C4;
   const int cin = x.coff + 4 * c4, cout = y.coff + 4 * c4;
-  lhn_resolve_table(x, px, smem);                     // pending BatchNorm of the input (LDS: >= 8 KB, weights staged after)
-  const Xf4 xf = lhn_load_xf(x, cin);
+  // pending BatchNorm of the input (LDS: >= 8 KB, weights staged after)
+  const Xf4 xf = lhn_load_xf_t(lhn_resolve_table(x, px, smem), x.cstride, cin);
   if (px.n > 0) __syncthreads();
   for (int i = tid; i < KK * C; i += 256) {
     const int c = i / KK, t = i - c * KK;
@@ -542,14 +542,13 @@ __global__ void __launch_bounds__(256) k_dwk_fwd_lds(lhn_view x, const float* __
   const int ntile = y.N * ps * ps * tiles_h * tiles_w * cgroups;
   const int cg = blockIdx.x % cgroups;                     // grid % cgroups == 0 (host): fixed per block
   const int cin = x.coff + cg * 32 + 4 * c4, cout = y.coff + cg * 32 + 4 * c4;
-  lhn_resolve_table(x, ex.pend[0], smem);       // (the tile region is free until the first commit, which follows a barrier)
-  const Xf4 xf = lhn_load_xf(x, cin);
+  // (the tile region is free until the first commit, which follows a barrier)
+  const Xf4 xf = lhn_load_xf_t(lhn_resolve_table(x, ex.pend[0], smem), x.cstride, cin);
   const int cin2 = NS > 1 ? ex.v.coff + cg * 32 + 4 * c4 : 0;
   Xf4 xf2;
   if (NS > 1) {
     if (ex.pend[0].n > 0 && ex.pend[1].n > 0) __syncthreads();
-    lhn_resolve_table(ex.v, ex.pend[1], smem);
-    xf2 = lhn_load_xf(ex.v, cin2);
+    xf2 = lhn_load_xf_t(lhn_resolve_table(ex.v, ex.pend[1], smem), ex.v.cstride, cin2);
   }
   for (int i = tid; i < KK * 8; i += 256) {
     const int k = i >> 3, cc = cg * 32 + 4 * (i & 7);

@@ -74,8 +74,7 @@ __global__ void __launch_bounds__(256, NS > 1 ? 1 : ((CIN == 64 && NT == 2) || (
   const bool kok = 4 * c4 < x.C;                     // channel groups beyond the view are zero columns of the tile
   const int cabs = x.coff + (kok ? 4 * c4 : 0);
   const bool pending = ex.pend[0].n > 0 || (NS > 1 && (ex.pend[1].n > 0 || ex.pend[2].n > 0));
-  lhn_resolve_table(x, ex.pend[0], smem);
-  const Xf4 xf = lhn_load_xf(x, cabs);
+  const Xf4 xf = lhn_load_xf_t(lhn_resolve_table(x, ex.pend[0], smem), x.cstride, cabs);
   const int HoWo = y.H * y.W;
   // extra sources (NS > 1): own buffer, table, gate, channel offset
   int ecabs[NS > 1 ? NS - 1 : 1];
@@ -87,8 +86,7 @@ __global__ void __launch_bounds__(256, NS > 1 ? 1 : ((CIN == 64 && NT == 2) || (
       if (e < ex.n) {
         ecabs[e] = ex.v[e].coff + (kok ? 4 * c4 : 0);
         if (pending) __syncthreads();               // the previous table copy has been read by everybody
-        lhn_resolve_table(ex.v[e], ex.pend[e + 1], smem);
-        exf[e] = lhn_load_xf(ex.v[e], ecabs[e]);
+        exf[e] = lhn_load_xf_t(lhn_resolve_table(ex.v[e], ex.pend[e + 1], smem), ex.v[e].cstride, ecabs[e]);
       }
   }
   if (pending) __syncthreads();
@@ -294,8 +292,7 @@ k_pw_fwd_wr(lhn_view x, const float* __restrict__ w, const float* __restrict__ b
   const int c4 = tid % C4, row0 = tid / C4;
   const int cabs = x.coff + 4 * c4;
   const bool pending = ex.pend[0].n > 0 || (NS > 1 && (ex.pend[1].n > 0 || ex.pend[2].n > 0));
-  lhn_resolve_table(x, ex.pend[0], smem);
-  const Xf4 xf = lhn_load_xf(x, cabs);
+  const Xf4 xf = lhn_load_xf_t(lhn_resolve_table(x, ex.pend[0], smem), x.cstride, cabs);
   const int HoWo = y.H * y.W;
   int ecabs[NS > 1 ? NS - 1 : 1];
   Xf4 exf[NS > 1 ? NS - 1 : 1];
@@ -305,8 +302,7 @@ k_pw_fwd_wr(lhn_view x, const float* __restrict__ w, const float* __restrict__ b
       if (e < ex.n) {
         ecabs[e] = ex.v[e].coff + 4 * c4;
         if (pending) __syncthreads();
-        lhn_resolve_table(ex.v[e], ex.pend[e + 1], smem);
-        exf[e] = lhn_load_xf(ex.v[e], ecabs[e]);
+        exf[e] = lhn_load_xf_t(lhn_resolve_table(ex.v[e], ex.pend[e + 1], smem), ex.v[e].cstride, ecabs[e]);
       }
   }
   if (pending) __syncthreads();               // the table copies lived in the pixel-tile buffers
@@ -530,6 +526,7 @@ extern "C" int lhn_conv_pw_fwd2(const lhn_view* x, const float* w, const float* 
       g.yacc = k0 > 0;
       g.statC = Cout;
       g.nchw_bstride = bstride;
+      if (co0 > 0 || k0 > 0) ex.pend[0].n = ex.pend[1].n = ex.pend[2].n = 0;      // later slices find the table in memory
       const int rc = pw_fwd_slice(&xv, w + (int64_t)co0 * wcols + k0, (last && bias) ? bias + co0 : nullptr, &yv,
                                   (last && stats) ? stats + co0 : nullptr, stride, y_nchw ? y_nchw + (int64_t)co0 * HoWo : nullptr,
                                   cc, single ? fin : nullptr, g, s, &ex);

@@ -95,8 +95,7 @@ __global__ void __launch_bounds__(256) k_ew_fwd(EwSrcs S, int nsrc, lhn_view dst
     if (k < nsrc) {
       ca[k] = S.v[k].coff + 4 * c4;
       if (pending && k > 0) __syncthreads();       // the previous table copy has been read by everybody
-      lhn_resolve_table(S.v[k], S.pend[k], s_res);
-      xf[k] = lhn_load_xf(S.v[k], ca[k]);
+      xf[k] = lhn_load_xf_t(lhn_resolve_table(S.v[k], S.pend[k], s_res), S.v[k].cstride, ca[k]);
     }
   for (int row = blockIdx.x; row < rows; row += gridDim.x) {
     const int n = row / dst.H, h = row - n * dst.H;
@@ -187,8 +186,7 @@ __global__ void __launch_bounds__(256) k_maxpool2_fwd(lhn_view x, lhn_view y, lh
   __shared__ __attribute__((aligned(16))) float s_res[LHN_RESOLVE_FLOATS];
   const int C4 = y.C >> 2, c4 = threadIdx.x % C4, pl = threadIdx.x / C4, PL = 256 / C4;
   const int ca = x.coff + 4 * c4;
-  lhn_resolve_table(x, px, s_res);
-  const Xf4 xf = lhn_load_xf(x, ca);
+  const Xf4 xf = lhn_load_xf_t(lhn_resolve_table(x, px, s_res), x.cstride, ca);
   const int rows = y.N * y.H;
   for (int row = blockIdx.x; row < rows; row += gridDim.x) {
     const int n = row / y.H, ho = row - n * y.H;
@@ -255,7 +253,7 @@ __global__ void __launch_bounds__(256) k_maxpool2_bwd(lhn_view x, lhn_view y, co
 __global__ void __launch_bounds__(256) k_avgpool_fwd(lhn_view x, float* __restrict__ out, int OH, int OW, lhn_pends px) {
   __shared__ f4 red[256];
   __shared__ __attribute__((aligned(16))) float s_res[LHN_RESOLVE_FLOATS];
-  lhn_resolve_table(x, px, s_res);
+  const float* xtab = lhn_resolve_table(x, px, s_res);
   const int C4 = x.C >> 2, PL = 256 / C4;
   const int b = blockIdx.x;
   const int ow = b % OW, oh = (b / OW) % OH, n = b / (OW * OH);
@@ -264,7 +262,7 @@ __global__ void __launch_bounds__(256) k_avgpool_fwd(lhn_view x, float* __restri
   const int bw = w1 - w0, cnt = (h1 - h0) * bw;
   const int c4 = threadIdx.x % C4, pl = threadIdx.x / C4;
   const int ca = x.coff + 4 * c4;
-  const Xf4 xf = lhn_load_xf(x, ca);
+  const Xf4 xf = lhn_load_xf_t(xtab, x.cstride, ca);
   // four independent loads in flight per thread; the (per-image) gate factors out of the sum
   const float* base = x.data + (int64_t)n * x.H * x.W * x.cstride + ca;
   auto at = [&](int p) { return *reinterpret_cast<const f4*>(base + (int64_t)((h0 + p / bw) * x.W + w0 + p % bw) * x.cstride); };

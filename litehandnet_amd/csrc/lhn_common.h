@@ -334,66 +334,84 @@ __device__ __forceinline__ void lhn_block_stat_atomics(f4 s, f4 q, int C4, f4* r
 // after its table loads.  On return v.table points at the block's private LDS copy [3][cstride] with the pending slices
 // filled in; block (0,0,0) has also written them to memory together with the BatchNorm's state.
 #define LHN_RESOLVE_FLOATS (3 * 256 + 2 * 2 * 256)      /* table for cstride <= 256 + double partials [g][2][C] with g*C <= 256 */
-__device__ __forceinline__ void lhn_resolve_table(lhn_view& v, const lhn_pends& P, float* scratch) {
-  if (P.n == 0) return;                       // block-uniform
-  const int cs = v.cstride, nt = blockDim.x, tid = threadIdx.x;
+__device__ __forceinline__ void lhn_resolve_one(const lhn_pend& p, float* tab, double* part, float* gtab, int cs, bool first) {
+  const int C = p.C, nt = blockDim.x, tid = threadIdx.x;
+  int ng = nt / C;                          // replica groups summed in parallel (C <= 256 = the tables this handles)
+  ng = ng < 1 ? 1 : (ng > 8 ? 8 : ng);
+  __syncthreads();
+  for (int t = tid; t < ng * C; t += nt) {
+    const int c = t % C, g = t / C;
+    double s1 = 0, s2 = 0;
+    for (int r = g; r < LHN_STAT_REPLICAS; r += ng) {
+      s1 += p.stats[(size_t)r * 2 * C + c];
+      s2 += p.stats[(size_t)r * 2 * C + C + c];
+    }
+    part[(g * 2 + 0) * C + c] = s1;
+    part[(g * 2 + 1) * C + c] = s2;
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += nt) {
+    double s1 = 0, s2 = 0;
+    for (int g = 0; g < ng; ++g) {
+      s1 += part[(g * 2 + 0) * C + c];
+      s2 += part[(g * 2 + 1) * C + c];
+    }
+    const double mean = s1 / p.count;
+    double var = s2 / p.count - mean * mean;
+    if (var < 0) var = 0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)p.eps));
+    const float gm = p.gamma ? p.gamma[c] : 1.f, bt = p.beta ? p.beta[c] : 0.f;
+    const float sc = gm * invstd, sh = bt - (float)mean * sc;
+    tab[p.coff + c] = sc;
+    tab[cs + p.coff + c] = sh;
+    tab[2 * cs + p.coff + c] = p.slope;
+    if (first) {
+      gtab[p.coff + c] = sc;
+      gtab[cs + p.coff + c] = sh;
+      gtab[2 * cs + p.coff + c] = p.slope;
+      if (p.running_mean) {
+        const double bm = mean + (p.conv_bias ? (double)p.conv_bias[c] : 0.0);
+        p.running_mean[c] = (float)((1.0 - (double)p.momentum) * (double)p.running_mean[c] + (double)p.momentum * bm);
+        const double unb = p.count > 1 ? var * p.count / (p.count - 1.0) : var;
+        p.running_var[c] = (float)((1.0 - (double)p.momentum) * (double)p.running_var[c] + (double)p.momentum * unb);
+      }
+      if (p.save_mean_invstd) {
+        p.save_mean_invstd[c] = (float)mean;
+        p.save_mean_invstd[C + c] = invstd;
+      }
+    }
+  }
+  if (first && tid == 0 && p.num_batches_tracked) p.num_batches_tracked[0] += 1;
+}
+// Returns the table to read the view's pending transform from: v.table when nothing is pending, else the block's LDS copy.
+// (Nothing here writes to a kernel argument or indexes one dynamically: either would push the argument struct into
+// scratch memory.)
+__device__ __forceinline__ const float* lhn_resolve_table(const lhn_view& v, const lhn_pends& P, float* scratch) {
+  if (P.n == 0) return v.table;               // block-uniform
+  const int cs = v.cstride;
   float* tab = scratch;
   double* part = reinterpret_cast<double*>(scratch + 3 * 256);
   float* gtab = const_cast<float*>(v.table);
   const bool first = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
-  for (int i = tid; i < 3 * cs; i += nt) tab[i] = gtab[i];
-  for (int k = 0; k < P.n; ++k) {
-    const lhn_pend& p = P.p[k];
-    const int C = p.C;
-    int ng = nt / C;                          // replica groups summed in parallel (C <= 256 = the tables this handles)
-    ng = ng < 1 ? 1 : (ng > 8 ? 8 : ng);
-    __syncthreads();
-    for (int t = tid; t < ng * C; t += nt) {
-      const int c = t % C, g = t / C;
-      double s1 = 0, s2 = 0;
-      for (int r = g; r < LHN_STAT_REPLICAS; r += ng) {
-        s1 += p.stats[(size_t)r * 2 * C + c];
-        s2 += p.stats[(size_t)r * 2 * C + C + c];
-      }
-      part[(g * 2 + 0) * C + c] = s1;
-      part[(g * 2 + 1) * C + c] = s2;
-    }
-    __syncthreads();
-    for (int c = tid; c < C; c += nt) {
-      double s1 = 0, s2 = 0;
-      for (int g = 0; g < ng; ++g) {
-        s1 += part[(g * 2 + 0) * C + c];
-        s2 += part[(g * 2 + 1) * C + c];
-      }
-      const double mean = s1 / p.count;
-      double var = s2 / p.count - mean * mean;
-      if (var < 0) var = 0;
-      const float invstd = (float)(1.0 / sqrt(var + (double)p.eps));
-      const float gm = p.gamma ? p.gamma[c] : 1.f, bt = p.beta ? p.beta[c] : 0.f;
-      const float sc = gm * invstd, sh = bt - (float)mean * sc;
-      tab[p.coff + c] = sc;
-      tab[cs + p.coff + c] = sh;
-      tab[2 * cs + p.coff + c] = p.slope;
-      if (first) {
-        gtab[p.coff + c] = sc;
-        gtab[cs + p.coff + c] = sh;
-        gtab[2 * cs + p.coff + c] = p.slope;
-        if (p.running_mean) {
-          const double bm = mean + (p.conv_bias ? (double)p.conv_bias[c] : 0.0);
-          p.running_mean[c] = (float)((1.0 - (double)p.momentum) * (double)p.running_mean[c] + (double)p.momentum * bm);
-          const double unb = p.count > 1 ? var * p.count / (p.count - 1.0) : var;
-          p.running_var[c] = (float)((1.0 - (double)p.momentum) * (double)p.running_var[c] + (double)p.momentum * unb);
-        }
-        if (p.save_mean_invstd) {
-          p.save_mean_invstd[c] = (float)mean;
-          p.save_mean_invstd[C + c] = invstd;
-        }
-      }
-    }
-    if (first && tid == 0 && p.num_batches_tracked) p.num_batches_tracked[0] += 1;
-  }
+  for (int i = threadIdx.x; i < 3 * cs; i += blockDim.x) tab[i] = gtab[i];
+  lhn_resolve_one(P.p[0], tab, part, gtab, cs, first);
+  if (P.n > 1) lhn_resolve_one(P.p[1], tab, part, gtab, cs, first);
   __syncthreads();
-  v.table = tab;
+  return tab;
+}
+// lhn_load_xf from an explicit table pointer (global or the LDS copy above); tab == NULL = identity
+__device__ __forceinline__ Xf4 lhn_load_xf_t(const float* tab, int cstride, int c_abs) {
+  Xf4 t;
+  if (tab) {
+    t.sc = *reinterpret_cast<const f4*>(tab + c_abs);
+    t.sh = *reinterpret_cast<const f4*>(tab + cstride + c_abs);
+    t.sl = *reinterpret_cast<const f4*>(tab + 2 * cstride + c_abs);
+  } else {
+    t.sc = (f4){1.f, 1.f, 1.f, 1.f};
+    t.sh = (f4){0.f, 0.f, 0.f, 0.f};
+    t.sl = (f4){1.f, 1.f, 1.f, 1.f};
+  }
+  return t;
 }
 
 __device__ __forceinline__ float lhn_wave_sum(float v) {

@@ -573,7 +573,14 @@ class PlanBuilder:
                     fwd.append(mk(KXK, ins=(x,), out=out, p=(pw, cb) + pbn, ws=(tuple(wsl) + (-1, -1, -1))[:3] + (self._abs(r["wt"]),),
                                   i=(r["stride"],), f=fl))
             elif k == EW:
-                if not r.get("lazy"):
+                if r.get("lazy"):
+                    continue
+                if "flat" in r:
+                    # a lazy sum that had to be materialised after all (a reader that cannot add on load): launched on the
+                    # flattened operand list -- an operand that is itself a lazy sum has never been written
+                    fl = r["flat"]
+                    fwd.append(mk(EW, ins=[t for t, _ in fl], out=r["out"], i=(len(fl), 1), f=(r["slope"], 0.0, 0.0, 0.0) + tuple(c for _, c in fl)))
+                else:
                     fwd.append(mk(EW, ins=r["srcs"], out=r["out"], i=(len(r["srcs"]),), f=(r["slope"],)))
             elif k == MAXPOOL:
                 fwd.append(mk(MAXPOOL, ins=(r["x"],), out=r["out"]))
