@@ -32,13 +32,14 @@ __global__ void __launch_bounds__(256) k_dw_fwd(lhn_view x, const float* __restr
 #pragma unroll
   for (int t = 0; t < KK; ++t) wt[t] = *reinterpret_cast<const f4*>(Ws + t * C + 4 * c4);
   const int rows = y.N * y.H;
-  f4 s = (f4){0.f, 0.f, 0.f, 0.f}, q = s;
+  double sd[4] = {0, 0, 0, 0}, qd[4] = {0, 0, 0, 0};      // per-row fp32 partials promoted to double (see k_conv_pw.hip)
   for (int row = blockIdx.x; row < rows; row += gridDim.x) {
     const int n = row / y.H, ho = row - n * y.H;
     const float* xin = x.data + (size_t)n * x.H * x.W * x.cstride + cin;
     f4 gate = (f4){1.f, 1.f, 1.f, 1.f};
     if (x.gate) gate = *reinterpret_cast<const f4*>(x.gate + (size_t)n * x.cstride + cin);
     float* yout = y.data + (size_t)row * y.W * y.cstride + cout;
+    f4 s = (f4){0.f, 0.f, 0.f, 0.f}, q = s;
     for (int wo = pl; wo < y.W; wo += PL) {
       f4 acc = (f4){0.f, 0.f, 0.f, 0.f};
       // branch-free taps: clamped (always in-bounds) addresses, so all K*K loads issue back to back
@@ -66,26 +67,39 @@ __global__ void __launch_bounds__(256) k_dw_fwd(lhn_view x, const float* __restr
       s += acc;
       q += acc * acc;
     }
+    sd[0] += s.x; sd[1] += s.y; sd[2] += s.z; sd[3] += s.w;
+    qd[0] += q.x; qd[1] += q.y; qd[2] += q.z; qd[3] += q.w;
   }
   if (stats) {
     double* st = stats + (size_t)(blockIdx.x % LHN_STAT_REPLICAS) * 2 * C;
+    double* redd = reinterpret_cast<double*>(red);          // [256][2] float4 = 1024 doubles
     if (C4 <= 32) {
-      lhn_block_stat_atomics(s, q, C4, red, st, st + C);
-    } else {
-      red[tid * 2] = s;
-      red[tid * 2 + 1] = q;
+      lhn_block_stat_atomics_d(sd, qd, C4, redd, st, st + C);
+    } else {                                                // C = 256: one thread per (channel group, pixel lane), PL = 4
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        redd[tid * 4 + j] = sd[j];
+      }
+      __syncthreads();
+      double ts[4] = {0, 0, 0, 0};
+      if (tid < C4)
+        for (int j = 0; j < PL; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ts[e] += redd[(j * C4 + tid) * 4 + e];
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 4; ++j) redd[tid * 4 + j] = qd[j];
       __syncthreads();
       if (tid < C4) {
-        double sd[4] = {0, 0, 0, 0}, qd[4] = {0, 0, 0, 0};
-        for (int j = 0; j < PL; ++j) {
-          const f4 a = red[(j * C4 + tid) * 2], b = red[(j * C4 + tid) * 2 + 1];
-          sd[0] += a.x; sd[1] += a.y; sd[2] += a.z; sd[3] += a.w;
-          qd[0] += b.x; qd[1] += b.y; qd[2] += b.z; qd[3] += b.w;
-        }
+        double tq[4] = {0, 0, 0, 0};
+        for (int j = 0; j < PL; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) tq[e] += redd[(j * C4 + tid) * 4 + e];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          atomicAdd(st + 4 * tid + j, sd[j]);
-          atomicAdd(st + C + 4 * tid + j, qd[j]);
+          atomicAdd(st + 4 * tid + j, ts[j]);
+          atomicAdd(st + C + 4 * tid + j, tq[j]);
         }
       }
     }
@@ -542,19 +556,13 @@ __global__ void __launch_bounds__(256) k_dwk_fwd_lds(lhn_view x, const float* __
   const int ntile = y.N * ps * ps * tiles_h * tiles_w * cgroups;
   const int cg = blockIdx.x % cgroups;                     // grid % cgroups == 0 (host): fixed per block
   const int cin = x.coff + cg * 32 + 4 * c4, cout = y.coff + cg * 32 + 4 * c4;
-  // (the tile region is free until the first commit, which follows a barrier)
-  const Xf4 xf = lhn_load_xf_t(lhn_resolve_table(x, ex.pend[0], smem), x.cstride, cin);
   const int cin2 = NS > 1 ? ex.v.coff + cg * 32 + 4 * c4 : 0;
-  Xf4 xf2;
-  if (NS > 1) {
-    if (ex.pend[0].n > 0 && ex.pend[1].n > 0) __syncthreads();
-    xf2 = lhn_load_xf_t(lhn_resolve_table(ex.v, ex.pend[1], smem), ex.v.cstride, cin2);
-  }
+  Xf4 xf, xf2;        // filled after the first tile's loads have been issued (pending BatchNorms are finalized meanwhile)
   for (int i = tid; i < KK * 8; i += 256) {
     const int k = i >> 3, cc = cg * 32 + 4 * (i & 7);
     wl[i] = (f4){w[(cc + 0) * KK + k], w[(cc + 1) * KK + k], w[(cc + 2) * KK + k], w[(cc + 3) * KK + k]};
   }
-  f4 s = (f4){0.f, 0.f, 0.f, 0.f}, q = s;
+  double sd[4] = {0, 0, 0, 0}, qd[4] = {0, 0, 0, 0};      // per-tile fp32 partials promoted to double (see k_conv_pw.hip)
   // halo staging in two phases: issue() sends every global load of a tile (clamped coordinates, no branches, so they
   // are all in flight together) into registers one tile AHEAD; commit() transforms, zeroes the padding and writes LDS
   constexpr int NIT = (T::PIX + 31) / 32;
@@ -569,7 +577,6 @@ __global__ void __launch_bounds__(256) k_dwk_fwd_lds(lhn_view x, const float* __
     const int SH = (x.H - pa + ps - 1) / ps, SW = (x.W - pb + ps - 1) / ps;     // sub-lattice extent
     const int h0 = th * TH - T::P, w0 = tw * TW - T::P;
     const float* xin = x.data + (size_t)n * x.H * x.W * x.cstride + cin;
-    const float* xin2 = NS > 1 ? ex.v.data + (size_t)n * x.H * x.W * ex.v.cstride + cin2 : nullptr;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int i = min(pl + 32 * it, T::PIX - 1);
@@ -577,11 +584,36 @@ __global__ void __launch_bounds__(256) k_dwk_fwd_lds(lhn_view x, const float* __
       const int ih = pa + ps * min(max(h0 + ph, 0), max(SH - 1, 0)), iw = pb + ps * min(max(w0 + pw, 0), max(SW - 1, 0));
       const size_t pix = (size_t)min(ih, x.H - 1) * x.W + min(iw, x.W - 1);
       raw[it] = *reinterpret_cast<const f4*>(xin + pix * x.cstride);
-      if (NS > 1) raw2[it] = *reinterpret_cast<const f4*>(xin2 + pix * ex.v.cstride);
+    }
+  };
+  // second source: loaded at commit time, NOT a tile ahead (44 more live registers would drop the kernel to one block per
+  // CU); the other resident block covers the latency
+  auto issue2 = [&](int t) __attribute__((always_inline)) {
+    int r = t / cgroups;
+    const int tw = r % tiles_w;
+    r /= tiles_w;
+    const int th = r % tiles_h;
+    r /= tiles_h;
+    const int par = r % (ps * ps), n = r / (ps * ps), pa = par / ps, pb = par % ps;
+    const int SH = (x.H - pa + ps - 1) / ps, SW = (x.W - pb + ps - 1) / ps;
+    const int h0 = th * TH - T::P, w0 = tw * TW - T::P;
+    const float* xin2 = ex.v.data + (size_t)n * x.H * x.W * ex.v.cstride + cin2;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int i = min(pl + 32 * it, T::PIX - 1);
+      const int ph = i / T::WW, pw = i - ph * T::WW;
+      const int ih = pa + ps * min(max(h0 + ph, 0), max(SH - 1, 0)), iw = pb + ps * min(max(w0 + pw, 0), max(SW - 1, 0));
+      raw2[it] = *reinterpret_cast<const f4*>(xin2 + ((size_t)min(ih, x.H - 1) * x.W + min(iw, x.W - 1)) * ex.v.cstride);
     }
   };
   int t = blockIdx.x;
   if (t < ntile) issue(t);
+  // (the tile region is free until the first commit, which follows a barrier)
+  xf = lhn_load_xf_t(lhn_resolve_table(x, ex.pend[0], smem), x.cstride, cin);
+  if (NS > 1) {
+    if (ex.pend[0].n > 0 && ex.pend[1].n > 0) __syncthreads();
+    xf2 = lhn_load_xf_t(lhn_resolve_table(ex.v, ex.pend[1], smem), ex.v.cstride, cin2);
+  }
   for (; t < ntile; t += gridDim.x) {
     int r = t / cgroups;
     const int tw = r % tiles_w;
@@ -597,6 +629,7 @@ __global__ void __launch_bounds__(256) k_dwk_fwd_lds(lhn_view x, const float* __
       gate2 = (ex.v.gate ? *reinterpret_cast<const f4*>(ex.v.gate + (size_t)n * ex.v.cstride + cin2) : (f4){1.f, 1.f, 1.f, 1.f}) * ex.coef[1];
     }
     const int h0 = th * TH - T::P, w0 = tw * TW - T::P;
+    if (NS > 1) issue2(t);
     __syncthreads();   // previous tile fully consumed (and wl visible)
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -613,6 +646,7 @@ __global__ void __launch_bounds__(256) k_dwk_fwd_lds(lhn_view x, const float* __
     __syncthreads();
     if (t + (int)gridDim.x < ntile) issue(t + gridDim.x);
     const int wo = tw * TW + pl;
+    f4 s = (f4){0.f, 0.f, 0.f, 0.f}, q = s;
     if (wo < SW) {
       const f4* col = tile + (pl + T::P) * 8 + c4;    // centre column of this thread, tile row 0
       float* yout = y.data + ((size_t)(n * y.H + pa + ps * th * TH) * y.W + pb + ps * wo) * y.cstride + cout;
@@ -659,11 +693,13 @@ __global__ void __launch_bounds__(256) k_dwk_fwd_lds(lhn_view x, const float* __
         }
       }
     }
+    sd[0] += s.x; sd[1] += s.y; sd[2] += s.z; sd[3] += s.w;
+    qd[0] += q.x; qd[1] += q.y; qd[2] += q.z; qd[3] += q.w;
   }
   if (stats) {
     const int C = x.C;
     double* st = stats + (size_t)((blockIdx.x / cgroups) % LHN_STAT_REPLICAS) * 2 * C + cg * 32;
-    lhn_block_stat_atomics(s, q, 8, red, st, st + C);
+    lhn_block_stat_atomics_d(sd, qd, 8, reinterpret_cast<double*>(red), st, st + C);
     if (fin.counter && lhn_last_block(fin.counter)) lhn_bn_finalize_block(fin, stats);
   }
 }

@@ -77,9 +77,9 @@ __global__ void __launch_bounds__(256) k_kxk(lhn_view x, const float* __restrict
   const Xf4 xf = lhn_load_xf(av, cabs);
   Gr4 gr;
   if (MODE == 1) gr = lhn_load_coef(gy, y.cstride, cabs);
-  float ssum[NT], ssq[NT];
+  double ssum[NT], ssq[NT];          // per-tile fp32 partials promoted to double (see k_conv_pw.hip)
 #pragma unroll
-  for (int j = 0; j < NT; ++j) ssum[j] = ssq[j] = 0.f;
+  for (int j = 0; j < NT; ++j) ssum[j] = ssq[j] = 0.0;
 
   constexpr bool LIN = (TAPS == 1);        // 1x1: launched with stride 1 only -> rows are linear pixel indices
   int rn[LIN ? 1 : PF], rh[LIN ? 1 : PF], rw[LIN ? 1 : PF];
@@ -258,6 +258,7 @@ __global__ void __launch_bounds__(256) k_kxk(lhn_view x, const float* __restrict
     for (int j = 0; j < NT; ++j) {
       const int ch = n0 + j * 32 + l31;
       if (ch >= nout) continue;
+      float ts = 0.f, tq = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = mbase + (r & 3) + 8 * (r >> 2);
@@ -265,8 +266,8 @@ __global__ void __launch_bounds__(256) k_kxk(lhn_view x, const float* __restrict
           const float v = acc[j][r];
           if (MODE == 0) {
             y.data[(size_t)m * y.cstride + y.coff + ch] = v;
-            ssum[j] += v;
-            ssq[j] += v * v;
+            ts += v;
+            tq += v * v;
           } else {
             size_t pix = (size_t)m;
             if (par) {
@@ -278,17 +279,22 @@ __global__ void __launch_bounds__(256) k_kxk(lhn_view x, const float* __restrict
           }
         }
       }
+      if (MODE == 0) {
+        ssum[j] += (double)ts;
+        ssq[j] += (double)tq;
+      }
     }
   }
   if (MODE == 0 && stats) {
     __syncthreads();
+    double* redd = reinterpret_cast<double*>(As);        // [4][32*NT][2] doubles inside the (now idle) A tile
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      const float s = ssum[j] + __shfl_xor(ssum[j], 32, 64);
-      const float q = ssq[j] + __shfl_xor(ssq[j], 32, 64);
+      const double s = ssum[j] + __shfl_xor(ssum[j], 32, 64);
+      const double q = ssq[j] + __shfl_xor(ssq[j], 32, 64);
       if (lh == 0) {
-        red[(wave * 32 * NT + j * 32 + l31) * 2 + 0] = s;
-        red[(wave * 32 * NT + j * 32 + l31) * 2 + 1] = q;
+        redd[(wave * 32 * NT + j * 32 + l31) * 2 + 0] = s;
+        redd[(wave * 32 * NT + j * 32 + l31) * 2 + 1] = q;
       }
     }
     __syncthreads();
@@ -296,8 +302,8 @@ __global__ void __launch_bounds__(256) k_kxk(lhn_view x, const float* __restrict
       double s = 0, q = 0;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        s += (double)red[(k * 32 * NT + tid) * 2 + 0];
-        q += (double)red[(k * 32 * NT + tid) * 2 + 1];
+        s += redd[(k * 32 * NT + tid) * 2 + 0];
+        q += redd[(k * 32 * NT + tid) * 2 + 1];
       }
       double* st = stats + (size_t)(blockIdx.x % LHN_STAT_REPLICAS) * 2 * nout;
       atomicAdd(st + n0 + tid, s);

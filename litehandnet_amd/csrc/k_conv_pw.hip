@@ -136,10 +136,13 @@ __global__ void __launch_bounds__(256, NS > 1 ? 1 : ((CIN == 64 && NT == 2) || (
     }
   };
 
-  float ssum[NT], ssq[NT], bv[NT];
+  // BatchNorm statistics: fp32 partial sums over ONE tile (16 values per lane), promoted to double per tile -- a running
+  // fp32 sum of squares over thousands of pixels loses the variance when |mean| >> sigma (E[x^2] - E[x]^2 cancels)
+  double ssum[NT], ssq[NT];
+  float bv[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    ssum[nt] = ssq[nt] = 0.f;
+    ssum[nt] = ssq[nt] = 0.0;
     const int ch = nt * 32 + l31;
     bv[nt] = (bias && ch < geo.wrows) ? bias[ch] : 0.f;
   }
@@ -193,6 +196,7 @@ __global__ void __launch_bounds__(256, NS > 1 ? 1 : ((CIN == 64 && NT == 2) || (
           }
         }
       } else {
+        float ts = 0.f, tq = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int m = mbase + (r & 3) + 8 * (r >> 2);
@@ -201,23 +205,26 @@ __global__ void __launch_bounds__(256, NS > 1 ? 1 : ((CIN == 64 && NT == 2) || (
             float v = acc[nt][r] + bv[nt];
             if (geo.yacc) v += *dst;
             *dst = v;
-            ssum[nt] += v;
-            ssq[nt] += v * v;
+            ts += v;
+            tq += v * v;
           }
         }
+        ssum[nt] += (double)ts;
+        ssq[nt] += (double)tq;
       }
     }
     __syncthreads();
   }
 
   if (stats) {
+    double* redd = reinterpret_cast<double*>(red);       // [4][32*NT][2] doubles: 8 KB at NT = 4, inside the A tile
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      const float s = ssum[nt] + __shfl_xor(ssum[nt], 32, 64);
-      const float q = ssq[nt] + __shfl_xor(ssq[nt], 32, 64);
+      const double s = ssum[nt] + __shfl_xor(ssum[nt], 32, 64);
+      const double q = ssq[nt] + __shfl_xor(ssq[nt], 32, 64);
       if (lh == 0) {
-        red[(wave * 32 * NT + nt * 32 + l31) * 2 + 0] = s;
-        red[(wave * 32 * NT + nt * 32 + l31) * 2 + 1] = q;
+        redd[(wave * 32 * NT + nt * 32 + l31) * 2 + 0] = s;
+        redd[(wave * 32 * NT + nt * 32 + l31) * 2 + 1] = q;
       }
     }
     __syncthreads();
@@ -225,8 +232,8 @@ __global__ void __launch_bounds__(256, NS > 1 ? 1 : ((CIN == 64 && NT == 2) || (
       double s = 0, q = 0;
 #pragma unroll
       for (int wv = 0; wv < 4; ++wv) {
-        s += (double)red[(wv * 32 * NT + tid) * 2 + 0];
-        q += (double)red[(wv * 32 * NT + tid) * 2 + 1];
+        s += redd[(wv * 32 * NT + tid) * 2 + 0];
+        q += redd[(wv * 32 * NT + tid) * 2 + 1];
       }
       double* st = stats + (size_t)(blockIdx.x % LHN_STAT_REPLICAS) * 2 * geo.statC;
       atomicAdd(st + tid, s);
@@ -292,21 +299,15 @@ k_pw_fwd_wr(lhn_view x, const float* __restrict__ w, const float* __restrict__ b
   const int c4 = tid % C4, row0 = tid / C4;
   const int cabs = x.coff + 4 * c4;
   const bool pending = ex.pend[0].n > 0 || (NS > 1 && (ex.pend[1].n > 0 || ex.pend[2].n > 0));
-  const Xf4 xf = lhn_load_xf_t(lhn_resolve_table(x, ex.pend[0], smem), x.cstride, cabs);
   const int HoWo = y.H * y.W;
   int ecabs[NS > 1 ? NS - 1 : 1];
-  Xf4 exf[NS > 1 ? NS - 1 : 1];
   if (NS > 1) {
 #pragma unroll
     for (int e = 0; e < NS - 1; ++e)
-      if (e < ex.n) {
-        ecabs[e] = ex.v[e].coff + 4 * c4;
-        if (pending) __syncthreads();
-        exf[e] = lhn_load_xf_t(lhn_resolve_table(ex.v[e], ex.pend[e + 1], smem), ex.v[e].cstride, ecabs[e]);
-      }
+      if (e < ex.n) ecabs[e] = ex.v[e].coff + 4 * c4;
   }
-  if (pending) __syncthreads();               // the table copies lived in the pixel-tile buffers
   f4 pre[PF], epre[NS > 1 ? NS - 1 : 1][PF];
+  Xf4 xf, exf[NS > 1 ? NS - 1 : 1];          // filled after the first tile's loads have been issued (see below)
   auto issue = [&](int tile) __attribute__((always_inline)) {
 #pragma unroll
     for (int p = 0; p < PF; ++p) {
@@ -343,10 +344,20 @@ k_pw_fwd_wr(lhn_view x, const float* __restrict__ w, const float* __restrict__ b
     }
   };
 
-  float ssum = 0.f, ssq = 0.f;
+  double ssum = 0.0, ssq = 0.0;       // fp32 partials per tile, promoted per tile (see k_pw_fwd)
   int tile = blockIdx.x, buf = 0;
+  if (tile < ntiles) issue(tile);     // the first tile's loads are in flight while pending BatchNorms are finalized
+  xf = lhn_load_xf_t(lhn_resolve_table(x, ex.pend[0], smem), x.cstride, cabs);
+  if (NS > 1) {
+#pragma unroll
+    for (int e = 0; e < NS - 1; ++e)
+      if (e < ex.n) {
+        if (pending) __syncthreads();
+        exf[e] = lhn_load_xf_t(lhn_resolve_table(ex.v[e], ex.pend[e + 1], smem), ex.v[e].cstride, ecabs[e]);
+      }
+  }
+  if (pending) __syncthreads();               // the table copies lived in the pixel-tile buffers
   if (tile < ntiles) {
-    issue(tile);
     commit(tile, smem);
     if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x);
   }
@@ -375,25 +386,28 @@ k_pw_fwd_wr(lhn_view x, const float* __restrict__ w, const float* __restrict__ b
     if (co < cout) {
       const int mbase = tile * BM + pxs * 32 + 4 * lh;
       float* yo = y.data + y.coff + co;
+      float ts = 0.f, tq = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = mbase + (r & 3) + 8 * (r >> 2);
         if (m < M) {
           const float v = acc[r] + bv;
           yo[(int64_t)m * y.cstride] = v;
-          ssum += v;
-          ssq += v * v;
+          ts += v;
+          tq += v * v;
         }
       }
+      ssum += (double)ts;
+      ssq += (double)tq;
     }
     __syncthreads();
   }
   if (stats && co < cout) {
-    const float s = ssum + __shfl_xor(ssum, 32, 64), q = ssq + __shfl_xor(ssq, 32, 64);
+    const double s = ssum + __shfl_xor(ssum, 32, 64), q = ssq + __shfl_xor(ssq, 32, 64);
     if (lh == 0) {
       double* st = stats + (size_t)(blockIdx.x % LHN_STAT_REPLICAS) * 2 * cout;
-      atomicAdd(st + co, (double)s);
-      atomicAdd(st + cout + co, (double)q);
+      atomicAdd(st + co, s);
+      atomicAdd(st + cout + co, q);
     }
   }
 }

@@ -35,7 +35,7 @@ static inline int lhn_pend_ok(const lhn_view* v) {      // what lhn_resolve_tabl
   if (v->pend->n < 0 || v->pend->n > 2 || v->cstride > 256 || !v->table) return 0;
   for (int k = 0; k < v->pend->n; ++k) {
     const lhn_pend& p = v->pend->p[k];
-    if (!p.stats || p.C <= 0 || p.C > 256 || p.coff < 0 || p.coff + p.C > v->cstride || p.count < 1) return 0;
+    if (!p.stats || p.C <= 0 || p.C > 128 || p.coff < 0 || p.coff + p.C > v->cstride || p.count < 1) return 0;
   }
   return 1;
 }
@@ -333,13 +333,17 @@ __device__ __forceinline__ void lhn_block_stat_atomics(f4 s, f4 q, int C4, f4* r
 // the view.  scratch: >= LHN_RESOLVE_FLOATS floats of LDS that nothing else uses until the caller's next __syncthreads()
 // after its table loads.  On return v.table points at the block's private LDS copy [3][cstride] with the pending slices
 // filled in; block (0,0,0) has also written them to memory together with the BatchNorm's state.
-#define LHN_RESOLVE_FLOATS (3 * 256 + 2 * 2 * 256)      /* table for cstride <= 256 + double partials [g][2][C] with g*C <= 256 */
-__device__ __forceinline__ void lhn_resolve_one(const lhn_pend& p, float* tab, double* part, float* gtab, int cs, bool first) {
-  const int C = p.C, nt = blockDim.x, tid = threadIdx.x;
-  int ng = nt / C;                          // replica groups summed in parallel (C <= 256 = the tables this handles)
+#define LHN_RESOLVE_FLOATS (3 * 256 + 2 * 2 * 256)      /* table for cstride <= 256 + double partials [g][2][C] (g*C <= 128) of two slices */
+// Two phases, two barriers: (A) every thread issues its share of ALL global loads at once -- the table copy and, per
+// pending slice, the replicated sums of its (channel, replica group) -- and parks partial sums in LDS; (B) one thread per
+// channel folds the groups, computes (scale, shift) and fills the LDS table.  The latency is one round of L2 loads plus the
+// double-precision divide / sqrt (the first version walked through four dependent phases and cost as much as the launch
+// it replaced).
+__device__ __forceinline__ void lhn_resolve_A(const lhn_pend& p, double* part) {
+  const int C = p.C, nt = blockDim.x;
+  int ng = 128 / C;                         // replica groups summed in parallel; ng * C <= 128 (the partials' LDS budget)
   ng = ng < 1 ? 1 : (ng > 8 ? 8 : ng);
-  __syncthreads();
-  for (int t = tid; t < ng * C; t += nt) {
+  for (int t = threadIdx.x; t < ng * C; t += nt) {
     const int c = t % C, g = t / C;
     double s1 = 0, s2 = 0;
     for (int r = g; r < LHN_STAT_REPLICAS; r += ng) {
@@ -349,8 +353,12 @@ __device__ __forceinline__ void lhn_resolve_one(const lhn_pend& p, float* tab, d
     part[(g * 2 + 0) * C + c] = s1;
     part[(g * 2 + 1) * C + c] = s2;
   }
-  __syncthreads();
-  for (int c = tid; c < C; c += nt) {
+}
+__device__ __forceinline__ void lhn_resolve_B(const lhn_pend& p, float* tab, const double* part, float* gtab, int cs, bool first) {
+  const int C = p.C, nt = blockDim.x;
+  int ng = 128 / C;
+  ng = ng < 1 ? 1 : (ng > 8 ? 8 : ng);
+  for (int c = threadIdx.x; c < C; c += nt) {
     double s1 = 0, s2 = 0;
     for (int g = 0; g < ng; ++g) {
       s1 += part[(g * 2 + 0) * C + c];
@@ -381,21 +389,26 @@ __device__ __forceinline__ void lhn_resolve_one(const lhn_pend& p, float* tab, d
       }
     }
   }
-  if (first && tid == 0 && p.num_batches_tracked) p.num_batches_tracked[0] += 1;
+  if (first && threadIdx.x == 0 && p.num_batches_tracked) p.num_batches_tracked[0] += 1;
 }
 // Returns the table to read the view's pending transform from: v.table when nothing is pending, else the block's LDS copy.
 // (Nothing here writes to a kernel argument or indexes one dynamically: either would push the argument struct into
-// scratch memory.)
+// scratch memory.)  The caller needs a __syncthreads() between its last read of the returned table and its next use of
+// `scratch`.
 __device__ __forceinline__ const float* lhn_resolve_table(const lhn_view& v, const lhn_pends& P, float* scratch) {
   if (P.n == 0) return v.table;               // block-uniform
   const int cs = v.cstride;
   float* tab = scratch;
-  double* part = reinterpret_cast<double*>(scratch + 3 * 256);
+  double* part0 = reinterpret_cast<double*>(scratch + 3 * 256);
+  double* part1 = part0 + 256;
   float* gtab = const_cast<float*>(v.table);
   const bool first = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
   for (int i = threadIdx.x; i < 3 * cs; i += blockDim.x) tab[i] = gtab[i];
-  lhn_resolve_one(P.p[0], tab, part, gtab, cs, first);
-  if (P.n > 1) lhn_resolve_one(P.p[1], tab, part, gtab, cs, first);
+  lhn_resolve_A(P.p[0], part0);
+  if (P.n > 1) lhn_resolve_A(P.p[1], part1);
+  __syncthreads();
+  lhn_resolve_B(P.p[0], tab, part0, gtab, cs, first);
+  if (P.n > 1) lhn_resolve_B(P.p[1], tab, part1, gtab, cs, first);
   __syncthreads();
   return tab;
 }
@@ -412,6 +425,31 @@ __device__ __forceinline__ Xf4 lhn_load_xf_t(const float* tab, int cstride, int 
     t.sl = (f4){1.f, 1.f, 1.f, 1.f};
   }
   return t;
+}
+
+// The same reduction for DOUBLE per-thread sums (convolution epilogues promote their per-tile fp32 partials to double: a
+// running fp32 sum of squares over thousands of pixels loses the variance when |mean| >> sigma).  red: >= 32*C4 doubles.
+__device__ __forceinline__ void lhn_block_stat_atomics_d(const double (&s)[4], const double (&q)[4], int C4, double* red,
+                                                         double* st0, double* st1) {
+  double v[8] = {s[0], s[1], s[2], s[3], q[0], q[1], q[2], q[3]};
+  for (int o = C4; o < 64; o <<= 1) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] += __shfl_xor(v[i], o, 64);
+  }
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __syncthreads();
+  if (lane < C4) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) red[(wave * C4 + lane) * 8 + i] = v[i];
+  }
+  __syncthreads();
+  if (tid < 8 * C4) {
+    const int kind = tid / (4 * C4), r = tid - kind * 4 * C4, cc = r >> 2, jj = r & 3;
+    double t = 0;
+#pragma unroll
+    for (int wv = 0; wv < 4; ++wv) t += red[(wv * C4 + cc) * 8 + kind * 4 + jj];
+    atomicAdd((kind ? st1 : st0) + 4 * cc + jj, t);
+  }
 }
 
 __device__ __forceinline__ float lhn_wave_sum(float v) {

@@ -477,7 +477,7 @@ class PlanBuilder:
         training run), the reader lists the producer in pend[slot].  Anything else keeps the separate launch."""
         self.deferred = 0
         for i, o in enumerate(fwd):
-            if o.kind not in (STEM, PW, DW, KXK) or o.p[2] < 0 or o.out_buf < 0 or o.ws[0] < 0 or o.out_C > 256:
+            if o.kind not in (STEM, PW, DW, KXK) or o.p[2] < 0 or o.out_buf < 0 or o.ws[0] < 0 or o.out_C > 128:
                 continue
             lo, hi = o.out_coff, o.out_coff + o.out_C
             if self.bufs[o.out_buf].C > 256:

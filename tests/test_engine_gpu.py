@@ -41,7 +41,8 @@ def test_stale_forward_and_double_backward_raise(dev):
     m.zero_grad(set_to_none=True)
     y = m(x1)
     y.sum().backward()                           # the plain sequence still works and reproduces the gradient
-    assert torch.allclose(next(m.parameters()).grad, g1, rtol=1e-4, atol=1e-6)
+    g2 = next(m.parameters()).grad
+    assert float((g2 - g1).norm() / g1.norm()) < 1e-3      # (random-init weights: huge gradients, fp32 atomics order)
     m.eval()
     y = m(x1)                                    # grad-enabled eval forward shares the training plan's workspace ...
     m.train()

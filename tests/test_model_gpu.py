@@ -679,3 +679,37 @@ def test_eval_tables_are_cached_and_invalidated(dev):
         y7 = m(x).clone()
     assert torch.equal(y6, y7)
     assert float((y6 - y5).abs().max()) <= 1e-3 * float(y5.abs().max())
+
+
+@pytest.mark.parametrize("kind", ["pw", "dw", "dense3x3"])
+def test_batchnorm_statistics_large_mean(dev, kind):
+    """BatchNorm batch statistics when |mean| = 1000 x sigma at the convolution output (E[x^2] - E[x]^2 cancels 6 digits):
+    the epilogues promote their per-tile fp32 partial sums to double, so the normalised output stays within 2e-3 of the
+    float64 oracle -- the inherent fp32 resolution of the convolution output itself (1000 +- 1 carries ~1e-4 per element).
+    A running fp32 sum of squares over the 16K pixels of this test loses the variance altogether."""
+    from litehandnet_amd import repblocks
+    r = np.random.Generator(np.random.PCG64(77))
+    c = 64
+    if kind == "pw":
+        ours, ref = repblocks.RepConv(c, c, 1, activation=None), torch_ref.RepConv(c, c, 1, activation=None)
+    elif kind == "dw":
+        ours = repblocks.RepConv(c, c, 3, 1, 1, groups=c, activation=None)
+        ref = torch_ref.RepConv(c, c, 3, 1, 1, groups=c, activation=None)
+    else:
+        ours, ref = repblocks.RepConv(c, c, 3, 1, 1, activation=None), torch_ref.RepConv(c, c, 3, 1, 1, activation=None)
+    sd = synth.synth_state_dict(ref, 3)
+    w = sd["conv.conv.weight"]
+    sd["conv.conv.weight"] = w - w.mean(dim=(1, 2, 3), keepdim=True) + 1.0 / w[0].numel()      # every output: sum of weights = 1
+    ref.load_state_dict(sd); ours.load_state_dict(sd)
+    x = torch.from_numpy((1000.0 + r.standard_normal((4, c, 64, 64))).astype(np.float32))
+    ours.to(dev).train(); ref.double().train()
+    with torch.no_grad():
+        y, y64 = ours(x.to(dev)), ref(x.double())
+    pre = torch.nn.functional.conv2d(x.double(), sd["conv.conv.weight"].double(), padding=(0 if kind == "pw" else 1),
+                                     groups=(c if kind == "dw" else 1))
+    ratio = float(pre.mean().abs() / pre.std())
+    assert ratio > 300, ratio                                    # the premise: mean >> sigma at the BatchNorm input
+    e = float((y.cpu().double() - y64).abs().max() / y64.abs().max())
+    assert e < 2e-3, (kind, e, ratio)
+    rv = dict(ours.named_buffers())["conv.bn.running_var"].cpu().double()
+    assert torch.allclose(rv, dict(ref.named_buffers())["conv.bn.running_var"], rtol=2e-3), kind
