@@ -133,6 +133,17 @@ int lhn_affine_warp_normalize(const unsigned char* img, int N, int Hs, int Ws, c
                               const float* std3, float* out, int Ho, int Wo, float* joints /*or NULL*/,
                               const float* visible, int vis_stride, int K,
                               int use_udp /*get_warp_matrix + warp_affine_joints, post_transforms.py:49-100*/, void* stream);
+/* TopDownRandomFlip (datasets/data_pipeline/RandomFlip.py:28-100) for the samples with flipped[n] != 0: lhn_random_flip
+ * exchanges the joints / visibility of every (left, right) pair, mirrors x (W - 1 - x), multiplies by the visibility and
+ * mirrors center_x; lhn_affine_warp_normalize2 then reads the source image of those samples mirrored (img[:, ::-1]) --
+ * the flipped image is never written.  pairs: int32 [npairs][2] on the device. */
+int lhn_random_flip(float* joints /*[N,K,3]*/, float* visible /*[N,K,vis_stride]*/, int vis_stride, float* center /*[N,2]*/,
+                    const unsigned char* flipped /*[N]*/, const int32_t* pairs, int npairs, int N, int K, int img_width,
+                    void* stream);
+int lhn_affine_warp_normalize2(const unsigned char* img, int N, int Hs, int Ws, const float* center, const float* scale,
+                               const float* rot_deg, const float* mean3, const float* std3, float* out, int Ho, int Wo,
+                               float* joints, const float* visible, int vis_stride, int K, int use_udp,
+                               const unsigned char* flipped /*[N] or NULL*/, void* stream);
 /* SimDR (cfg.PIPELINE.simdr_split_ratio = k > 0): 1-D Gaussian target vectors (generate_simder.py:9-31) and the
  * auxiliary loss on the decoded vectors (centernet_simdr_loss.py:6-71: per joint, SmoothL1 'mean' over [N, L] times the
  * MEAN of that joint's weights, x and y, averaged over joints).  The two shared Linear decoders are plain library
@@ -154,6 +165,11 @@ int lhn_heatmap_decode_dark_udp(const float* hm, const float* center, const floa
                                 float* preds, float* maxvals, int N, int K, int H, int W, int kernel, void* stream);
 int lhn_heatmap_nms(float* hm /*in place*/, float* scratch /*same size*/, int N, int K, int H, int W,
                     int kernel, void* stream);
+/* HeatmapParser.candidate_bbox (utils/HeatmapParser.py:52-85): per centre map [N,H,W] (after lhn_heatmap_nms) the k highest
+ * peaks in descending order as candidates[N,k,5] = (x, y, w, h, confidence) in image pixels; size_maps [N,2,H,W] = the
+ * region-averaged width / height ratio maps (NULL: w = h = 0). */
+int lhn_heatmap_topk(const float* centre_maps, const float* size_maps, float* candidates, int N, int H, int W, int k,
+                     float image_size, void* stream);
 int lhn_pck_accuracy(const float* pred, const float* gt, const uint8_t* mask /*[N,K]*/,
                      const float* normalize /*[N,2]*/, float thr, float* acc /*[K]*/,
                      float* avg_cnt /*[2]: avg, cnt*/, int N, int K, void* stream);

@@ -670,8 +670,10 @@ extern "C" int lhn_simdr_loss_bwd(const float* px, const float* py, const float*
 __global__ void __launch_bounds__(256) k_affine_warp_norm(const unsigned char* __restrict__ img, int Hs, int Ws,
                                                           const float* __restrict__ center, const float* __restrict__ scale,
                                                           const float* __restrict__ rot, float m0, float m1, float m2, float s0,
-                                                          float s1, float s2, float* __restrict__ out, int Ho, int Wo, int udp) {
+                                                          float s1, float s2, float* __restrict__ out, int Ho, int Wo, int udp,
+                                                          const unsigned char* __restrict__ flipped) {
   const int n = blockIdx.y;
+  const bool flip = flipped && flipped[n];      // TopDownRandomFlip (RandomFlip.py:40-41): the source image is read mirrored
   const float r = rot[n] * 3.14159265358979323846f / 180.f;
   const float cr = cosf(r), sr = sinf(r);
   // src = (qx, qy) + [[a00, a01], [a10, a11]] * (dst - (px, py))
@@ -705,7 +707,7 @@ __global__ void __launch_bounds__(256) k_affine_warp_norm(const unsigned char* _
         const int xx = x0 + i, yy = y0 + j;
         if (xx >= 0 && xx < Ws && yy >= 0 && yy < Hs) {
           const float wgt = (i ? ax : 1.f - ax) * (j ? ay : 1.f - ay);
-          const unsigned char* q = src + ((size_t)yy * Ws + xx) * 3;
+          const unsigned char* q = src + ((size_t)yy * Ws + (flip ? Ws - 1 - xx : xx)) * 3;
           v[0] += wgt * q[0];
           v[1] += wgt * q[1];
           v[2] += wgt * q[2];
@@ -740,9 +742,121 @@ __global__ void k_affine_joints(float* __restrict__ joints, const float* __restr
   joints[(size_t)i * 3 + 1] = s * (-sr * dx + cr * dy) + 0.5f * Ho;
 }
 
+// HeatmapParser.candidate_bbox (utils/HeatmapParser.py:52-85): the k highest values of every (NMS-suppressed) centre map in
+// descending order -> (x, y) = (idx % W, idx // W) * feature_stride, confidence, and the box width / height ratios sampled
+// from the (already region-averaged) size maps at the peak, clipped to [0, 0.99] and scaled by the image size.
+// One block per map: the map sits in LDS, k rounds of block arg-max (first index wins ties, like a stable sort) each
+// knocking its winner out.  k is small (num_candidates ~ 10-30), H*W <= 16384.
+__global__ void __launch_bounds__(256) k_topk_candidates(const float* __restrict__ centre, const float* __restrict__ sizes,
+                                                         float* __restrict__ cand, int H, int W, int k, float stride,
+                                                         float image_size) {
+  extern __shared__ __attribute__((aligned(16))) float A[];
+  const int n = blockIdx.x, HW = H * W;
+  const float* m = centre + (size_t)n * HW;
+  for (int i = threadIdx.x; i < HW; i += blockDim.x) A[i] = m[i];
+  __syncthreads();
+  for (int t = 0; t < k; ++t) {
+    const MaxI r = block_argmax(A, HW);          // contains barriers; every thread gets the winner
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float* c = cand + ((size_t)n * k + t) * 5;
+      const int x = r.i % W, y = r.i / W;
+      c[0] = (float)x * stride;
+      c[1] = (float)y * stride;
+      float bw = 0.f, bh = 0.f;
+      if (sizes) {
+        bw = fminf(fmaxf(sizes[((size_t)n * 2 + 0) * HW + r.i], 0.f), 0.99f);
+        bh = fminf(fmaxf(sizes[((size_t)n * 2 + 1) * HW + r.i], 0.f), 0.99f);
+      }
+      c[2] = bw * image_size;
+      c[3] = bh * image_size;
+      c[4] = r.v;
+      A[r.i] = -INFINITY;
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" int lhn_heatmap_topk(const float* centre_maps, const float* size_maps, float* candidates, int N, int H, int W, int k,
+                                float image_size, void* stream) {
+  LHN_CHECK_ARG(centre_maps && candidates && N > 0 && H > 0 && W > 0 && k > 0 && k <= H * W, "lhn_heatmap_topk: bad argument");
+  LHN_CHECK_ARG((H * W) % 4 == 0 && H * W <= 16384, "lhn_heatmap_topk: H*W must be a multiple of 4 and <= 16384");
+  static LhnKernelCfg cfg;
+  (void)lhn_kernel_cfg(cfg, &k_topk_candidates, (size_t)16384 * 4, 4, nullptr);
+  hipLaunchKernelGGL(k_topk_candidates, dim3(N), dim3(256), (size_t)H * W * 4, (hipStream_t)stream, centre_maps, size_maps, candidates, H,
+                     W, k, image_size / (float)W, image_size);
+  LHN_CHECK_LAUNCH("lhn_heatmap_topk");
+  return 0;
+}
+
+// TopDownRandomFlip.__call__ + fliplr_joints (RandomFlip.py:28-100) for the samples flagged in `flipped`, minus the image
+// (lhn_affine_warp_normalize2 reads it mirrored): joints / visibility of every (left, right) pair exchanged FROM THE ORIGINAL
+// arrays, x -> W - 1 - x for every joint, joints *= visibility, center_x -> W - 1 - center_x.  One block per sample.
+__global__ void __launch_bounds__(64) k_flip_joints(float* __restrict__ joints, float* __restrict__ visible, int vs,
+                                                    float* __restrict__ center, const unsigned char* __restrict__ flipped,
+                                                    const int* __restrict__ pairs, int npairs, int K, float img_w) {
+  __shared__ float sj[64 * 3], sv[64 * 3];
+  __shared__ int src[64];
+  const int n = blockIdx.x, k = threadIdx.x;
+  if (!flipped[n]) return;
+  if (k < K) {
+    src[k] = k;
+    for (int c = 0; c < 3; ++c) {
+      sj[k * 3 + c] = joints[((size_t)n * K + k) * 3 + c];
+      sv[k * 3 + c] = visible[((size_t)n * K + k) * vs + (c < vs ? c : vs - 1)];
+    }
+  }
+  __syncthreads();
+  if (k == 0)
+    for (int p = 0; p < npairs; ++p) {           // later pairs win, as the reference's sequential assignments do
+      const int l = pairs[2 * p], r = pairs[2 * p + 1];
+      if (l >= 0 && l < K && r >= 0 && r < K) {
+        src[l] = r;
+        src[r] = l;
+      }
+    }
+  __syncthreads();
+  if (k < K) {
+    const int q = src[k];
+    float v[3], jx[3];
+    for (int c = 0; c < 3; ++c) {
+      v[c] = sv[q * 3 + c];
+      jx[c] = sj[q * 3 + c];
+    }
+    jx[0] = img_w - 1.f - jx[0];
+    for (int c = 0; c < 3; ++c) {
+      joints[((size_t)n * K + k) * 3 + c] = jx[c] * v[c];
+      if (c < vs) visible[((size_t)n * K + k) * vs + c] = v[c];
+    }
+  }
+  if (k == 0) center[n * 2] = img_w - center[n * 2] - 1.f;
+}
+
+extern "C" int lhn_random_flip(float* joints, float* visible, int vis_stride, float* center, const unsigned char* flipped,
+                               const int32_t* pairs, int npairs, int N, int K, int img_width, void* stream) {
+  LHN_CHECK_ARG(joints && visible && center && flipped && (pairs || npairs == 0) && N > 0 && K > 0 && K <= 64 && npairs >= 0 &&
+                    vis_stride >= 1 && vis_stride <= 3 && img_width > 0,
+                "lhn_random_flip: bad argument (K <= 64, visibility columns 1..3)");
+  hipLaunchKernelGGL(k_flip_joints, dim3(N), dim3(64), 0, (hipStream_t)stream, joints, visible, vis_stride, center, flipped, pairs,
+                     npairs, K, (float)img_width);
+  LHN_CHECK_LAUNCH("lhn_random_flip");
+  return 0;
+}
+
+extern "C" int lhn_affine_warp_normalize2(const unsigned char* img, int N, int Hs, int Ws, const float* center, const float* scale,
+                                          const float* rot, const float* mean3, const float* std3, float* out, int Ho, int Wo,
+                                          float* joints, const float* visible, int vis_stride, int K, int use_udp,
+                                          const unsigned char* flipped, void* stream);
 extern "C" int lhn_affine_warp_normalize(const unsigned char* img, int N, int Hs, int Ws, const float* center, const float* scale,
                                          const float* rot, const float* mean3, const float* std3, float* out, int Ho, int Wo,
                                          float* joints, const float* visible, int vis_stride, int K, int use_udp, void* stream) {
+  return lhn_affine_warp_normalize2(img, N, Hs, Ws, center, scale, rot, mean3, std3, out, Ho, Wo, joints, visible, vis_stride, K,
+                                    use_udp, nullptr, stream);
+}
+extern "C" int lhn_affine_warp_normalize2(const unsigned char* img, int N, int Hs, int Ws, const float* center, const float* scale,
+                                          const float* rot, const float* mean3, const float* std3, float* out, int Ho, int Wo,
+                                          float* joints, const float* visible, int vis_stride, int K, int use_udp,
+                                          const unsigned char* flipped, void* stream) {
   LHN_CHECK_ARG(img && center && scale && rot && mean3 && std3 && out && N > 0 && Hs > 0 && Ws > 0 && Ho > 0 && Wo > 0,
                 "lhn_affine_warp_normalize: bad argument");
   LHN_CHECK_ARG(!joints || (visible && K > 0), "lhn_affine_warp_normalize: joints need visibility flags");
@@ -750,7 +864,7 @@ extern "C" int lhn_affine_warp_normalize(const unsigned char* img, int N, int Hs
   int gx = (Ho * Wo + 255) / 256;
   if (gx > 64) gx = 64;
   hipLaunchKernelGGL(k_affine_warp_norm, dim3(gx, N), dim3(256), 0, s, img, Hs, Ws, center, scale, rot, mean3[0], mean3[1], mean3[2],
-                     std3[0], std3[1], std3[2], out, Ho, Wo, use_udp);
+                     std3[0], std3[1], std3[2], out, Ho, Wo, use_udp, flipped);
   if (joints)
     hipLaunchKernelGGL(k_affine_joints, dim3((N * K + 255) / 256), dim3(256), 0, s, joints, visible, vis_stride, center, scale, rot, K,
                        Ho, Wo, N * K, use_udp);

@@ -218,6 +218,18 @@ def keypoints_from_simdr(x_vectors, y_vectors, center, scale, k=2):
     return torch.cat([out, (mx + my) / 2], dim=2)
 
 
+def candidate_bbox(center_maps, size_maps, num_candidates, image_size):
+    """HeatmapParser.candidate_bbox (utils/HeatmapParser.py:52-85): center_maps [N,H,W] (peak-suppressed, see heatmap_nms),
+    size_maps [N,2,H,W] already region-averaged (or None) -> candidates [N,k,5] = (x, y, w, h, confidence), descending."""
+    cm = _lib.f32c(_dev(center_maps))
+    N, H, W = cm.shape
+    sm = None if size_maps is None else _lib.f32c(_dev(size_maps, cm.device))
+    out = torch.empty((N, int(num_candidates), 5), dtype=torch.float32, device=cm.device)
+    _lib.check(_lib.lib().lhn_heatmap_topk(_lib.ptr(cm), _lib.ptr(sm), _lib.ptr(out), N, H, W, int(num_candidates),
+                                           C.c_float(float(image_size)), _lib.stream()), "lhn_heatmap_topk")
+    return out
+
+
 class TopDownDecoder:
     """utils/post_processing/decoder.py:9-107.  Same attributes (`k` is read by test.py:125) and the same result dicts: host
     numpy arrays for preds / hm_preds / boxes / output_heatmap, a python list for bbox_ids.  The decode itself runs on the

@@ -12,10 +12,29 @@ IMAGENET_MEAN = (0.485, 0.456, 0.406)
 IMAGENET_STD = (0.229, 0.224, 0.225)
 
 
+def random_flip(joints, visible, center, flipped, flip_pairs, img_width):
+    """TopDownRandomFlip / fliplr_joints (RandomFlip.py:28-100) for a device-resident batch: returns NEW (joints, visible,
+    center) with the flagged samples flipped.  The image itself is not touched: pass the same `flipped` flags to
+    affine_warp_normalize, which reads those source images mirrored."""
+    _lib.require_device()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    j = _lib.f32c(torch.as_tensor(joints, dtype=torch.float32).to(dev)).clone()
+    v = _lib.f32c(torch.as_tensor(visible, dtype=torch.float32).to(dev)).clone()
+    c = _lib.f32c(torch.as_tensor(center, dtype=torch.float32).to(dev)).clone().reshape(-1, 2)
+    f = torch.as_tensor(flipped).to(dev).to(torch.uint8).contiguous()
+    N, K = j.shape[0], j.shape[1]
+    pr = torch.as_tensor(list(flip_pairs), dtype=torch.int32).reshape(-1, 2).to(dev).contiguous()
+    _lib.check(_lib.lib().lhn_random_flip(_lib.ptr(j), _lib.ptr(v), int(v.shape[-1]), _lib.ptr(c), _lib.ptr(f),
+                                          _lib.ptr(pr) if pr.numel() else None, int(pr.shape[0]), N, K, int(img_width),
+                                          _lib.stream()), "lhn_random_flip")
+    return j, v, c
+
+
 def affine_warp_normalize(images_u8, center, scale, rotation, image_size, joints=None, visible=None, mean=IMAGENET_MEAN,
-                          std=IMAGENET_STD, use_udp=False):
+                          std=IMAGENET_STD, use_udp=False, flipped=None):
     """images_u8 [N,Hs,Ws,3] uint8, center/scale [N,2], rotation [N] degrees -> float32 [N,3,H,W] normalised crops
-    (+ joints [N,K,3] mapped into the crop, visible ones only, when given)."""
+    (+ joints [N,K,3] mapped into the crop, visible ones only, when given).  flipped [N]: those source images are read
+    mirrored (the image half of TopDownRandomFlip; joints / center come from random_flip)."""
     _lib.require_device()
     dev = torch.device("cuda", torch.cuda.current_device())
     img = torch.as_tensor(images_u8).to(dev)
@@ -35,9 +54,11 @@ def affine_warp_normalize(images_u8, center, scale, rotation, image_size, joints
         j = _lib.f32c(torch.as_tensor(joints, dtype=torch.float32).to(dev)).clone()
         v = _lib.f32c(torch.as_tensor(visible, dtype=torch.float32).to(dev))
         K = j.shape[1]
-    _lib.check(_lib.lib().lhn_affine_warp_normalize(_lib.ptr(img), N, Hs, Ws, _lib.ptr(ce), _lib.ptr(sc), _lib.ptr(ro), m3, s3,
-                                                    _lib.ptr(out), Ho, Wo, _lib.ptr(j), _lib.ptr(v),
-                                                    0 if v is None else v.shape[-1], K, 1 if use_udp else 0, _lib.stream()),
+    fl = None if flipped is None else torch.as_tensor(flipped).to(dev).to(torch.uint8).contiguous()
+    _lib.check(_lib.lib().lhn_affine_warp_normalize2(_lib.ptr(img), N, Hs, Ws, _lib.ptr(ce), _lib.ptr(sc), _lib.ptr(ro), m3, s3,
+                                                     _lib.ptr(out), Ho, Wo, _lib.ptr(j), _lib.ptr(v),
+                                                     0 if v is None else v.shape[-1], K, 1 if use_udp else 0, _lib.ptr(fl),
+                                                     _lib.stream()),
                "lhn_affine_warp_normalize")
     return (out, j) if joints is not None else out
 

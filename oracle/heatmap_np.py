@@ -397,3 +397,44 @@ def keypoints_from_heatmaps_udp(heatmaps, center, scale, kernel=11):
     for i in range(N):
         preds[i] = transform_preds(preds[i], center[i], scale[i], [W, H], use_udp=True)
     return hm_preds, preds, maxvals
+
+
+def fliplr_joints(joints_3d, joints_3d_visible, img_width, flip_pairs):
+    """datasets/data_pipeline/RandomFlip.py:64-100."""
+    jf, vf = joints_3d.copy(), joints_3d_visible.copy()
+    for left, right in flip_pairs:
+        jf[left, :] = joints_3d[right, :]
+        jf[right, :] = joints_3d[left, :]
+        vf[left, :] = joints_3d_visible[right, :]
+        vf[right, :] = joints_3d_visible[left, :]
+    jf[:, 0] = img_width - 1 - jf[:, 0]
+    return jf * vf, vf
+
+
+def random_flip(img, joints_3d, joints_3d_visible, center, flip_pairs):
+    """TopDownRandomFlip.__call__ (RandomFlip.py:28-61) with the coin already tossed to 'flip'."""
+    img = img[:, ::-1, :]
+    j, v = fliplr_joints(joints_3d, joints_3d_visible, img.shape[1], flip_pairs)
+    c = center.copy()
+    c[0] = img.shape[1] - c[0] - 1
+    return img, j, v, c
+
+
+def candidate_bbox(center_maps, size_maps, num_candidates, image_size):
+    """utils/HeatmapParser.py:52-85 (size_maps already region-averaged): top-k peaks, descending, ties by lower index."""
+    b, h, w = center_maps.shape
+    flat = center_maps.reshape(b, -1)
+    idx = np.argsort(-flat, axis=1, kind="stable")[:, :num_candidates]
+    val = np.take_along_axis(flat, idx, 1)
+    cand = np.zeros((b, num_candidates, 5), np.float32)
+    cand[..., 0] = idx % w
+    cand[..., 1] = idx // w
+    if size_maps is not None:
+        sm = size_maps.reshape(b, 2, -1)
+        cand[..., 2] = np.take_along_axis(sm[:, 0], idx, 1)
+        cand[..., 3] = np.take_along_axis(sm[:, 1], idx, 1)
+    cand[..., 2:4] = cand[..., 2:4].clip(0, 0.99)
+    cand[..., 4] = val
+    cand[..., :2] *= np.float32(image_size / w)
+    cand[..., 2:4] *= np.float32(image_size)
+    return cand

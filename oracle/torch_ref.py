@@ -754,6 +754,236 @@ class HourglassNet(nn.Module):
         return torch.stack(outs, dim=1)
 
 
+# --------------------------------------------------------------------------
+# Lite-HRNet baseline (models/pose_estimation/lite_hrnet.py) -- BASELINE config 5
+# --------------------------------------------------------------------------
+class LHDWConv(nn.Module):
+    """lite_hrnet.py:11-27: depthwise 3x3 + BN [+ ReLU] -> 1x1 + BN [+ ReLU]."""
+
+    def __init__(self, cin, cout, stride=1, padding=1, dilation=1, mid_relu=True, last_relu=True, bias=False):
+        super().__init__()
+        self.depthwise_conv = nn.Sequential(nn.Conv2d(cin, cin, 3, stride, padding, groups=cin, bias=bias, dilation=dilation),
+                                            nn.BatchNorm2d(cin))
+        self.mid_relu = nn.ReLU() if mid_relu else nn.Identity()
+        self.pointwise_conv = nn.Sequential(nn.Conv2d(cin, cout, 1, 1, 0, bias=bias), nn.BatchNorm2d(cout))
+        self.last_relu = nn.ReLU() if last_relu else nn.Identity()
+
+    def forward(self, x):
+        return self.last_relu(self.pointwise_conv(self.mid_relu(self.depthwise_conv(x))))
+
+
+def channel_shuffle(x, groups):
+    """lite_hrnet.py:29-52."""
+    b, c, h, w = x.size()
+    return x.view(b, groups, c // groups, h, w).transpose(1, 2).contiguous().view(b, -1, h, w)
+
+
+class SpatialWeighting(nn.Module):
+    """lite_hrnet.py:55-74: x * sigmoid(relu(conv2(sigmoid(relu(conv1(global_avg_pool(x)))))))."""
+
+    def __init__(self, channels, ratio=16):
+        super().__init__()
+        self.global_avgpool = nn.AdaptiveAvgPool2d(1)
+        mid = int(channels / ratio)
+        self.conv1 = nn.Sequential(nn.Conv2d(channels, mid, 1, 1), nn.ReLU(True), nn.Sigmoid())
+        self.conv2 = nn.Sequential(nn.Conv2d(mid, channels, 1, 1), nn.ReLU(True), nn.Sigmoid())
+
+    def forward(self, x):
+        return x * self.conv2(self.conv1(self.global_avgpool(x)))
+
+
+class CrossResolutionWeighting(nn.Module):
+    """lite_hrnet.py:76-108."""
+
+    def __init__(self, channels, ratio=16):
+        super().__init__()
+        self.channels = channels
+        total = sum(channels)
+        mid = int(total / ratio)
+        self.conv1 = nn.Sequential(nn.Conv2d(total, mid, 1, 1), nn.BatchNorm2d(mid), nn.ReLU(True), nn.Sigmoid())
+        self.conv2 = nn.Sequential(nn.Conv2d(mid, total, 1, 1), nn.BatchNorm2d(total), nn.ReLU(True), nn.Sigmoid())
+
+    def forward(self, x):
+        mini = x[-1].shape[-2:]
+        out = torch.cat([F.adaptive_avg_pool2d(s, mini) for s in x[:-1]] + [x[-1]], dim=1)
+        out = torch.split(self.conv2(self.conv1(out)), self.channels, dim=1)
+        return [s * F.interpolate(a, size=s.shape[-2:], mode="nearest") for s, a in zip(x, out)]
+
+
+class ConditionalChannelWeighting(nn.Module):
+    """lite_hrnet.py:110-143."""
+
+    def __init__(self, in_channels, reduce_ratio, stride=1):
+        super().__init__()
+        bc = [c // 2 for c in in_channels]
+        self.cross_resolution_weighting = CrossResolutionWeighting(channels=bc, ratio=reduce_ratio)
+        self.depthwise_convs = nn.ModuleList([nn.Sequential(nn.Conv2d(c, c, 3, stride, 1, groups=c), nn.BatchNorm2d(c)) for c in bc])
+        self.spatial_weighting = nn.ModuleList([SpatialWeighting(channels=c, ratio=4) for c in bc])
+
+    def forward(self, x):
+        x = [s.chunk(2, dim=1) for s in x]
+        x1, x2 = [s[0] for s in x], [s[1] for s in x]
+        x2 = self.cross_resolution_weighting(x2)
+        x2 = [dw(s) for s, dw in zip(x2, self.depthwise_convs)]
+        x2 = [sw(s) for s, sw in zip(x2, self.spatial_weighting)]
+        return [channel_shuffle(torch.cat([a, b], dim=1), 2) for a, b in zip(x1, x2)]
+
+
+class StageModule(nn.Module):
+    """lite_hrnet.py:145-204."""
+
+    def __init__(self, in_branches, num_blocks, in_channels, reduce_ratio=8, with_fuse=True):
+        super().__init__()
+        self.in_branches, self.in_channels, self.with_fuse = in_branches, in_channels, with_fuse
+        self.layers = nn.Sequential(*[ConditionalChannelWeighting(in_channels, reduce_ratio) for _ in range(num_blocks)])
+        if self.with_fuse and self.in_branches > 1:
+            self.fuse_layers = self._make_fuse_layers()
+            self.relu = nn.ReLU()
+        else:
+            self.with_fuse = False
+
+    def _make_fuse_layers(self):
+        cs = self.in_channels
+        fuse = nn.ModuleList()
+        for i in range(self.in_branches):
+            fuse.append(nn.ModuleList())
+            for j in range(self.in_branches):
+                cin, cout = cs[j], cs[i]
+                if i == j:
+                    fuse[-1].append(nn.Identity())
+                elif j > i:
+                    fuse[-1].append(nn.Sequential(nn.Conv2d(cin, cout, 1, 1, 0, bias=False), nn.BatchNorm2d(cout),
+                                                  nn.Upsample(scale_factor=2 ** (j - i), mode="nearest")))
+                else:
+                    down = [LHDWConv(cin, cin, stride=2, mid_relu=False, last_relu=False) for _ in range(i - j - 1)]
+                    down.append(LHDWConv(cin, cout, stride=2, mid_relu=False, last_relu=False))
+                    fuse[-1].append(nn.Sequential(*down))
+        return fuse
+
+    def forward(self, x):
+        if self.in_branches == 1:
+            return [self.layers[0](x[0])]
+        out = self.layers(x)
+        if self.with_fuse:
+            # lite_hrnet.py:190-199, including its aliasing: for i == 0 `y` IS out[0] and `y += ...` accumulates INTO it, so
+            #   out[0] becomes 2*out[0] + sum_j fuse[0][j](out[j])   (the un-rectified fused branch 0),
+            # and every later row i starts from fuse[i][0](that), evaluated TWICE (initial value + the j == 0 term; in
+            # training mode its BatchNorm running statistics therefore move twice per forward).
+            out = list(out)
+            out_fuse = []
+            for i in range(len(self.fuse_layers)):
+                y = out[0] if i == 0 else self.fuse_layers[i][0](out[0])
+                for j in range(self.in_branches):
+                    y = y + (out[j] if i == j else self.fuse_layers[i][j](out[j]))
+                if i == 0:
+                    out[0] = y
+                out_fuse.append(self.relu(y))
+            out = out_fuse
+        return out
+
+
+class LHStemModule(nn.Module):
+    """lite_hrnet.py:206-248."""
+
+    def __init__(self, in_channels, stem_channels, out_channels, expand_ratio):
+        super().__init__()
+        self.conv1 = nn.Sequential(nn.Conv2d(in_channels, stem_channels, 3, 2, 1), nn.BatchNorm2d(stem_channels), nn.ReLU())
+        self.out_channels = out_channels
+        mid = int(round(stem_channels * expand_ratio))
+        bc = stem_channels // 2
+        inc = out_channels - bc if stem_channels == out_channels else out_channels - stem_channels
+        self.branch1 = LHDWConv(bc, inc, stride=2, mid_relu=False, bias=True)
+        self.expand_conv = nn.Sequential(nn.Conv2d(bc, mid, 1, 1, 0), nn.BatchNorm2d(mid), nn.ReLU())
+        self.depthwise_conv = nn.Sequential(nn.Conv2d(mid, mid, 3, 2, 1, groups=mid), nn.BatchNorm2d(mid))
+        lc = bc if stem_channels == out_channels else stem_channels
+        self.linear_conv = nn.Sequential(nn.Conv2d(mid, lc, 1, 1, 0), nn.BatchNorm2d(lc), nn.ReLU())
+
+    def forward(self, x):
+        x = self.conv1(x)
+        x1, x2 = x.chunk(2, dim=1)
+        x2 = self.linear_conv(self.depthwise_conv(self.expand_conv(x2)))
+        return channel_shuffle(torch.cat((self.branch1(x1), x2), dim=1), 2)
+
+
+class IterativeHead(nn.Module):
+    """lite_hrnet.py:250-281."""
+
+    def __init__(self, in_channels):
+        super().__init__()
+        nb = len(in_channels)
+        self.in_channels = in_channels[::-1]
+        self.projects = nn.ModuleList([LHDWConv(self.in_channels[i], self.in_channels[i + 1] if i != nb - 1 else self.in_channels[i])
+                                       for i in range(nb)])
+
+    def forward(self, x):
+        x = x[::-1]
+        y, last = [], None
+        for i, s in enumerate(x):
+            if last is not None:
+                s = s + F.interpolate(last, size=s.shape[-2:], mode="bilinear", align_corners=True)
+            s = self.projects[i](s)
+            y.append(s)
+            last = s
+        return y[::-1]
+
+
+class LiteHRNet(nn.Module):
+    """lite_hrnet.py:284-390."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        out_channel = cfg.MODEL.get("output_channel", cfg.DATASET.num_joints)
+        depth = cfg.MODEL.get("depth", 30)
+        self.stem = LHStemModule(in_channels=3, stem_channels=32, out_channels=32, expand_ratio=1)
+        self.num_stages = 3
+        self.stages_spec = dict(num_modules=(3, 8, 3) if depth != 18 else (3, 4, 3), num_branches=(2, 3, 4), num_blocks=(2, 2, 2),
+                                with_fuse=(True, True, True), reduce_ratios=(8, 8, 8),
+                                num_channels=((40, 80), (40, 80, 160), (40, 80, 160, 320)))
+        last = [self.stem.out_channels]
+        for i in range(self.num_stages):
+            nc = list(self.stages_spec["num_channels"][i])
+            setattr(self, f"transition{i}", self._make_transition_layer(last, nc))
+            stage, last = self._make_stage(i, nc)
+            setattr(self, f"stage{i}", stage)
+        self.head_layer = IterativeHead(in_channels=last)
+        self.out_conv = nn.Conv2d(40, out_channel, 1, 1, 0)
+
+    @staticmethod
+    def _make_transition_layer(pre, cur):
+        layers = []
+        for i in range(len(cur)):
+            if i < len(pre):
+                layers.append(LHDWConv(pre[i], cur[i], mid_relu=False) if cur[i] != pre[i] else None)
+            else:
+                down = []
+                for j in range(i + 1 - len(pre)):
+                    cin = pre[-1]
+                    down.append(LHDWConv(cin, cur[i] if j == i - len(pre) else cin, stride=2, mid_relu=False))
+                layers.append(nn.Sequential(*down))
+        return nn.ModuleList(layers)
+
+    def _make_stage(self, si, in_channels):
+        sp = self.stages_spec
+        mods = []
+        for _ in range(sp["num_modules"][si]):
+            mods.append(StageModule(sp["num_branches"][si], sp["num_blocks"][si], in_channels, sp["reduce_ratios"][si], sp["with_fuse"][si]))
+            in_channels = mods[-1].in_channels
+        return nn.Sequential(*mods), in_channels
+
+    def forward(self, x):
+        y_list = [self.stem(x)]
+        for i in range(self.num_stages):
+            tr = getattr(self, f"transition{i}")
+            x_list = []
+            for j in range(self.stages_spec["num_branches"][i]):
+                if tr[j]:
+                    x_list.append(tr[j](y_list[-1] if j >= len(y_list) else y_list[j]))
+                else:
+                    x_list.append(y_list[j])
+            y_list = getattr(self, f"stage{i}")(x_list)
+        return self.out_conv(self.head_layer(y_list)[0])
+
+
 def get_model(cfg, p_drop=0.3):
     """Mirror of models/__init__.py:20-26 restricted to the hot path.
 
@@ -768,6 +998,8 @@ def get_model(cfg, p_drop=0.3):
         return MultiScaleAttentionHourglass(cfg, p_drop)
     if name == "hourglass":
         return HourglassNet(cfg)
+    if name == "litehrnet":
+        return LiteHRNet(cfg)
     raise AssertionError(f"model <{name}> is outside the hot path")
 
 

@@ -6,7 +6,10 @@
   model_H{1,2}_*.npz   hourglass (models/pose_estimation/hourglassnet.py), num_stack 1 and 2: forward [N,S,K,H,W], loss,
                        gradient norms -- same recipe as make_golden.py::_model_case
 
-    python tests/golden/make_golden_r2.py [decoder|hourglass|all]
+  random_flip.npz      TopDownRandomFlip (datasets/data_pipeline/RandomFlip.py:28-100) of the REAL reference
+  candidates.npz       HeatmapParser.candidate_bbox arithmetic on torch.topk (class un-importable: restated)
+
+    python tests/golden/make_golden_r2.py [decoder|hourglass|flip|topk|all]
 """
 import os
 import sys
@@ -63,6 +66,71 @@ def decoder_fixture(ev):
     print("written decoder_result.npz", {k: getattr(v, "shape", None) for k, v in res.items()}, rs["preds"].dtype)
 
 
+def flip_fixture():
+    """TopDownRandomFlip of the REAL reference (datasets/data_pipeline/RandomFlip.py, pure numpy) with the coin forced to
+    'flip' (flip_prob = 1): image, joints, visibility, centre.  Pairs include an overlapping one (later pair wins)."""
+    rf = by_path_ref("ref_random_flip", "datasets/data_pipeline/RandomFlip.py")
+    r = np.random.Generator(np.random.PCG64(95))
+    n, k, hs, ws = 5, 21, 40, 56
+    imgs = r.integers(0, 256, (n, hs, ws, 3), dtype=np.uint8)
+    joints = np.zeros((n, k, 3), np.float32)
+    joints[..., :2] = r.uniform(0, ws, (n, k, 2)).astype(np.float32)
+    vis = (r.random((n, k, 1)) > 0.2).astype(np.float32).repeat(3, 2)
+    vis[..., 2] = 0
+    centers = r.uniform(10, 40, (n, 2)).astype(np.float32)
+    pairs = [(1, 5), (2, 6), (3, 7), (4, 8), (8, 12)]
+    flipped = np.array([1, 0, 1, 1, 0], np.uint8)
+    oi, oj, ov, oc = [], [], [], []
+    for i in range(n):
+        res = dict(img=imgs[i], joints_3d=joints[i].copy(), joints_3d_visible=vis[i].copy(), center=centers[i].copy(),
+                   ann_info=dict(flip_pairs=pairs))
+        t = rf.TopDownRandomFlip(flip_prob=1.0 if flipped[i] else -1.0)
+        res = t(res)
+        assert res["flipped"] == bool(flipped[i])
+        if flipped[i]:
+            ei, ej, ev, ec = onp.random_flip(imgs[i], joints[i], vis[i], centers[i], pairs)
+            assert np.array_equal(res["img"], ei) and np.array_equal(res["joints_3d"], ej)
+            assert np.array_equal(res["joints_3d_visible"], ev) and np.array_equal(res["center"], ec)
+        oi.append(np.ascontiguousarray(res["img"]))
+        oj.append(res["joints_3d"])
+        ov.append(res["joints_3d_visible"])
+        oc.append(res["center"])
+    np.savez_compressed(os.path.join(HERE, "random_flip.npz"), images=imgs, joints=joints, visible=vis, center=centers,
+                        pairs=np.array(pairs, np.int32), flipped=flipped, out_images=np.stack(oi), out_joints=np.stack(oj),
+                        out_visible=np.stack(ov), out_center=np.stack(oc))
+    print("written random_flip.npz")
+
+
+def topk_fixture():
+    """HeatmapParser.candidate_bbox (utils/HeatmapParser.py:52-85).  The class cannot be imported (stale config symbols,
+    munkres / torchvision absent), so its arithmetic is re-run here line by line on torch.topk -- the
+    third-party call that decides the ordering -- and the oracle must agree.  Distinct values: topk's tie order is
+    unspecified."""
+    r = np.random.Generator(np.random.PCG64(96))
+    b, hm, k, image_size = 4, 64, 12, 256
+    centre = r.permutation(b * hm * hm).reshape(b, hm, hm).astype(np.float32) / (b * hm * hm)
+    sizes = r.uniform(-0.1, 1.1, (b, 2, hm, hm)).astype(np.float32)
+    cm = torch.from_numpy(centre).reshape(b, -1)
+    top_val, top_idx = torch.topk(cm, k=k)
+    cand = torch.zeros((b, k, 5), dtype=torch.float32)
+    cand[..., 0] = top_idx % hm
+    cand[..., 1] = torch.div(top_idx, hm, rounding_mode="trunc")
+    sm = torch.from_numpy(sizes)
+    for bi in range(b):
+        for ki in range(k):
+            x, y = int(cand[bi, ki, 0]), int(cand[bi, ki, 1])
+            cand[bi, ki, 2] = sm[bi, 0, y, x]
+            cand[bi, ki, 3] = sm[bi, 1, y, x]
+    cand[..., 2:4] = cand[..., 2:4].clip(0, 0.99)
+    cand[..., 4] = top_val
+    cand[..., :2] *= image_size / hm
+    cand[..., 2:4] *= image_size
+    assert np.array_equal(cand.numpy(), onp.candidate_bbox(centre, sizes, k, image_size))
+    np.savez_compressed(os.path.join(HERE, "candidates.npz"), centre=centre, sizes=sizes, k=k, image_size=image_size,
+                        candidates=cand.numpy())
+    print("written candidates.npz")
+
+
 def main():
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     torch.manual_seed(0)
@@ -70,6 +138,10 @@ def main():
     ref_models, _, RefLoss, pt, _, ev = _load_reference()
     if what in ("decoder", "all"):
         decoder_fixture(ev)
+    if what in ("flip", "all"):
+        flip_fixture()
+    if what in ("topk", "all"):
+        topk_fixture()
     if what in ("hourglass", "all"):
         from make_golden_r2_models import hourglass_fixtures
         hourglass_fixtures(ref_models, RefLoss)

@@ -309,3 +309,37 @@ def test_transform_preds_udp_golden(dev, golden_dir):
     for key, udp in (("plain", False), ("udp", True)):
         out = heatmap.transform_preds(g["coords"], g["center"], g["scale"], g["output_size"].tolist(), use_udp=udp)
         assert np.array_equal(out.cpu().numpy(), g[key]), key
+
+
+def test_random_flip_and_mirrored_warp(dev, golden_dir):
+    """TopDownRandomFlip on the device against the REAL reference's output (tests/golden/random_flip.npz): joints,
+    visibility and centre bit-exact; and the fused warp reading a flagged source image mirrored equals warping the
+    reference's flipped image (same kernel, so exact)."""
+    from litehandnet_amd import pipeline
+    g = np.load(os.path.join(golden_dir, "random_flip.npz"))
+    j, v, c = pipeline.random_flip(g["joints"], g["visible"], g["center"], g["flipped"], g["pairs"].tolist(), g["images"].shape[2])
+    assert np.array_equal(j.cpu().numpy(), g["out_joints"])
+    assert np.array_equal(v.cpu().numpy(), g["out_visible"])
+    assert np.array_equal(c.cpu().numpy(), g["out_center"])
+    n = g["images"].shape[0]
+    scale = np.full((n, 2), 0.25, np.float32)
+    rot = np.linspace(-20, 20, n).astype(np.float32)
+    a = pipeline.affine_warp_normalize(g["images"], c, scale, rot, [32, 32], flipped=g["flipped"])
+    b = pipeline.affine_warp_normalize(g["out_images"], c, scale, rot, [32, 32])
+    assert torch.equal(a, b)
+    assert not torch.equal(a, pipeline.affine_warp_normalize(g["images"], c, scale, rot, [32, 32]))
+
+
+def test_topk_candidates(dev, golden_dir):
+    """HeatmapParser.candidate_bbox (utils/HeatmapParser.py:52-85) on torch.topk's ordering (fixture: the reference's
+    arithmetic re-run on the real torch.topk; the class itself cannot be imported): bit-exact, and the composition with
+    the 11x11 peak NMS."""
+    from litehandnet_amd import heatmap
+    g = np.load(os.path.join(golden_dir, "candidates.npz"))
+    out = heatmap.candidate_bbox(g["centre"], g["sizes"], int(g["k"]), float(g["image_size"]))
+    assert np.array_equal(out.cpu().numpy(), g["candidates"])
+    assert np.array_equal(out.cpu().numpy(), onp.candidate_bbox(g["centre"], g["sizes"], int(g["k"]), float(g["image_size"])))
+    nms = heatmap.heatmap_nms(torch.from_numpy(g["centre"][:, None].copy()).to(dev), 11)[:, 0]
+    o2 = heatmap.candidate_bbox(nms, None, 5, 256.0).cpu().numpy()
+    want = onp.candidate_bbox(onp.heatmap_nms(g["centre"][:, None], 11)[:, 0], None, 5, 256.0)
+    assert np.array_equal(o2, want)

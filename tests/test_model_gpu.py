@@ -681,35 +681,46 @@ def test_eval_tables_are_cached_and_invalidated(dev):
     assert float((y6 - y5).abs().max()) <= 1e-3 * float(y5.abs().max())
 
 
-@pytest.mark.parametrize("kind", ["pw", "dw", "dense3x3"])
+@pytest.mark.parametrize("kind", ["pw", "dw1", "dw3", "dense3x3"])
 def test_batchnorm_statistics_large_mean(dev, kind):
     """BatchNorm batch statistics when |mean| = 1000 x sigma at the convolution output (E[x^2] - E[x]^2 cancels 6 digits):
-    the epilogues promote their per-tile fp32 partial sums to double, so the normalised output stays within 2e-3 of the
-    float64 oracle -- the inherent fp32 resolution of the convolution output itself (1000 +- 1 carries ~1e-4 per element).
-    A running fp32 sum of squares over the 16K pixels of this test loses the variance altogether."""
+    the epilogues promote their per-tile fp32 partial sums to double.  Checked where it shows: the batch VARIANCE (through
+    running_var, momentum 0.1 on an initial value 1) within 1e-3 of the float64 oracle -- a running fp32 sum of squares over
+    the 16K pixels per channel of this test is off by tens of percent -- and the normalised output no further from float64
+    than 3x the oracle's own fp32 CPU run (the convolution output itself only resolves 1000 +- 1 to ~1e-4)."""
     from litehandnet_amd import repblocks
     r = np.random.Generator(np.random.PCG64(77))
     c = 64
-    if kind == "pw":
-        ours, ref = repblocks.RepConv(c, c, 1, activation=None), torch_ref.RepConv(c, c, 1, activation=None)
-    elif kind == "dw":
-        ours = repblocks.RepConv(c, c, 3, 1, 1, groups=c, activation=None)
-        ref = torch_ref.RepConv(c, c, 3, 1, 1, groups=c, activation=None)
-    else:
-        ours, ref = repblocks.RepConv(c, c, 3, 1, 1, activation=None), torch_ref.RepConv(c, c, 3, 1, 1, activation=None)
+    mk = {"pw": lambda M: M.RepConv(c, c, 1, activation=None), "dw1": lambda M: M.RepConv(c, c, 1, groups=c, activation=None),
+          "dw3": lambda M: M.RepConv(c, c, 3, 1, 1, groups=c, activation=None), "dense3x3": lambda M: M.RepConv(c, c, 3, 1, 1, activation=None)}[kind]
+    ours, ref = mk(repblocks), mk(torch_ref)
     sd = synth.synth_state_dict(ref, 3)
     w = sd["conv.conv.weight"]
-    sd["conv.conv.weight"] = w - w.mean(dim=(1, 2, 3), keepdim=True) + 1.0 / w[0].numel()      # every output: sum of weights = 1
+    if kind == "pw":
+        w = w - w.mean(dim=(1, 2, 3), keepdim=True) + 1.0 / w[0].numel()          # every output feature: weights sum to 1
+    else:                                                                          # (near-)identity kernels: no border effect
+        d = torch.zeros_like(w)
+        k = w.shape[-1] // 2
+        if w.shape[1] == 1:
+            d[:, 0, k, k] = 1.0
+        else:
+            d[torch.arange(c), torch.arange(c), k, k] = 1.0
+        w = d + 1e-5 * w
+    sd["conv.conv.weight"] = w
+    sd["conv.bn.running_var"] = torch.ones_like(sd["conv.bn.running_var"])
     ref.load_state_dict(sd); ours.load_state_dict(sd)
     x = torch.from_numpy((1000.0 + r.standard_normal((4, c, 64, 64))).astype(np.float32))
+    ref32 = copy.deepcopy(ref).train()
     ours.to(dev).train(); ref.double().train()
     with torch.no_grad():
-        y, y64 = ours(x.to(dev)), ref(x.double())
-    pre = torch.nn.functional.conv2d(x.double(), sd["conv.conv.weight"].double(), padding=(0 if kind == "pw" else 1),
-                                     groups=(c if kind == "dw" else 1))
-    ratio = float(pre.mean().abs() / pre.std())
+        y, y64, y32 = ours(x.to(dev)), ref(x.double()), ref32(x)
+    pad = 0 if w.shape[-1] == 1 else 1
+    pre = torch.nn.functional.conv2d(x.double(), w.double(), padding=pad, groups=(c if w.shape[1] == 1 else 1))
+    ratio = float((pre.mean(dim=(0, 2, 3)).abs() / pre.std(dim=(0, 2, 3))).min())
     assert ratio > 300, ratio                                    # the premise: mean >> sigma at the BatchNorm input
-    e = float((y.cpu().double() - y64).abs().max() / y64.abs().max())
-    assert e < 2e-3, (kind, e, ratio)
     rv = dict(ours.named_buffers())["conv.bn.running_var"].cpu().double()
-    assert torch.allclose(rv, dict(ref.named_buffers())["conv.bn.running_var"], rtol=2e-3), kind
+    rv64 = dict(ref.named_buffers())["conv.bn.running_var"]
+    bvar, bvar64 = (rv - 0.9) / 0.1, (rv64 - 0.9) / 0.1            # the batch variance behind the momentum update
+    assert float(((bvar - bvar64).abs() / bvar64).max()) < 1e-3, (kind, float(((bvar - bvar64).abs() / bvar64).max()))
+    e, e32 = _rel(y, y64), _rel(y32, y64)
+    assert e < max(5e-4, 3 * e32), (kind, e, e32, ratio)

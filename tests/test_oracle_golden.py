@@ -313,3 +313,18 @@ def test_hourglass_fixtures(golden_dir):
         y = m(synth.synth_images(int(g["n"]), int(g["size"]), int(g["seed"])))
         assert tuple(y.shape) == g["heatmap"].shape and y.shape[1] == ns
         assert np.abs(y.detach().numpy() - g["heatmap"]).max() <= 1e-5 * np.abs(g["heatmap"]).max()
+
+
+def test_flip_and_candidates_fixtures(golden_dir):
+    """oracle random_flip / candidate_bbox against the reference-generated vectors (make_golden_r2.py)."""
+    g = np.load(os.path.join(golden_dir, "random_flip.npz"))
+    pairs = g["pairs"].tolist()
+    for i in range(g["images"].shape[0]):
+        if g["flipped"][i]:
+            im, j, v, c = onp.random_flip(g["images"][i], g["joints"][i], g["visible"][i], g["center"][i], pairs)
+            assert np.array_equal(im, g["out_images"][i]) and np.array_equal(j, g["out_joints"][i])
+            assert np.array_equal(v, g["out_visible"][i]) and np.array_equal(c, g["out_center"][i])
+        else:
+            assert np.array_equal(g["images"][i], g["out_images"][i]) and np.array_equal(g["joints"][i], g["out_joints"][i])
+    c = np.load(os.path.join(golden_dir, "candidates.npz"))
+    assert np.array_equal(onp.candidate_bbox(c["centre"], c["sizes"], int(c["k"]), float(c["image_size"])), c["candidates"])
