@@ -39,7 +39,8 @@ __global__ void __launch_bounds__(256) k_dw_fwd(lhn_view x, const float* __restr
     f4 gate = (f4){1.f, 1.f, 1.f, 1.f};
     if (x.gate) gate = *reinterpret_cast<const f4*>(x.gate + (size_t)n * x.cstride + cin);
     float* yout = y.data + (size_t)row * y.W * y.cstride + cout;
-    f4 s = (f4){0.f, 0.f, 0.f, 0.f}, q = s;
+    f4 s = (f4){0.f, 0.f, 0.f, 0.f}, q = s, kk = s;     // shifted by the row's first value (see TileStat)
+    int cnt = 0;
     for (int wo = pl; wo < y.W; wo += PL) {
       f4 acc = (f4){0.f, 0.f, 0.f, 0.f};
       // branch-free taps: clamped (always in-bounds) addresses, so all K*K loads issue back to back
@@ -64,11 +65,13 @@ __global__ void __launch_bounds__(256) k_dw_fwd(lhn_view x, const float* __restr
         acc += (ok[t] ? v : (f4){0.f, 0.f, 0.f, 0.f}) * wt[t];
       }
       *reinterpret_cast<f4*>(yout + wo * y.cstride) = acc;
-      s += acc;
-      q += acc * acc;
+      if (cnt == 0) kk = acc;
+      const f4 d = acc - kk;
+      s += d;
+      q += d * d;
+      ++cnt;
     }
-    sd[0] += s.x; sd[1] += s.y; sd[2] += s.z; sd[3] += s.w;
-    qd[0] += q.x; qd[1] += q.y; qd[2] += q.z; qd[3] += q.w;
+    lhn_unshift4(sd, qd, s, q, kk, cnt);
   }
   if (stats) {
     double* st = stats + (size_t)(blockIdx.x % LHN_STAT_REPLICAS) * 2 * C;
@@ -646,7 +649,8 @@ __global__ void __launch_bounds__(256) k_dwk_fwd_lds(lhn_view x, const float* __
     __syncthreads();
     if (t + (int)gridDim.x < ntile) issue(t + gridDim.x);
     const int wo = tw * TW + pl;
-    f4 s = (f4){0.f, 0.f, 0.f, 0.f}, q = s;
+    f4 s = (f4){0.f, 0.f, 0.f, 0.f}, q = s, kk = s;      // shifted by the tile's first value (see TileStat)
+    int cnt = 0;
     if (wo < SW) {
       const f4* col = tile + (pl + T::P) * 8 + c4;    // centre column of this thread, tile row 0
       float* yout = y.data + ((size_t)(n * y.H + pa + ps * th * TH) * y.W + pb + ps * wo) * y.cstride + cout;
@@ -674,8 +678,11 @@ __global__ void __launch_bounds__(256) k_dwk_fwd_lds(lhn_view x, const float* __
 #pragma unroll
               for (int b = 0; b < 3; ++b) acc += win[a][b] * wt[a * 3 + b];
             *reinterpret_cast<f4*>(yout + (size_t)rr * ps * y.W * y.cstride) = acc;
-            s += acc;
-            q += acc * acc;
+            if (cnt == 0) kk = acc;
+            const f4 d = acc - kk;
+            s += d;
+            q += d * d;
+            ++cnt;
           }
         }
       } else {
@@ -688,13 +695,15 @@ __global__ void __launch_bounds__(256) k_dwk_fwd_lds(lhn_view x, const float* __
             for (int b = 0; b < K; ++b)
               acc += col[((rr + a * DIL) * T::WW + (b * DIL - T::P)) * 8] * wl[(a * K + b) * 8 + c4];
           *reinterpret_cast<f4*>(yout + (size_t)rr * ps * y.W * y.cstride) = acc;
-          s += acc;
-          q += acc * acc;
+          if (cnt == 0) kk = acc;
+          const f4 d = acc - kk;
+          s += d;
+          q += d * d;
+          ++cnt;
         }
       }
     }
-    sd[0] += s.x; sd[1] += s.y; sd[2] += s.z; sd[3] += s.w;
-    qd[0] += q.x; qd[1] += q.y; qd[2] += q.z; qd[3] += q.w;
+    lhn_unshift4(sd, qd, s, q, kk, cnt);
   }
   if (stats) {
     const int C = x.C;

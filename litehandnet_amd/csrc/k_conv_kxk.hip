@@ -258,7 +258,8 @@ __global__ void __launch_bounds__(256) k_kxk(lhn_view x, const float* __restrict
     for (int j = 0; j < NT; ++j) {
       const int ch = n0 + j * 32 + l31;
       if (ch >= nout) continue;
-      float ts = 0.f, tq = 0.f;
+      TileStat ts;
+      ts.reset();
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = mbase + (r & 3) + 8 * (r >> 2);
@@ -266,8 +267,7 @@ __global__ void __launch_bounds__(256) k_kxk(lhn_view x, const float* __restrict
           const float v = acc[j][r];
           if (MODE == 0) {
             y.data[(size_t)m * y.cstride + y.coff + ch] = v;
-            ts += v;
-            tq += v * v;
+            ts.add(v);
           } else {
             size_t pix = (size_t)m;
             if (par) {
@@ -279,10 +279,7 @@ __global__ void __launch_bounds__(256) k_kxk(lhn_view x, const float* __restrict
           }
         }
       }
-      if (MODE == 0) {
-        ssum[j] += (double)ts;
-        ssq[j] += (double)tq;
-      }
+      if (MODE == 0) ts.flush(ssum[j], ssq[j]);
     }
   }
   if (MODE == 0 && stats) {

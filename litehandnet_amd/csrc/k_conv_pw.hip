@@ -136,8 +136,8 @@ __global__ void __launch_bounds__(256, NS > 1 ? 1 : ((CIN == 64 && NT == 2) || (
     }
   };
 
-  // BatchNorm statistics: fp32 partial sums over ONE tile (16 values per lane), promoted to double per tile -- a running
-  // fp32 sum of squares over thousands of pixels loses the variance when |mean| >> sigma (E[x^2] - E[x]^2 cancels)
+  // BatchNorm statistics: shifted fp32 partial sums over ONE tile (16 values per lane), un-shifted into double per tile
+  // (TileStat) -- a running fp32 sum of squares loses the variance when |mean| >> sigma (E[x^2] - E[x]^2 cancels)
   double ssum[NT], ssq[NT];
   float bv[NT];
 #pragma unroll
@@ -196,7 +196,8 @@ __global__ void __launch_bounds__(256, NS > 1 ? 1 : ((CIN == 64 && NT == 2) || (
           }
         }
       } else {
-        float ts = 0.f, tq = 0.f;
+        TileStat ts;
+        ts.reset();
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int m = mbase + (r & 3) + 8 * (r >> 2);
@@ -205,12 +206,10 @@ __global__ void __launch_bounds__(256, NS > 1 ? 1 : ((CIN == 64 && NT == 2) || (
             float v = acc[nt][r] + bv[nt];
             if (geo.yacc) v += *dst;
             *dst = v;
-            ts += v;
-            tq += v * v;
+            ts.add(v);
           }
         }
-        ssum[nt] += (double)ts;
-        ssq[nt] += (double)tq;
+        ts.flush(ssum[nt], ssq[nt]);
       }
     }
     __syncthreads();
@@ -386,19 +385,18 @@ k_pw_fwd_wr(lhn_view x, const float* __restrict__ w, const float* __restrict__ b
     if (co < cout) {
       const int mbase = tile * BM + pxs * 32 + 4 * lh;
       float* yo = y.data + y.coff + co;
-      float ts = 0.f, tq = 0.f;
+      TileStat ts;
+      ts.reset();
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = mbase + (r & 3) + 8 * (r >> 2);
         if (m < M) {
           const float v = acc[r] + bv;
           yo[(int64_t)m * y.cstride] = v;
-          ts += v;
-          tq += v * v;
+          ts.add(v);
         }
       }
-      ssum += (double)ts;
-      ssq += (double)tq;
+      ts.flush(ssum, ssq);
     }
     __syncthreads();
   }

@@ -427,6 +427,39 @@ __device__ __forceinline__ Xf4 lhn_load_xf_t(const float* tab, int cstride, int 
   return t;
 }
 
+// Per-tile BatchNorm partial sums, SHIFTED: within one tile a thread accumulates sum(v - K) and sum((v - K)^2) in fp32 with
+// K = the first value it saw in this tile (differences of the order of sigma: no cancellation, full fp32 relative accuracy
+// even when |mean| = 1000 sigma), and un-shifts in double when the tile is done:
+//   sum v   = s + n K            sum v^2 = q + 2 K s + n K^2
+struct TileStat {
+  float k, s, q;
+  int n;
+  __device__ __forceinline__ void reset() { n = 0; k = s = q = 0.f; }
+  __device__ __forceinline__ void add(float v) {
+    if (n == 0) k = v;
+    const float d = v - k;
+    s += d;
+    q += d * d;
+    ++n;
+  }
+  __device__ __forceinline__ void flush(double& sum, double& sq) const {
+    const double K = (double)k, S = (double)s;
+    sum += S + (double)n * K;
+    sq += (double)q + 2.0 * K * S + (double)n * K * K;
+  }
+};
+
+// float4 form: sd / qd (double[4]) += the un-shifted sums of n values accumulated as s = sum(v - k), q = sum((v - k)^2)
+__device__ __forceinline__ void lhn_unshift4(double (&sd)[4], double (&qd)[4], f4 s, f4 q, f4 k, int n) {
+  const float sv[4] = {s.x, s.y, s.z, s.w}, qv[4] = {q.x, q.y, q.z, q.w}, kv[4] = {k.x, k.y, k.z, k.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const double K = (double)kv[j], S = (double)sv[j];
+    sd[j] += S + (double)n * K;
+    qd[j] += (double)qv[j] + 2.0 * K * S + (double)n * K * K;
+  }
+}
+
 // The same reduction for DOUBLE per-thread sums (convolution epilogues promote their per-tile fp32 partials to double: a
 // running fp32 sum of squares over thousands of pixels loses the variance when |mean| >> sigma).  red: >= 32*C4 doubles.
 __device__ __forceinline__ void lhn_block_stat_atomics_d(const double (&s)[4], const double (&q)[4], int C4, double* red,

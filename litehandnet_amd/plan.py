@@ -628,7 +628,11 @@ class PlanBuilder:
                               f=(bn.eps, bn.momentum)))
             else:
                 raise AssertionError(k)
-        if os.environ.get("LHN_DEFER_FINALIZE", "1") != "0":
+        # measured on MI355X (profiles/r02c_*): every workgroup of the reader re-reading the replicated sums costs more than
+        # the ~5.7 us single-workgroup launch it removes (3x3 depthwise 21.7 -> 30.3 us, forward 2.75 -> 2.88 ms), so the
+        # separate finalize stays the default; LHN_DEFER_FINALIZE=1 selects the deferred form
+        self.deferred = 0
+        if os.environ.get("LHN_DEFER_FINALIZE", "0") == "1":
             self._defer_finalizes(fwd)
         # ---------------- backward
         if self.with_backward:

@@ -724,3 +724,20 @@ def test_batchnorm_statistics_large_mean(dev, kind):
     assert float(((bvar - bvar64).abs() / bvar64).max()) < 1e-3, (kind, float(((bvar - bvar64).abs() / bvar64).max()))
     e, e32 = _rel(y, y64), _rel(y32, y64)
     assert e < max(5e-4, 3 * e32), (kind, e, e32, ratio)
+
+
+def test_deferred_finalize_mode(dev, monkeypatch):
+    """LHN_DEFER_FINALIZE=1: the first reader of every convolution output folds the BatchNorm statistics into the table in
+    its prologue (lhn_pend) instead of a separate finalize launch.  Same bars as the default mode: forward, gradients,
+    running statistics and num_batches_tracked (updated exactly once, by workgroup 0 of the reader) -- blocks and the whole
+    variant B, whose 52 BatchNorms all take this path."""
+    from litehandnet_amd import get_model, litehourglass as lh
+    monkeypatch.setenv("LHN_DEFER_FINALIZE", "1")
+    _check_block(lh.MSRB(64, 64, "ca", p_drop=0.0), torch_ref.MSRB(64, 64, "ca", 0.0), _x(4, 64, 16, 16), dev, seed=31)
+    _check_block(lh.RepBasicUnit(64, 64, "ca", p_drop=0.0), torch_ref.RepBasicUnit(64, 64, "ca", 0.0), _x(4, 64, 12, 12), dev, seed=32)
+    cfg = litehandnet_cfg("B")
+    cfg.MODEL["ca_dropout"] = 0.0
+    ours, ref = get_model(cfg), torch_ref.get_model(cfg, p_drop=0.0)
+    _check_block(ours, ref, synth.synth_images(8, 64, 33), dev, seed=34, no_dx=True, grad_tol=2e-2)
+    plan = next(iter(ours.__dict__["_engine"].plans.values()))
+    assert plan.pb.deferred == 52

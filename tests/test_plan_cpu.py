@@ -164,8 +164,9 @@ def test_lazy_sums_are_summed_on_load():
 def test_deferred_finalizes(monkeypatch):
     """Every train-mode BatchNorm of variant B is finalized by the first reader of its convolution's output (lhn_pend): the
     producer is flagged, exactly one later op lists it, readers are kernels that can do it and hold at most two; the
-    switch LHN_DEFER_FINALIZE=0 restores the separate launches."""
+    default (LHN_DEFER_FINALIZE unset / 0) keeps the separate launches."""
     from litehandnet_amd.plan import AVGPOOL, DW, EW, KXK, MAXPOOL, PW, STEM
+    monkeypatch.setenv("LHN_DEFER_FINALIZE", "1")          # (off by default: measured slower, see PlanBuilder.finalize)
     _, pb, _ = _build("B", backward=True)
     cb, cf, cbw, nf, nb = pb.finalize()
     fwd = [cf[i] for i in range(nf)]
