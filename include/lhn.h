@@ -231,6 +231,12 @@ int lhn_bn_finalize(const double* stats, const float* gamma, const float* beta, 
                     float* running_var, int64_t* num_batches_tracked, float* table, int cstride, int coff,
                     int C, float* save_mean_invstd /*[2][C]*/, double count, float eps, float momentum,
                     float slope, int training, const float* conv_bias /*or NULL*/, void* stream);
+/* stat_channels >= C: the statistics / save arrays were laid out for a view padded to a multiple of 4 (lite_hrnet.py:84-96:
+ * BatchNorm over 7 / 17 / 37 channels behind a 1x1 whose output view has 8 / 20 / 40) */
+int lhn_bn_finalize2(const double* stats, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                     int64_t* num_batches_tracked, float* table, int cstride, int coff, int C, int stat_channels,
+                     float* save_mean_invstd, double count, float eps, float momentum, float slope, int training,
+                     const float* conv_bias, void* stream);
 int lhn_table_fill(float* table, int cstride, int coff, int C, float scale, float shift, float slope,
                    void* stream);
 
@@ -249,11 +255,33 @@ int lhn_fold_bn(const float* w, int kb, const float* gamma, const float* beta, c
 /* out_slope == LHN_SLOPE_SILU selects SiLU instead of a leaky ReLU as the combine's output activation (the
  * BN -> SiLU -> conv pre-activation unit of models/pose_hg_ms_att.py:76-90; single same-size source in backward) */
 #define LHN_SLOPE_SILU 2.0f
+/* out_slope == LHN_SLOPE_RELU_SIGMOID: sigmoid(relu(v)) -- the nn.ReLU + nn.Sigmoid pairs of lite_hrnet.py:62-70,86-97
+ * (single same-size source in backward, like SiLU) */
+#define LHN_SLOPE_RELU_SIGMOID 3.0f
 int lhn_ew_fwd(const lhn_view* srcs, int nsrc, const lhn_view* dst, float out_slope, void* stream);
 /* dst = act(sum_i coef[i] * value_i); coef == NULL: all ones (host pointer, nsrc floats) */
 int lhn_ew_fwd2(const lhn_view* srcs, int nsrc, const float* coef, const lhn_view* dst, float out_slope, void* stream);
+/* mode bit 0: PRODUCT of the sources instead of their sum (lite_hrnet.py:105-107, s * F.interpolate(a, nearest));
+ * mode bit 1: smaller sources are resampled bilinearly with align_corners=True (lite_hrnet.py:272-275) instead of nearest.
+ * Backward of the product: lhn_ew_mul_bwd per operand; of a bilinear source: lhn_bilinear_bwd (same-size sources of
+ * that combine: lhn_ew_bwd2 as usual). */
+int lhn_ew_fwd3(const lhn_view* srcs, int nsrc, const float* coef, const lhn_view* dst, float out_slope, int mode, void* stream);
+int lhn_ew_mul_bwd(const lhn_view* src, const lhn_view* other, const lhn_view* dst, const float* ddst, float* dsrc,
+                   int accumulate, void* stream);
+int lhn_bilinear_bwd(const lhn_view* src, const lhn_view* dst, const float* ddst, float* dsrc, int accumulate, float out_slope,
+                     void* stream);
+/* channel_shuffle(torch.cat([a, b], 1), groups = 2) (lite_hrnet.py:29-52,141-142,246-247): dst[2j] = value(a)[j],
+ * dst[2j+1] = value(b)[j]; dst stored plain.  Backward hands d(dst) back to the operands' gradient buffers. */
+int lhn_shuffle2_fwd(const lhn_view* a, const lhn_view* b, const lhn_view* dst, void* stream);
+int lhn_shuffle2_bwd(const lhn_view* a, const lhn_view* b, const lhn_view* dst, const float* ddst, float* da, int acc_a,
+                     float* db, int acc_b, void* stream);
 int lhn_maxpool2_fwd(const lhn_view* x, const lhn_view* y, void* stream);
 int lhn_avgpool_fwd(const lhn_view* x, float* out /*[N,OH,OW,x.C]*/, int OH, int OW, void* stream);
+/* ... into channels [out_coff, out_coff + x.C) of an [N,OH,OW,out_cstride] tensor: the pooled branches of
+ * CrossResolutionWeighting land side by side, torch.cat needs no copy (lite_hrnet.py:99-102) */
+int lhn_avgpool_fwd2(const lhn_view* x, float* out, int OH, int OW, int out_cstride, int out_coff, void* stream);
+int lhn_avgpool_bwd2(const lhn_view* x, const float* dout, int OH, int OW, int out_cstride, int out_coff, float* dx,
+                     int dx_accumulate, void* stream);
 /* gamma == NULL: deployed attention, `beta` is the bias of the fused depthwise conv, no BatchNorm (eval only) */
 int lhn_ca_mlp_fwd(const float* pooled /*[N,9,C]*/, const float* w3 /*[C,1,3,3]*/, const float* gamma,
                    const float* beta, float* rmean, float* rvar, int64_t* nbt, const float* w1 /*[C/2,C]*/,
@@ -283,6 +311,12 @@ int lhn_att_mlp_bwd(const float* pooled, const float* gamma, const float* beta, 
 int lhn_se_mlp_fwd(const float* pooled, const float* w1 /*[J,C]*/, const float* b1, const float* w2 /*[C,J]*/,
                    const float* b2, float* gate, int gate_stride, int gate_coff, float* save, int N, int C, int J,
                    void* stream);
+/* mode 1: SpatialWeighting of lite_hrnet.py:55-74 -- sigmoid(relu(.)) after both 1x1 convolutions (mode 0 = SEBlock) */
+int lhn_se_mlp_fwd2(const float* pooled, const float* w1, const float* b1, const float* w2, const float* b2, float* gate,
+                    int gate_stride, int gate_coff, float* save, int N, int C, int J, int mode, void* stream);
+int lhn_se_mlp_bwd2(const float* pooled, const float* w1, const float* w2, const float* save, const float* dgate,
+                    float* dpool, int cstride, int coff, int H, int W, float* dw1, float* db1, float* dw2, float* db2, int N,
+                    int C, int J, int mode, void* stream);
 int lhn_se_mlp_bwd(const float* pooled, const float* w1, const float* w2, const float* save, const float* dgate /*[N,C]*/,
                    float* dpool /*[N,25,cstride]*/, int cstride, int coff, int H, int W, float* dw1, float* db1, float* dw2,
                    float* db2, int N, int C, int J, void* stream);
@@ -293,6 +327,9 @@ int lhn_bn_bwd_reduce(const lhn_view* y, const lhn_gradview* g, const float* sav
 int lhn_bn_bwd_finalize(const double* sums, const float* gamma, const float* save_mean_invstd,
                         float* coef, int cstride, int coff, int C, double count, float* dgamma, float* dbeta,
                         float pgrad_scale /*1, or 1/world under SyncBatchNorm*/, void* stream);
+int lhn_bn_bwd_finalize2(const double* sums, const float* gamma, const float* save_mean_invstd, float* coef, int cstride,
+                         int coff, int C, int stat_channels, double count, float* dgamma, float* dbeta, float pgrad_scale,
+                         void* stream);
 int lhn_conv_pw_bwd(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy,
                     float* dx /*grad buffer of x, same geometry, or NULL*/, int dx_accumulate, float* dw,
                     float* dbias, int stride, const float* dy_nchw, int nrep, int64_t rep_stride, void* stream);

@@ -44,6 +44,8 @@ def litehandnet_cfg(variant="A", channels=128, num_joints=21, image_size=256, **
     elif variant == "H":            # stacked hourglass, config/hourglass/_2_rhd2d_256x256_dark_h2.py:4-10 (num_stack 2; _3_*_h1: 1)
         model = dict(name="hourglass", input_channel=256 if channels == 128 else channels, output_channel=num_joints,
                      num_stack=2, num_level=4)
+    elif variant == "L":            # Lite-HRNet, config/litehrnet/_2_rhd2d_256x256_dark_18.py:4-9 (depth 18; _1_*_30: depth 30)
+        model = dict(name="litehrnet", depth=18, output_channel=num_joints)
     else:
         raise ValueError(variant)
     model.update(model_kw)

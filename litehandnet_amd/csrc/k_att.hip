@@ -265,7 +265,9 @@ extern "C" int lhn_att_mlp_bwd(const float* pooled, const float* gamma, const fl
 __global__ void __launch_bounds__(256) k_se_fwd(const float* __restrict__ pooled, const float* __restrict__ w1,
                                                 const float* __restrict__ b1, const float* __restrict__ w2,
                                                 const float* __restrict__ b2, float* __restrict__ save, float* __restrict__ gate,
-                                                int gs, int gcoff, int N, int C, int J) {
+                                                int gs, int gcoff, int N, int C, int J, int mode) {
+  // mode 0: SEBlock (common.py:23-37) relu inside, sigmoid outside; mode 1: SpatialWeighting (lite_hrnet.py:55-74):
+  // sigmoid(relu(.)) after BOTH 1x1 convolutions
   __shared__ float sp[256], sh[64];
   const int n = blockIdx.x;
   for (int c = threadIdx.x; c < C; c += blockDim.x) sp[c] = pooled[(int64_t)n * C + c];
@@ -274,6 +276,7 @@ __global__ void __launch_bounds__(256) k_se_fwd(const float* __restrict__ pooled
     float v = b1[j];
     for (int c = 0; c < C; ++c) v += w1[j * C + c] * sp[c];
     v = fmaxf(v, 0.f);
+    if (mode == 1) v = 1.f / (1.f + expf(-v));
     sh[j] = v;
     save[(int64_t)n * J + j] = v;
   }
@@ -281,7 +284,7 @@ __global__ void __launch_bounds__(256) k_se_fwd(const float* __restrict__ pooled
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     float v = b2[c];
     for (int j = 0; j < J; ++j) v += w2[c * J + j] * sh[j];
-    const float g = 1.f / (1.f + expf(-v));
+    const float g = 1.f / (1.f + expf(-(mode == 1 ? fmaxf(v, 0.f) : v)));
     save[(int64_t)N * J + (int64_t)n * C + c] = g;
     gate[(int64_t)n * gs + gcoff + c] = g;
   }
@@ -293,13 +296,15 @@ __global__ void __launch_bounds__(256) k_se_bwd(const float* __restrict__ pooled
                                                 const float* __restrict__ w2, const float* __restrict__ save,
                                                 const float* __restrict__ dgate, float* __restrict__ dpool, int cs, int coff,
                                                 float inv_hw, float* __restrict__ dw1, float* __restrict__ db1,
-                                                float* __restrict__ dw2, float* __restrict__ db2, int N, int C, int J) {
+                                                float* __restrict__ dw2, float* __restrict__ db2, int N, int C, int J, int mode) {
+  // mode 1: sigmoid(relu(v)) has derivative g(1-g) where v > 0, i.e. where g > 1/2, and 0 elsewhere (both layers)
   __shared__ float sp[256], sh[64], sdz[256], sdh[64];
   const int n = blockIdx.x;
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     sp[c] = pooled[(int64_t)n * C + c];
     const float g = save[(int64_t)N * J + (int64_t)n * C + c];
-    const float dz = dgate[(int64_t)n * C + c] * g * (1.f - g);
+    float dz = dgate[(int64_t)n * C + c] * g * (1.f - g);
+    if (mode == 1 && !(g > 0.5f)) dz = 0.f;
     sdz[c] = dz;
     atomicAdd(db2 + c, dz);
   }
@@ -309,7 +314,8 @@ __global__ void __launch_bounds__(256) k_se_bwd(const float* __restrict__ pooled
   for (int j = threadIdx.x; j < J; j += blockDim.x) {
     float d = 0.f;
     for (int c = 0; c < C; ++c) d += w2[c * J + j] * sdz[c];
-    d = sh[j] > 0.f ? d : 0.f;
+    if (mode == 1) d = sh[j] > 0.5f ? d * sh[j] * (1.f - sh[j]) : 0.f;
+    else d = sh[j] > 0.f ? d : 0.f;
     sdh[j] = d;
     atomicAdd(db1 + j, d);
   }
@@ -323,23 +329,37 @@ __global__ void __launch_bounds__(256) k_se_bwd(const float* __restrict__ pooled
   }
 }
 
+extern "C" int lhn_se_mlp_fwd2(const float* pooled, const float* w1, const float* b1, const float* w2, const float* b2, float* gate,
+                               int gate_stride, int gate_coff, float* save, int N, int C, int J, int mode, void* stream);
 extern "C" int lhn_se_mlp_fwd(const float* pooled, const float* w1, const float* b1, const float* w2, const float* b2, float* gate,
                               int gate_stride, int gate_coff, float* save, int N, int C, int J, void* stream) {
+  return lhn_se_mlp_fwd2(pooled, w1, b1, w2, b2, gate, gate_stride, gate_coff, save, N, C, J, 0, stream);
+}
+extern "C" int lhn_se_mlp_fwd2(const float* pooled, const float* w1, const float* b1, const float* w2, const float* b2, float* gate,
+                               int gate_stride, int gate_coff, float* save, int N, int C, int J, int mode, void* stream) {
   LHN_CHECK_ARG(pooled && w1 && b1 && w2 && b2 && gate && save, "lhn_se_mlp_fwd: null pointer");
   LHN_CHECK_ARG(C > 0 && C <= 256 && J > 0 && J <= 64 && N > 0, "lhn_se_mlp_fwd: C=%d J=%d (C <= 256, J <= 64)", C, J);
   hipLaunchKernelGGL(k_se_fwd, dim3(N), dim3(128), 0, (hipStream_t)stream, pooled, w1, b1, w2, b2, save, gate, gate_stride, gate_coff,
-                     N, C, J);
+                     N, C, J, mode);
   LHN_CHECK_LAUNCH("lhn_se_mlp_fwd");
   return 0;
 }
 
+extern "C" int lhn_se_mlp_bwd2(const float* pooled, const float* w1, const float* w2, const float* save, const float* dgate,
+                               float* dpool, int cstride, int coff, int H, int W, float* dw1, float* db1, float* dw2, float* db2,
+                               int N, int C, int J, int mode, void* stream);
 extern "C" int lhn_se_mlp_bwd(const float* pooled, const float* w1, const float* w2, const float* save, const float* dgate,
                               float* dpool, int cstride, int coff, int H, int W, float* dw1, float* db1, float* dw2, float* db2,
                               int N, int C, int J, void* stream) {
+  return lhn_se_mlp_bwd2(pooled, w1, w2, save, dgate, dpool, cstride, coff, H, W, dw1, db1, dw2, db2, N, C, J, 0, stream);
+}
+extern "C" int lhn_se_mlp_bwd2(const float* pooled, const float* w1, const float* w2, const float* save, const float* dgate,
+                               float* dpool, int cstride, int coff, int H, int W, float* dw1, float* db1, float* dw2, float* db2,
+                               int N, int C, int J, int mode, void* stream) {
   LHN_CHECK_ARG(pooled && w1 && w2 && save && dgate && dpool && dw1 && db1 && dw2 && db2, "lhn_se_mlp_bwd: null pointer");
   LHN_CHECK_ARG(C > 0 && C <= 256 && J > 0 && J <= 64 && N > 0 && H > 0 && W > 0, "lhn_se_mlp_bwd: C=%d J=%d", C, J);
   hipLaunchKernelGGL(k_se_bwd, dim3(N), dim3(256), 0, (hipStream_t)stream, pooled, w1, w2, save, dgate, dpool, cstride, coff,
-                     1.f / (float)(H * W), dw1, db1, dw2, db2, N, C, J);
+                     1.f / (float)(H * W), dw1, db1, dw2, db2, N, C, J, mode);
   LHN_CHECK_LAUNCH("lhn_se_mlp_bwd");
   return 0;
 }

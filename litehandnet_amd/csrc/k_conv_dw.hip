@@ -41,7 +41,7 @@ __global__ void __launch_bounds__(256) k_dw_fwd(lhn_view x, const float* __restr
     float* yout = y.data + (size_t)row * y.W * y.cstride + cout;
     f4 s = (f4){0.f, 0.f, 0.f, 0.f}, q = s, kk = s;     // shifted by the row's first value (see TileStat)
     int cnt = 0;
-    for (int wo = pl; wo < y.W; wo += PL) {
+    for (int wo = LHN_LANE0(pl, PL); wo < y.W; wo += PL) {
       f4 acc = (f4){0.f, 0.f, 0.f, 0.f};
       // branch-free taps: clamped (always in-bounds) addresses, so all K*K loads issue back to back
       f4 raw[KK];
@@ -76,9 +76,9 @@ __global__ void __launch_bounds__(256) k_dw_fwd(lhn_view x, const float* __restr
   if (stats) {
     double* st = stats + (size_t)(blockIdx.x % LHN_STAT_REPLICAS) * 2 * C;
     double* redd = reinterpret_cast<double*>(red);          // [256][2] float4 = 1024 doubles
-    if (C4 <= 32) {
+    if (C4 <= 32 && (C4 & (C4 - 1)) == 0) {
       lhn_block_stat_atomics_d(sd, qd, C4, redd, st, st + C);
-    } else {                                                // C = 256: one thread per (channel group, pixel lane), PL = 4
+    } else {                                                // any other C: one LDS slot per (channel group, pixel lane)
       __syncthreads();
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -238,7 +238,7 @@ extern "C" int lhn_conv_dw_fwd(const lhn_view* x, const float* w, const lhn_view
   lhn_bnfin fin;
   if (finp && stats) fin = *finp; else fin.counter = nullptr;
   LHN_CHECK_ARG(lhn_view_ok(x) && lhn_view_ok(y) && (w || k == 1), "lhn_conv_dw_fwd: bad view / null pointer (w may be NULL = ones only for k=1)");
-  LHN_CHECK_ARG(x->C == y->C && pow2(x->C) && x->C <= 256, "lhn_conv_dw_fwd: channels %d -> %d (power of two <= 256)", x->C, y->C);
+  LHN_CHECK_ARG(x->C == y->C && x->C % 4 == 0 && x->C <= 512, "lhn_conv_dw_fwd: channels %d -> %d (multiple of 4, <= 512)", x->C, y->C);
   LHN_CHECK_ARG((k == 1 || k == 3 || k == 5 || k == 7) && stride >= 1 && dil >= 1 && pad >= 0, "lhn_conv_dw_fwd: k=%d stride=%d dil=%d", k, stride, dil);
   const int Ho = (x->H + 2 * pad - dil * (k - 1) - 1) / stride + 1, Wo = (x->W + 2 * pad - dil * (k - 1) - 1) / stride + 1;
   LHN_CHECK_ARG(y->N == x->N && y->H == Ho && y->W == Wo, "lhn_conv_dw_fwd: output %dx%d, expected %dx%d", y->H, y->W, Ho, Wo);
@@ -331,7 +331,7 @@ __global__ void __launch_bounds__(256) k_dw_bwd_data(lhn_view x, const float* __
     f4 gate = (f4){1.f, 1.f, 1.f, 1.f};
     if (y.gate) gate = *reinterpret_cast<const f4*>(y.gate + (size_t)n * y.cstride + cy);
     float* dxr = dx + (size_t)row * x.W * x.cstride + cx;
-    for (int wi = pl; wi < x.W; wi += PL) {
+    for (int wi = LHN_LANE0(pl, PL); wi < x.W; wi += PL) {
       f4 acc = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int kh = 0; kh < K; ++kh) {
@@ -377,7 +377,7 @@ __global__ void __launch_bounds__(256) k_dw_bwd_weight(lhn_view x, lhn_view y, l
     if (y.gate) ygate = *reinterpret_cast<const f4*>(y.gate + (size_t)n * y.cstride + cy);
     if (x.gate) xgate = *reinterpret_cast<const f4*>(x.gate + (size_t)n * x.cstride + cx);
     const float* xin = x.data + (size_t)n * x.H * x.W * x.cstride + cx;
-    for (int wo = pl; wo < y.W; wo += PL) {
+    for (int wo = LHN_LANE0(pl, PL); wo < y.W; wo += PL) {
       const size_t off = ((size_t)row * y.W + wo) * y.cstride + cy;
       f4 raw[KR * K];
       bool ok[KR * K];
@@ -481,7 +481,7 @@ extern "C" int lhn_conv_dw_bwd(const lhn_view* x, const float* w, const lhn_view
                                void* stream) {
   if (nrep < 1) nrep = 1;
   LHN_CHECK_ARG(lhn_view_ok(x) && lhn_view_ok(y) && gy && gy->dz && ((w && dw) || k == 1) && lhn_no_pend(x) && lhn_no_pend(y), "lhn_conv_dw_bwd: bad view / null pointer");
-  LHN_CHECK_ARG(x->C == y->C && pow2(x->C) && x->C <= 256, "lhn_conv_dw_bwd: channels");
+  LHN_CHECK_ARG(x->C == y->C && x->C % 4 == 0 && x->C <= 512, "lhn_conv_dw_bwd: channels");
   LHN_CHECK_ARG(k == 1 || k == 3 || k == 7, "lhn_conv_dw_bwd: k=%d (1, 3 or 7)", k);
   hipStream_t s = (hipStream_t)stream;
   if (w && dw && stride == 1 && pad == dil * (k - 1) / 2 && x->C % 32 == 0 && x->W >= 8 && !lhn_dw_force_gather() &&

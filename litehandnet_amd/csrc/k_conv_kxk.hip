@@ -20,7 +20,7 @@ __global__ void __launch_bounds__(256) k_dy_inplace(lhn_view y, lhn_gradview g, 
   const int rows = y.N * y.H;
   for (int row = blockIdx.x; row < rows; row += gridDim.x) {
     const int n = row / y.H, h = row - n * y.H;
-    for (int w = pl; w < y.W; w += PL) {
+    for (int w = LHN_LANE0(pl, PL); w < y.W; w += PL) {
       const size_t off = ((size_t)row * y.W + w) * y.cstride + ca;
       const f4 raw = *reinterpret_cast<const f4*>(y.data + off);
       const f4 du = lhn_grad_du(y, g, xf, raw, *reinterpret_cast<const f4*>(dz + off), n, h, w, ca);

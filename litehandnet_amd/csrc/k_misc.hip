@@ -17,15 +17,17 @@ __global__ void k_bn_finalize(const double* __restrict__ stats, const float* __r
                               const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
                               int64_t* __restrict__ nbt, float* __restrict__ table, int cs, int coff, int C,
                               float* __restrict__ save, double count, float eps, float momentum, float slope, int training,
-                              const float* __restrict__ cbias) {
+                              const float* __restrict__ cbias, int SC) {
+  // SC = channels of the statistics / save layout (>= C: a convolution whose output view is padded to a multiple of 4
+  // accumulates SC columns, the BatchNorm owns the first C)
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     double mean, var;
     const double cb = cbias ? (double)cbias[c] : 0.0;   // bias of the conv in front: stored output excludes it
     if (training) {
       double s1 = 0, s2 = 0;
       for (int r = 0; r < LHN_STAT_REPLICAS; ++r) {
-        s1 += stats[(size_t)r * 2 * C + c];
-        s2 += stats[(size_t)r * 2 * C + C + c];
+        s1 += stats[(size_t)r * 2 * SC + c];
+        s2 += stats[(size_t)r * 2 * SC + SC + c];
       }
       mean = s1 / count;
       var = s2 / count - mean * mean;
@@ -47,7 +49,7 @@ __global__ void k_bn_finalize(const double* __restrict__ stats, const float* __r
     table[2 * cs + coff + c] = slope;
     if (save) {
       save[c] = (float)mean;
-      save[C + c] = invstd;
+      save[SC + c] = invstd;
     }
   }
   if (training && nbt && threadIdx.x == 0) nbt[0] += 1;
@@ -76,7 +78,30 @@ struct EwSrcs {
   lhn_view v[3];
   float coef[3];     // dst = act(sum_i coef[i] * value_i)
   lhn_pends pend[3]; // BatchNorms to finalize first (see lhn_pend)
+  int mode;          // bit 0: PRODUCT of the sources instead of their sum (lite_hrnet.py:105-107: s * interpolate(a));
+                     // bit 1: smaller sources are resampled bilinearly with align_corners=True (lite_hrnet.py:272-274)
 };
+// bilinear taps of destination index d in a source axis of `in` samples (align_corners=True): i0, i1, weight of i1
+__device__ __forceinline__ void bil_taps(int d, int in, int out, int& i0, int& i1, float& w1) {
+  if (in == out || out == 1) {
+    i0 = i1 = (in == out) ? d : 0;
+    w1 = 0.f;
+    return;
+  }
+  const float pos = (float)d * ((float)(in - 1) / (float)(out - 1));
+  i0 = (int)floorf(pos);
+  if (i0 > in - 1) i0 = in - 1;
+  i1 = i0 + 1 < in ? i0 + 1 : in - 1;
+  w1 = pos - (float)i0;
+}
+// activation codes of the combine beyond a leaky slope: LHN_SLOPE_SILU (2), LHN_SLOPE_RELU_SIGMOID (3) = sigmoid(relu(v))
+// (lite_hrnet.py:62-70,86-97: nn.ReLU followed by nn.Sigmoid)
+__device__ __forceinline__ float lhn_relu_sigmoid(float v) { return 1.f / (1.f + expf(-fmaxf(v, 0.f))); }
+__device__ __forceinline__ float lhn_relu_sigmoid_grad(float v) {
+  if (!(v > 0.f)) return 0.f;
+  const float s = 1.f / (1.f + expf(-v));
+  return s * (1.f - s);
+}
 __device__ __forceinline__ int nearest_src(int d, int in, int out) {
   if (in == out) return d;
   const float sc = (float)in / (float)out;
@@ -110,15 +135,39 @@ __global__ void __launch_bounds__(256) k_ew_fwd(EwSrcs S, int nsrc, lhn_view dst
         gate[k] = v.gate ? *reinterpret_cast<const f4*>(v.gate + (size_t)n * v.cstride + ca[k]) : (f4){1.f, 1.f, 1.f, 1.f};
       }
     float* out = dst.data + (size_t)row * dst.W * dst.cstride + dst.coff + 4 * c4;
-    for (int w = pl; w < dst.W; w += PL) {
-      f4 acc = (f4){0.f, 0.f, 0.f, 0.f};
+    const bool mul = (S.mode & 1) != 0, bil = (S.mode & 2) != 0;
+    for (int w = LHN_LANE0(pl, PL); w < dst.W; w += PL) {
+      f4 acc = mul ? (f4){1.f, 1.f, 1.f, 1.f} : (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int k = 0; k < 3; ++k)
         if (k < nsrc) {
-          const int ws = nearest_src(w, S.v[k].W, dst.W);
-          acc += lhn_apply_xf(*reinterpret_cast<const f4*>(base[k] + (size_t)ws * S.v[k].cstride), xf[k]) * (gate[k] * S.coef[k]);
+          const lhn_view& v = S.v[k];
+          f4 val;
+          if (bil && (v.H != dst.H || v.W != dst.W)) {
+            int h0, h1, w0, w1;
+            float ah, aw;
+            bil_taps(h, v.H, dst.H, h0, h1, ah);
+            bil_taps(w, v.W, dst.W, w0, w1, aw);
+            const float* b0 = v.data + ((size_t)(n * v.H + h0) * v.W) * v.cstride + ca[k];
+            const float* b1 = v.data + ((size_t)(n * v.H + h1) * v.W) * v.cstride + ca[k];
+            const f4 v00 = lhn_apply_xf(*reinterpret_cast<const f4*>(b0 + (size_t)w0 * v.cstride), xf[k]);
+            const f4 v01 = lhn_apply_xf(*reinterpret_cast<const f4*>(b0 + (size_t)w1 * v.cstride), xf[k]);
+            const f4 v10 = lhn_apply_xf(*reinterpret_cast<const f4*>(b1 + (size_t)w0 * v.cstride), xf[k]);
+            const f4 v11 = lhn_apply_xf(*reinterpret_cast<const f4*>(b1 + (size_t)w1 * v.cstride), xf[k]);
+            // torch's upsample_bilinear2d order: rows first, then columns
+            val = ((v00 * (1.f - aw) + v01 * aw) * (1.f - ah) + (v10 * (1.f - aw) + v11 * aw) * ah) * (gate[k] * S.coef[k]);
+          } else {
+            const int ws = nearest_src(w, v.W, dst.W);
+            val = lhn_apply_xf(*reinterpret_cast<const f4*>(base[k] + (size_t)ws * v.cstride), xf[k]) * (gate[k] * S.coef[k]);
+          }
+          if (mul) acc *= val; else acc += val;
         }
-      if (out_slope == LHN_SLOPE_SILU) {
+      if (out_slope == LHN_SLOPE_RELU_SIGMOID) {
+        acc.x = lhn_relu_sigmoid(acc.x);
+        acc.y = lhn_relu_sigmoid(acc.y);
+        acc.z = lhn_relu_sigmoid(acc.z);
+        acc.w = lhn_relu_sigmoid(acc.w);
+      } else if (out_slope == LHN_SLOPE_SILU) {
         acc.x = lhn_silu(acc.x);
         acc.y = lhn_silu(acc.y);
         acc.z = lhn_silu(acc.z);
@@ -146,7 +195,7 @@ __global__ void __launch_bounds__(256) k_ew_bwd_src(lhn_view src, lhn_view dst, 
   for (int row = blockIdx.x; row < rows; row += gridDim.x) {
     const int n = row / src.H, h = row - n * src.H;
     const f4 gate = dst.gate ? *reinterpret_cast<const f4*>(dst.gate + (size_t)n * dst.cstride + cd) : (f4){1.f, 1.f, 1.f, 1.f};
-    for (int w = pl; w < src.W; w += PL) {
+    for (int w = LHN_LANE0(pl, PL); w < src.W; w += PL) {
       f4 g = (f4){0.f, 0.f, 0.f, 0.f};
       for (int a = 0; a < fh; ++a)
         for (int b = 0; b < fw; ++b) {
@@ -157,14 +206,21 @@ __global__ void __launch_bounds__(256) k_ew_bwd_src(lhn_view src, lhn_view dst, 
             lhn_gradview gv{nullptr, dst_dpool, nullptr};
             e += lhn_dpool_sum(gv, dst, n, hd, wd, cd);
           }
-          if (out_slope == LHN_SLOPE_SILU) {
+          if (out_slope == LHN_SLOPE_SILU || out_slope == LHN_SLOPE_RELU_SIGMOID) {
             // single same-size source (host-checked): recompute the pre-activation from it
             const Xf4 sxf = lhn_load_xf(src, src.coff + 4 * c4);
             const f4 v = lhn_load_val(src, sxf, (int64_t)(n * src.H + h) * src.W + w, n, src.coff + 4 * c4);
-            e.x *= lhn_silu_grad(v.x);
-            e.y *= lhn_silu_grad(v.y);
-            e.z *= lhn_silu_grad(v.z);
-            e.w *= lhn_silu_grad(v.w);
+            if (out_slope == LHN_SLOPE_SILU) {
+              e.x *= lhn_silu_grad(v.x);
+              e.y *= lhn_silu_grad(v.y);
+              e.z *= lhn_silu_grad(v.z);
+              e.w *= lhn_silu_grad(v.w);
+            } else {
+              e.x *= lhn_relu_sigmoid_grad(v.x);
+              e.y *= lhn_relu_sigmoid_grad(v.y);
+              e.z *= lhn_relu_sigmoid_grad(v.z);
+              e.w *= lhn_relu_sigmoid_grad(v.w);
+            }
           } else if (out_slope != 1.f) {
             const f4 o = *reinterpret_cast<const f4*>(dst.data + pd);
             e.x *= o.x > 0.f ? 1.f : out_slope;
@@ -191,7 +247,7 @@ __global__ void __launch_bounds__(256) k_maxpool2_fwd(lhn_view x, lhn_view y, lh
   for (int row = blockIdx.x; row < rows; row += gridDim.x) {
     const int n = row / y.H, ho = row - n * y.H;
     const f4 gate = x.gate ? *reinterpret_cast<const f4*>(x.gate + (size_t)n * x.cstride + ca) : (f4){1.f, 1.f, 1.f, 1.f};
-    for (int wo = pl; wo < y.W; wo += PL) {
+    for (int wo = LHN_LANE0(pl, PL); wo < y.W; wo += PL) {
       f4 m = (f4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
       for (int o = 0; o < 4; ++o) {
@@ -220,7 +276,7 @@ __global__ void __launch_bounds__(256) k_maxpool2_bwd(lhn_view x, lhn_view y, co
   for (int row = blockIdx.x; row < rows; row += gridDim.x) {
     const int n = row / y.H, ho = row - n * y.H;
     const f4 gate = x.gate ? *reinterpret_cast<const f4*>(x.gate + (size_t)n * x.cstride + ca) : (f4){1.f, 1.f, 1.f, 1.f};
-    for (int wo = pl; wo < y.W; wo += PL) {
+    for (int wo = LHN_LANE0(pl, PL); wo < y.W; wo += PL) {
       const f4 g = *reinterpret_cast<const f4*>(dy + ((size_t)row * y.W + wo) * y.cstride + y.coff + 4 * c4);
       f4 m = (f4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
       int arg[4] = {-1, -1, -1, -1};
@@ -250,7 +306,8 @@ __global__ void __launch_bounds__(256) k_maxpool2_bwd(lhn_view x, lhn_view y, co
 }
 
 // ------------------------------------------------------------------ adaptive average pool -> dense [N,OH,OW,C]
-__global__ void __launch_bounds__(256) k_avgpool_fwd(lhn_view x, float* __restrict__ out, int OH, int OW, lhn_pends px) {
+__global__ void __launch_bounds__(256) k_avgpool_fwd(lhn_view x, float* __restrict__ out, int OH, int OW, lhn_pends px, int ostride,
+                                                     int ocoff) {
   __shared__ f4 red[256];
   __shared__ __attribute__((aligned(16))) float s_res[LHN_RESOLVE_FLOATS];
   const float* xtab = lhn_resolve_table(x, px, s_res);
@@ -267,7 +324,7 @@ __global__ void __launch_bounds__(256) k_avgpool_fwd(lhn_view x, float* __restri
   const float* base = x.data + (int64_t)n * x.H * x.W * x.cstride + ca;
   auto at = [&](int p) { return *reinterpret_cast<const f4*>(base + (int64_t)((h0 + p / bw) * x.W + w0 + p % bw) * x.cstride); };
   f4 s0 = (f4){0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
-  int p = pl;
+  int p = LHN_LANE0(pl, PL);
   for (; p + 3 * PL < cnt; p += 4 * PL) {
     const f4 a = at(p), b2 = at(p + PL), c2 = at(p + 2 * PL), d2 = at(p + 3 * PL);
     s0 += lhn_apply_xf(a, xf);
@@ -278,33 +335,36 @@ __global__ void __launch_bounds__(256) k_avgpool_fwd(lhn_view x, float* __restri
   for (; p < cnt; p += PL) s0 += lhn_apply_xf(at(p), xf);
   f4 s = (s0 + s1) + (s2 + s3);
   if (x.gate) s *= *reinterpret_cast<const f4*>(x.gate + (int64_t)n * x.cstride + ca);
-  // lanes of a wave that share c4 meet by xor-shuffles, the four waves through LDS
-  for (int o = C4; o < 64; o <<= 1) {
-    s.x += __shfl_xor(s.x, o, 64); s.y += __shfl_xor(s.y, o, 64); s.z += __shfl_xor(s.z, o, 64); s.w += __shfl_xor(s.w, o, 64);
-  }
+  // power-of-two C4 <= 64: lanes of a wave that share c4 meet by xor-shuffles, the four waves through LDS; any other C4
+  // (C4 = 5, 10, 20, 40, 80 ...): one LDS slot per thread
+  const bool shuf = C4 <= 64 && (C4 & (C4 - 1)) == 0;
+  if (shuf)
+    for (int o = C4; o < 64; o <<= 1) {
+      s.x += __shfl_xor(s.x, o, 64); s.y += __shfl_xor(s.y, o, 64); s.z += __shfl_xor(s.z, o, 64); s.w += __shfl_xor(s.w, o, 64);
+    }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (C4 <= 64 && lane < C4) red[wave * C4 + lane] = s;
-  if (C4 > 64) red[threadIdx.x] = s;
+  if (shuf && lane < C4) red[wave * C4 + lane] = s;
+  if (!shuf) red[threadIdx.x] = s;
   __syncthreads();
   if (threadIdx.x < C4) {
     f4 t = (f4){0.f, 0.f, 0.f, 0.f};
-    if (C4 <= 64) {
+    if (shuf) {
       for (int j = 0; j < 4; ++j) t += red[j * C4 + threadIdx.x];
     } else {
       for (int j = 0; j < PL; ++j) t += red[j * C4 + threadIdx.x];
     }
     const float inv = 1.f / (float)cnt;
-    *reinterpret_cast<f4*>(out + (int64_t)b * x.C + 4 * threadIdx.x) = t * inv;
+    *reinterpret_cast<f4*>(out + (int64_t)b * ostride + ocoff + 4 * threadIdx.x) = t * inv;
   }
 }
 // d(value of x) (+)= sum over bins containing the pixel of dout[bin]/|bin|
 __global__ void __launch_bounds__(256) k_avgpool_bwd(lhn_view x, const float* __restrict__ dout, int OH, int OW,
-                                                     float* __restrict__ dx, int accumulate) {
+                                                     float* __restrict__ dx, int accumulate, int ostride, int ocoff) {
   const int C4 = x.C >> 2, c4 = threadIdx.x % C4, pl = threadIdx.x / C4, PL = 256 / C4;
   const int rows = x.N * x.H;
   for (int row = blockIdx.x; row < rows; row += gridDim.x) {
     const int n = row / x.H, h = row - n * x.H;
-    for (int w = pl; w < x.W; w += PL) {
+    for (int w = LHN_LANE0(pl, PL); w < x.W; w += PL) {
       f4 g = (f4){0.f, 0.f, 0.f, 0.f};
       // bin oh contains h iff floor(oh*H/OH) <= h < ceil((oh+1)*H/OH): candidates are floor(h*OH/H) and its neighbours
       const int ohc = (h * OH) / x.H, owc = (w * OW) / x.W;
@@ -315,7 +375,7 @@ __global__ void __launch_bounds__(256) k_avgpool_bwd(lhn_view x, const float* __
           const int w0 = (ow * x.W) / OW, w1 = ((ow + 1) * x.W + OW - 1) / OW;
           if (w < w0 || w >= w1) continue;
           const float inv = 1.f / (float)((h1 - h0) * (w1 - w0));
-          g += *reinterpret_cast<const f4*>(dout + ((size_t)(n * OH + oh) * OW + ow) * x.C + 4 * c4) * inv;
+          g += *reinterpret_cast<const f4*>(dout + ((size_t)(n * OH + oh) * OW + ow) * ostride + ocoff + 4 * c4) * inv;
         }
       }
       float* o = dx + ((size_t)row * x.W + w) * x.cstride + x.coff + 4 * c4;
@@ -453,7 +513,7 @@ __global__ void __launch_bounds__(256) k_gate_bwd_reduce(lhn_view y, const float
   const int chunk = (HW + gridDim.y - 1) / gridDim.y;
   const int p0 = blockIdx.y * chunk, p1 = min(HW, p0 + chunk);
   f4 s = (f4){0.f, 0.f, 0.f, 0.f};
-  for (int p = p0 + pl; p < p1; p += PL) {
+  for (int p = p0 + LHN_LANE0(pl, PL); p < p1; p += PL) {
     const int64_t pix = (int64_t)n * HW + p;
     const f4 raw = *reinterpret_cast<const f4*>(y.data + pix * y.cstride + ca);
     const f4 v = lhn_apply_xf(raw, xf);
@@ -618,7 +678,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_reduce(lhn_view y, lhn_gradview 
     const int n = row / y.H, h = row - n * y.H;
     const f4 gate = y.gate ? *reinterpret_cast<const f4*>(y.gate + (size_t)n * y.cstride + ca) : (f4){1.f, 1.f, 1.f, 1.f};
     const size_t rbase = (size_t)row * y.W * y.cstride + ca;
-    for (int w = pl; w < y.W; w += PL) {
+    for (int w = LHN_LANE0(pl, PL); w < y.W; w += PL) {
       const size_t off = rbase + (size_t)w * y.cstride;
       const f4 raw = *reinterpret_cast<const f4*>(y.data + off);
       f4 e = *reinterpret_cast<const f4*>(g.dz + off) * gate;
@@ -630,7 +690,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_reduce(lhn_view y, lhn_gradview 
     }
   }
   double* st = sums + (size_t)(blockIdx.x % LHN_STAT_REPLICAS) * 2 * y.C;
-  if (C4 <= 32) {
+  if (C4 <= 32 && (C4 & (C4 - 1)) == 0) {
     lhn_block_stat_atomics(s, q, C4, red, st, st + y.C);
   } else {
     red[threadIdx.x * 2] = s;
@@ -655,14 +715,14 @@ __global__ void __launch_bounds__(256) k_bn_bwd_reduce(lhn_view y, lhn_gradview 
 // dy = A*du + B*y + C with  A = s, B = -s*invstd*dgamma/n, C = -s*dbeta/n + s*invstd*mean*dgamma/n, s = gamma*invstd
 __global__ void k_bn_bwd_finalize(const double* __restrict__ sums, const float* __restrict__ gamma,
                                   const float* __restrict__ save, float* __restrict__ coef, int cs, int coff, int C,
-                                  double count, float* __restrict__ dgamma, float* __restrict__ dbeta, float pgrad_scale) {
+                                  double count, float* __restrict__ dgamma, float* __restrict__ dbeta, float pgrad_scale, int SC) {
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     double db = 0, dg = 0;
     for (int r = 0; r < LHN_STAT_REPLICAS; ++r) {
-      db += sums[(size_t)r * 2 * C + c];
-      dg += sums[(size_t)r * 2 * C + C + c];
+      db += sums[(size_t)r * 2 * SC + c];
+      dg += sums[(size_t)r * 2 * SC + SC + c];
     }
-    const double mean = save[c], inv = save[C + c], s = (double)(gamma ? gamma[c] : 1.f) * inv;
+    const double mean = save[c], inv = save[SC + c], s = (double)(gamma ? gamma[c] : 1.f) * inv;
     coef[coff + c] = (float)s;
     coef[cs + coff + c] = (float)(-s * inv * dg / count);
     coef[2 * cs + coff + c] = (float)(-s * db / count + s * inv * mean * dg / count);
@@ -694,12 +754,18 @@ int lhn_reduce_replicas(float* out, const float* part, int64_t n, int nrep, int6
 int lhn_bn_finalize(const double* stats, const float* gamma, const float* beta, float* running_mean, float* running_var,
                     int64_t* nbt, float* table, int cstride, int coff, int C, float* save, double count, float eps,
                     float momentum, float slope, int training, const float* conv_bias, void* stream) {
-  LHN_CHECK_ARG(table && C > 0 && coff >= 0 && coff + C <= cstride, "lhn_bn_finalize: bad table slice");
+  return lhn_bn_finalize2(stats, gamma, beta, running_mean, running_var, nbt, table, cstride, coff, C, C, save, count, eps, momentum,
+                          slope, training, conv_bias, stream);
+}
+int lhn_bn_finalize2(const double* stats, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                     int64_t* nbt, float* table, int cstride, int coff, int C, int stat_channels, float* save, double count,
+                     float eps, float momentum, float slope, int training, const float* conv_bias, void* stream) {
+  LHN_CHECK_ARG(table && C > 0 && coff >= 0 && coff + C <= cstride && stat_channels >= C, "lhn_bn_finalize: bad table slice");
   LHN_CHECK_ARG(training ? (stats != nullptr) : (running_mean && running_var), "lhn_bn_finalize: missing statistics");
   LHN_CHECK_ARG(!training || count >= 1, "lhn_bn_finalize: count");
   hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(C <= 64 ? 64 : (C <= 128 ? 128 : 256)), 0, (hipStream_t)stream, stats,
                      gamma, beta, running_mean, running_var, nbt, table, cstride, coff, C, save, count, eps, momentum,
-                     slope, training, conv_bias);
+                     slope, training, conv_bias, stat_channels);
   LHN_CHECK_LAUNCH("lhn_bn_finalize");
   return 0;
 }
@@ -722,16 +788,20 @@ int lhn_ew_fwd(const lhn_view* srcs, int nsrc, const lhn_view* dst, float out_sl
   return lhn_ew_fwd2(srcs, nsrc, nullptr, dst, out_slope, stream);
 }
 int lhn_ew_fwd2(const lhn_view* srcs, int nsrc, const float* coef, const lhn_view* dst, float out_slope, void* stream) {
-  LHN_CHECK_ARG(srcs && nsrc >= 1 && nsrc <= 3 && lhn_view_ok(dst), "lhn_ew_fwd: 1..3 sources, valid dst");
+  return lhn_ew_fwd3(srcs, nsrc, coef, dst, out_slope, 0, stream);
+}
+int lhn_ew_fwd3(const lhn_view* srcs, int nsrc, const float* coef, const lhn_view* dst, float out_slope, int mode, void* stream) {
+  LHN_CHECK_ARG(srcs && nsrc >= 1 && nsrc <= 3 && lhn_view_ok(dst) && mode >= 0 && mode <= 3, "lhn_ew_fwd: 1..3 sources, valid dst");
   EwSrcs S;
   memset(&S, 0, sizeof(S));
+  S.mode = mode;
   for (int i = 0; i < nsrc; ++i) {
     LHN_CHECK_ARG(lhn_view_ok(&srcs[i]) && srcs[i].C == dst->C && srcs[i].N == dst->N && lhn_pend_ok(&srcs[i]), "lhn_ew_fwd: source %d mismatch", i);
     S.v[i] = srcs[i];
     S.coef[i] = coef ? coef[i] : 1.f;
     S.pend[i] = lhn_pends_of(&srcs[i]);
   }
-  LHN_CHECK_ARG(pow2i(dst->C / 4) && dst->C <= 1024, "lhn_ew_fwd: C=%d", dst->C);
+  LHN_CHECK_ARG(dst->C % 4 == 0 && dst->C <= 1024, "lhn_ew_fwd: C=%d", dst->C);
   hipLaunchKernelGGL(k_ew_fwd, dim3(grid_cap((int64_t)dst->N * dst->H, 8)), dim3(256), 0, (hipStream_t)stream, S, nsrc, *dst, out_slope);
   LHN_CHECK_LAUNCH("lhn_ew_fwd");
   return 0;
@@ -746,7 +816,7 @@ int lhn_ew_bwd(const lhn_view* srcs, int nsrc, const lhn_view* dst, const float*
     const lhn_view* s = &srcs[i];
     LHN_CHECK_ARG(lhn_view_ok(s) && s->C == dst->C, "lhn_ew_bwd: source %d mismatch", i);
     LHN_CHECK_ARG(dst->H % s->H == 0 && dst->W % s->W == 0, "lhn_ew_bwd: non-integer upsample %dx%d -> %dx%d", s->H, s->W, dst->H, dst->W);
-    LHN_CHECK_ARG(pow2i(s->C / 4) && s->C <= 1024, "lhn_ew_bwd: C=%d", s->C);
+    LHN_CHECK_ARG(s->C % 4 == 0 && s->C <= 1024, "lhn_ew_bwd: C=%d", s->C);
     hipLaunchKernelGGL(k_ew_bwd_src, dim3(grid_cap((int64_t)s->N * s->H, 8)), dim3(256), 0, (hipStream_t)stream, *s, *dst, ddst,
                        (const float*)nullptr, out_slope, dsrcs[i], accumulate[i]);
   }
@@ -758,8 +828,8 @@ int lhn_ew_bwd2(const lhn_view* src, const lhn_view* dst, const float* ddst, con
                 float* dsrc, int accumulate, void* stream) {
   LHN_CHECK_ARG(lhn_view_ok(src) && lhn_view_ok(dst) && ddst && dsrc && src->C == dst->C && lhn_no_pend(src) && lhn_no_pend(dst), "lhn_ew_bwd2: bad args");
   LHN_CHECK_ARG(dst->H % src->H == 0 && dst->W % src->W == 0, "lhn_ew_bwd2: non-integer upsample");
-  LHN_CHECK_ARG(out_slope != LHN_SLOPE_SILU || (dst->H == src->H && dst->W == src->W), "lhn_ew_bwd2: SiLU needs a single same-size source");
-  LHN_CHECK_ARG(pow2i(src->C / 4) && src->C <= 1024, "lhn_ew_bwd2: C=%d", src->C);
+  LHN_CHECK_ARG((out_slope != LHN_SLOPE_SILU && out_slope != LHN_SLOPE_RELU_SIGMOID) || (dst->H == src->H && dst->W == src->W), "lhn_ew_bwd2: SiLU / ReLU-sigmoid need a single same-size source");
+  LHN_CHECK_ARG(src->C % 4 == 0 && src->C <= 1024, "lhn_ew_bwd2: C=%d", src->C);
   hipLaunchKernelGGL(k_ew_bwd_src, dim3(grid_cap((int64_t)src->N * src->H, 8)), dim3(256), 0, (hipStream_t)stream, *src, *dst, ddst,
                      dst_dpool, out_slope, dsrc, accumulate);
   LHN_CHECK_LAUNCH("lhn_ew_bwd2");
@@ -769,7 +839,7 @@ int lhn_ew_bwd2(const lhn_view* src, const lhn_view* dst, const float* ddst, con
 int lhn_maxpool2_fwd(const lhn_view* x, const lhn_view* y, void* stream) {
   LHN_CHECK_ARG(lhn_view_ok(x) && lhn_view_ok(y) && x->C == y->C, "lhn_maxpool2_fwd: bad views");
   LHN_CHECK_ARG(y->H == (x->H + 1) / 2 && y->W == (x->W + 1) / 2 && y->N == x->N, "lhn_maxpool2_fwd: geometry");
-  LHN_CHECK_ARG(pow2i(y->C / 4) && y->C <= 1024, "lhn_maxpool2_fwd: C=%d", y->C);
+  LHN_CHECK_ARG(y->C % 4 == 0 && y->C <= 1024, "lhn_maxpool2_fwd: C=%d", y->C);
   LHN_CHECK_ARG(lhn_pend_ok(x), "lhn_maxpool2_fwd: bad pending BatchNorm");
   hipLaunchKernelGGL(k_maxpool2_fwd, dim3(grid_cap((int64_t)y->N * y->H, 8)), dim3(256), 0, (hipStream_t)stream, *x, *y, lhn_pends_of(x));
   LHN_CHECK_LAUNCH("lhn_maxpool2_fwd");
@@ -777,24 +847,33 @@ int lhn_maxpool2_fwd(const lhn_view* x, const lhn_view* y, void* stream) {
 }
 int lhn_maxpool2_bwd(const lhn_view* x, const lhn_view* y, const float* dy, float* dx, int dx_accumulate, void* stream) {
   LHN_CHECK_ARG(lhn_view_ok(x) && lhn_view_ok(y) && dy && dx && x->C == y->C && lhn_no_pend(x), "lhn_maxpool2_bwd: bad args");
-  LHN_CHECK_ARG(pow2i(y->C / 4) && y->C <= 1024, "lhn_maxpool2_bwd: C=%d", y->C);
+  LHN_CHECK_ARG(y->C % 4 == 0 && y->C <= 1024, "lhn_maxpool2_bwd: C=%d", y->C);
   hipLaunchKernelGGL(k_maxpool2_bwd, dim3(grid_cap((int64_t)y->N * y->H, 8)), dim3(256), 0, (hipStream_t)stream, *x, *y, dy, dx, dx_accumulate);
   LHN_CHECK_LAUNCH("lhn_maxpool2_bwd");
   return 0;
 }
 
 int lhn_avgpool_fwd(const lhn_view* x, float* out, int OH, int OW, void* stream) {
-  LHN_CHECK_ARG(lhn_view_ok(x) && out && OH > 0 && OW > 0, "lhn_avgpool_fwd: bad args");
-  LHN_CHECK_ARG(pow2i(x->C / 4) && x->C <= 1024, "lhn_avgpool_fwd: C=%d", x->C);
+  return lhn_avgpool_fwd2(x, out, OH, OW, x ? x->C : 0, 0, stream);
+}
+int lhn_avgpool_fwd2(const lhn_view* x, float* out, int OH, int OW, int out_cstride, int out_coff, void* stream) {
+  LHN_CHECK_ARG(lhn_view_ok(x) && out && OH > 0 && OW > 0 && out_coff >= 0 && out_coff % 4 == 0 && out_cstride % 4 == 0 &&
+                    out_coff + x->C <= out_cstride,
+                "lhn_avgpool_fwd: bad args");
+  LHN_CHECK_ARG(x->C % 4 == 0 && x->C <= 1024, "lhn_avgpool_fwd: C=%d", x->C);
   LHN_CHECK_ARG(lhn_pend_ok(x), "lhn_avgpool_fwd: bad pending BatchNorm");
-  hipLaunchKernelGGL(k_avgpool_fwd, dim3(x->N * OH * OW), dim3(256), 0, (hipStream_t)stream, *x, out, OH, OW, lhn_pends_of(x));
+  hipLaunchKernelGGL(k_avgpool_fwd, dim3(x->N * OH * OW), dim3(256), 0, (hipStream_t)stream, *x, out, OH, OW, lhn_pends_of(x), out_cstride, out_coff);
   LHN_CHECK_LAUNCH("lhn_avgpool_fwd");
   return 0;
 }
 int lhn_avgpool_bwd(const lhn_view* x, const float* dout, int OH, int OW, float* dx, int dx_accumulate, void* stream) {
-  LHN_CHECK_ARG(lhn_view_ok(x) && dout && dx, "lhn_avgpool_bwd: bad args");
-  LHN_CHECK_ARG(pow2i(x->C / 4) && x->C <= 1024, "lhn_avgpool_bwd: C=%d", x->C);
-  hipLaunchKernelGGL(k_avgpool_bwd, dim3(grid_cap((int64_t)x->N * x->H, 8)), dim3(256), 0, (hipStream_t)stream, *x, dout, OH, OW, dx, dx_accumulate);
+  return lhn_avgpool_bwd2(x, dout, OH, OW, x ? x->C : 0, 0, dx, dx_accumulate, stream);
+}
+int lhn_avgpool_bwd2(const lhn_view* x, const float* dout, int OH, int OW, int out_cstride, int out_coff, float* dx,
+                     int dx_accumulate, void* stream) {
+  LHN_CHECK_ARG(lhn_view_ok(x) && dout && dx && out_coff >= 0 && out_coff + x->C <= out_cstride, "lhn_avgpool_bwd: bad args");
+  LHN_CHECK_ARG(x->C % 4 == 0 && x->C <= 1024, "lhn_avgpool_bwd: C=%d", x->C);
+  hipLaunchKernelGGL(k_avgpool_bwd, dim3(grid_cap((int64_t)x->N * x->H, 8)), dim3(256), 0, (hipStream_t)stream, *x, dout, OH, OW, dx, dx_accumulate, out_cstride, out_coff);
   LHN_CHECK_LAUNCH("lhn_avgpool_bwd");
   return 0;
 }
@@ -815,7 +894,7 @@ int lhn_ca_mlp_fwd(const float* pooled, const float* w3, const float* gamma, con
 }
 
 int lhn_gate_bwd_reduce(const lhn_view* y, const float* dz, float* dgate, void* stream) {
-  LHN_CHECK_ARG(lhn_view_ok(y) && dz && dgate && pow2i(y->C / 4) && lhn_no_pend(y), "lhn_gate_bwd_reduce: bad args");
+  LHN_CHECK_ARG(lhn_view_ok(y) && dz && dgate && y->C % 4 == 0 && y->C <= 1024 && lhn_no_pend(y), "lhn_gate_bwd_reduce: bad args");
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(dgate, 0, (size_t)y->N * y->C * 4, s) != hipSuccess) {
     lhn_set_error("lhn_gate_bwd_reduce: memset failed");
@@ -851,15 +930,19 @@ int lhn_bn_bwd_reduce(const lhn_view* y, const lhn_gradview* g, const float* sav
                       void* stream) {
   lhn_bnbwdfin fin;
   if (finp) fin = *finp; else fin.counter = nullptr;
-  LHN_CHECK_ARG(lhn_view_ok(y) && g && g->dz && save && sums && pow2i(y->C / 4) && y->C <= 1024 && lhn_no_pend(y), "lhn_bn_bwd_reduce: bad args");
+  LHN_CHECK_ARG(lhn_view_ok(y) && g && g->dz && save && sums && y->C % 4 == 0 && y->C <= 1024 && lhn_no_pend(y), "lhn_bn_bwd_reduce: bad args");
   hipLaunchKernelGGL(k_bn_bwd_reduce, dim3(grid_cap((int64_t)y->N * y->H, 8)), dim3(256), 0, (hipStream_t)stream, *y, *g, save, sums, fin);
   LHN_CHECK_LAUNCH("lhn_bn_bwd_reduce");
   return 0;
 }
 int lhn_bn_bwd_finalize(const double* sums, const float* gamma, const float* save, float* coef, int cstride, int coff, int C,
                         double count, float* dgamma, float* dbeta, float pgrad_scale, void* stream) {
-  LHN_CHECK_ARG(sums && save && coef && C > 0 && coff + C <= cstride, "lhn_bn_bwd_finalize: bad args");
-  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(1), dim3(C <= 64 ? 64 : (C <= 128 ? 128 : 256)), 0, (hipStream_t)stream, sums, gamma, save, coef, cstride, coff, C, count, dgamma, dbeta, pgrad_scale);
+  return lhn_bn_bwd_finalize2(sums, gamma, save, coef, cstride, coff, C, C, count, dgamma, dbeta, pgrad_scale, stream);
+}
+int lhn_bn_bwd_finalize2(const double* sums, const float* gamma, const float* save, float* coef, int cstride, int coff, int C,
+                         int stat_channels, double count, float* dgamma, float* dbeta, float pgrad_scale, void* stream) {
+  LHN_CHECK_ARG(sums && save && coef && C > 0 && coff + C <= cstride && stat_channels >= C, "lhn_bn_bwd_finalize: bad args");
+  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(1), dim3(C <= 64 ? 64 : (C <= 128 ? 128 : 256)), 0, (hipStream_t)stream, sums, gamma, save, coef, cstride, coff, C, count, dgamma, dbeta, pgrad_scale, stat_channels);
   LHN_CHECK_LAUNCH("lhn_bn_bwd_finalize");
   return 0;
 }

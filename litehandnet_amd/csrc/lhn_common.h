@@ -8,6 +8,11 @@
 #include "../../include/lhn.h"
 
 #define LHN_WAVE 64
+// Elementwise kernels map thread -> (channel group c4 = tid % C4, pixel lane pl = tid / C4) with PL = 256 / C4 live lanes.
+// C4 = C / 4 need not divide 256 (lite_hrnet.py: C = 20, 40, 80, 160, 320): the left-over threads (pl == PL) start their
+// loops at LHN_DEAD, i.e. beyond any extent, and contribute zeros to reductions.
+#define LHN_DEAD (1 << 30)
+#define LHN_LANE0(pl, PL) ((pl) < (PL) ? (pl) : LHN_DEAD)
 
 void lhn_set_error(const char* fmt, ...);
 

@@ -12,9 +12,10 @@ extern "C" int lhn_ew_bwd2(const lhn_view* src, const lhn_view* dst, const float
 
 enum {
   OP_STEM = 1, OP_PW = 2, OP_DW = 3, OP_KXK = 4, OP_FINALIZE = 5, OP_EW = 6, OP_MAXPOOL = 7, OP_AVGPOOL = 8,
-  OP_CA_MLP = 9, OP_TABLE_FILL = 10, OP_MEMSET = 11, OP_ATT_MLP = 12, OP_SE_MLP = 13,
+  OP_CA_MLP = 9, OP_TABLE_FILL = 10, OP_MEMSET = 11, OP_ATT_MLP = 12, OP_SE_MLP = 13, OP_SHUFFLE = 14,
   OP_STEM_BWD = 101, OP_PW_BWD = 102, OP_DW_BWD = 103, OP_KXK_BWD = 104, OP_BN_BWD = 105, OP_EW_BWD = 106,
   OP_MAXPOOL_BWD = 107, OP_AVGPOOL_BWD = 108, OP_GATE_REDUCE = 109, OP_CA_MLP_BWD = 110, OP_ATT_MLP_BWD = 111, OP_SE_MLP_BWD = 112,
+  OP_SHUFFLE_BWD = 113,
 };
 
 // One captured launch sequence (hipGraph) of a phase for one set of pointers.
@@ -92,10 +93,16 @@ static bool fuse_finalize() {
   }
   return v == 1;
 }
-static int sep_finalize(const lhn_bnfin& f, const double* stats, int training, void* stream) {
-  return lhn_bn_finalize(training ? stats : nullptr, f.gamma, f.beta, f.running_mean, f.running_var,
-                         training ? f.num_batches_tracked : nullptr, f.table, f.cstride, f.coff, f.C,
-                         training ? f.save_mean_invstd : nullptr, f.count, f.eps, f.momentum, f.slope, training, f.conv_bias, stream);
+// creal: channels the BatchNorm really has when the convolution's output view is padded to a multiple of 4 (f.C then is the
+// layout of the statistics); repeat: the reference evaluates some units twice per forward (lite_hrnet.py:192-197), which
+// moves their running statistics twice -- the table is the same both times.
+static int sep_finalize(const lhn_bnfin& f, const double* stats, int training, void* stream, int creal = 0, int repeat = 1) {
+  int rc = 0;
+  for (int r = 0; r < (training ? (repeat < 1 ? 1 : repeat) : 1) && !rc; ++r)
+    rc = lhn_bn_finalize2(training ? stats : nullptr, f.gamma, f.beta, f.running_mean, f.running_var,
+                          training ? f.num_batches_tracked : nullptr, f.table, f.cstride, f.coff, creal > 0 ? creal : f.C, f.C,
+                          training ? f.save_mean_invstd : nullptr, f.count, f.eps, f.momentum, f.slope, training, f.conv_bias, stream);
+  return rc;
 }
 
 // Deferred BatchNorm finalize (see lhn_pend): in a plain training run a convolution flagged i[7] leaves its statistics to
@@ -260,7 +267,8 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
         if (h0) rc = lhn_conv_pw_fwd2(&x, prm<const float>(params, o.p[0]), bn ? nullptr : prm<const float>(params, o.p[1]), &y,
                               (training && o.ws[0] >= 0) ? reinterpret_cast<double*>(at(ws, o.ws[0])) : nullptr, o.i[0], nchw,
                               (bn && training && fuse_finalize() && whole) ? &fin : nullptr, &po, stream);
-        if (!rc && bn && h1 && !skip_tables && !deferred && !(training && fuse_finalize() && whole)) rc = sep_finalize(fin, reinterpret_cast<const double*>(at(ws, o.ws[0])), training, stream);
+        if (!rc && bn && h1 && !skip_tables && !deferred && !(training && fuse_finalize() && whole))
+          rc = sep_finalize(fin, reinterpret_cast<const double*>(at(ws, o.ws[0])), training, stream, o.i[2], (int)o.f[3]);
         break;
       }
       case OP_DW: {
@@ -282,7 +290,8 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
         if (h0) rc = lhn_conv_dw_fwd2(&x, prm<const float>(params, o.p[0]), &y,
                               (training && o.ws[0] >= 0) ? reinterpret_cast<double*>(at(ws, o.ws[0])) : nullptr, o.i[0], o.i[1], o.i[2], o.i[3],
                               (bn && training && fuse_finalize() && whole) ? &fin : nullptr, o.i[6] > 1 ? &extra : nullptr, coef2, stream);
-        if (!rc && bn && h1 && !skip_tables && !deferred && !(training && fuse_finalize() && whole)) rc = sep_finalize(fin, reinterpret_cast<const double*>(at(ws, o.ws[0])), training, stream);
+        if (!rc && bn && h1 && !skip_tables && !deferred && !(training && fuse_finalize() && whole))
+          rc = sep_finalize(fin, reinterpret_cast<const double*>(at(ws, o.ws[0])), training, stream, 0, (int)o.f[3]);
         break;
       }
       case OP_KXK: {
@@ -321,7 +330,7 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
         }
         lhn_view d = mkview(P, ws, o.out_buf, o.out_coff, o.out_C);
         const float coef[3] = {o.f[4], o.f[5], o.f[6]};
-        rc = lhn_ew_fwd2(srcs, o.i[0], o.i[1] ? coef : nullptr, &d, o.f[0], stream);      // i[1]: coefficients given
+        rc = lhn_ew_fwd3(srcs, o.i[0], o.i[1] ? coef : nullptr, &d, o.f[0], o.i[2], stream);      // i[1]: coefficients given; i[2]: mode
         break;
       }
       case OP_MAXPOOL: {
@@ -331,10 +340,17 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
         rc = lhn_maxpool2_fwd(&x, &y, stream);
         break;
       }
+      case OP_SHUFFLE: {
+        lhn_view a = mkview(P, ws, o.in_buf[0], o.in_coff[0], o.in_C[0]);
+        lhn_view b = mkview(P, ws, o.in_buf[1], o.in_coff[1], o.in_C[1]);
+        lhn_view d = mkview(P, ws, o.out_buf, o.out_coff, o.out_C);
+        rc = lhn_shuffle2_fwd(&a, &b, &d, stream);
+        break;
+      }
       case OP_AVGPOOL: {
         lhn_view x = mkview(P, ws, o.in_buf[0], o.in_coff[0], o.in_C[0], o.i[2] == 0);
         if (has_pend && pd[0].n) x.pend = &pd[0];
-        rc = lhn_avgpool_fwd(&x, reinterpret_cast<float*>(at(ws, o.ws[0])), o.i[0], o.i[1], stream);
+        rc = lhn_avgpool_fwd2(&x, reinterpret_cast<float*>(at(ws, o.ws[0])), o.i[0], o.i[1], o.i[3] > 0 ? o.i[3] : x.C, o.i[4], stream);
         break;
       }
       case OP_CA_MLP: {
@@ -367,10 +383,10 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
       }
       case OP_SE_MLP: {  // p: w1, b1, w2, b2; ws: pooled, save; i[0] = J
         const lhn_buf& b = P->bufs[o.out_buf];
-        rc = lhn_se_mlp_fwd(reinterpret_cast<const float*>(at(ws, o.ws[0])), prm<const float>(params, o.p[0]),
-                            prm<const float>(params, o.p[1]), prm<const float>(params, o.p[2]), prm<const float>(params, o.p[3]),
-                            reinterpret_cast<float*>(at(ws, b.gate_off)), b.C, o.out_coff, reinterpret_cast<float*>(at(ws, o.ws[1])),
-                            b.N, o.out_C, o.i[0], stream);
+        rc = lhn_se_mlp_fwd2(reinterpret_cast<const float*>(at(ws, o.ws[0])), prm<const float>(params, o.p[0]),
+                             prm<const float>(params, o.p[1]), prm<const float>(params, o.p[2]), prm<const float>(params, o.p[3]),
+                             reinterpret_cast<float*>(at(ws, b.gate_off)), b.C, o.out_coff, reinterpret_cast<float*>(at(ws, o.ws[1])),
+                             b.N, o.out_C, o.i[0], o.i[1], stream);
         break;
       }
       // ------------------------------------------------------------------ backward
@@ -446,8 +462,8 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
         } else {
           if (h0) rc = lhn_bn_bwd_reduce(&y, &g, save, sums, nullptr, stream);
           if (!rc && h1)
-            rc = lhn_bn_bwd_finalize(sums, fin.gamma, save, fin.coef, b.C, o.out_coff, o.out_C, fin.count, fin.dgamma, fin.dbeta,
-                                     pscale, stream);
+            rc = lhn_bn_bwd_finalize2(sums, fin.gamma, save, fin.coef, b.C, o.out_coff, o.i[0] > 0 ? o.i[0] : o.out_C, o.out_C, fin.count,
+                                      fin.dgamma, fin.dbeta, pscale, stream);      // i[0]: real channels of a padded output
         }
         break;
       }
@@ -455,9 +471,18 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
         lhn_view src = mkview(P, ws, o.in_buf[0], o.in_coff[0], o.in_C[0]);
         lhn_view d = mkview(P, ws, o.out_buf, o.out_coff, o.out_C);
         const lhn_buf& db = P->bufs[o.out_buf];
-        rc = lhn_ew_bwd2(&src, &d, reinterpret_cast<const float*>(at(ws, db.grad_off)),
-                         reinterpret_cast<const float*>(at(ws, db.dpool_off)), o.f[0],
-                         reinterpret_cast<float*>(at(ws, P->bufs[o.in_buf[0]].grad_off)), o.i[0], stream);
+        if (o.i[1] == 1) {            // product: in_buf[1] = the other operand
+          lhn_view other = mkview(P, ws, o.in_buf[1], o.in_coff[1], o.in_C[1]);
+          rc = lhn_ew_mul_bwd(&src, &other, &d, reinterpret_cast<const float*>(at(ws, db.grad_off)),
+                              reinterpret_cast<float*>(at(ws, P->bufs[o.in_buf[0]].grad_off)), o.i[0], stream);
+        } else if (o.i[1] == 2) {     // bilinearly resampled source
+          rc = lhn_bilinear_bwd(&src, &d, reinterpret_cast<const float*>(at(ws, db.grad_off)),
+                                reinterpret_cast<float*>(at(ws, P->bufs[o.in_buf[0]].grad_off)), o.i[0], o.f[0], stream);
+        } else {
+          rc = lhn_ew_bwd2(&src, &d, reinterpret_cast<const float*>(at(ws, db.grad_off)),
+                           reinterpret_cast<const float*>(at(ws, db.dpool_off)), o.f[0],
+                           reinterpret_cast<float*>(at(ws, P->bufs[o.in_buf[0]].grad_off)), o.i[0], stream);
+        }
         break;
       }
       case OP_MAXPOOL_BWD: {
@@ -469,8 +494,17 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
       }
       case OP_AVGPOOL_BWD: {
         lhn_view x = mkview(P, ws, o.in_buf[0], o.in_coff[0], o.in_C[0]);
-        rc = lhn_avgpool_bwd(&x, reinterpret_cast<const float*>(at(ws, o.ws[0])), o.i[0], o.i[1],
-                             reinterpret_cast<float*>(at(ws, P->bufs[o.in_buf[0]].grad_off)), o.i[2], stream);
+        rc = lhn_avgpool_bwd2(&x, reinterpret_cast<const float*>(at(ws, o.ws[0])), o.i[0], o.i[1], o.i[3] > 0 ? o.i[3] : x.C, o.i[4],
+                              reinterpret_cast<float*>(at(ws, P->bufs[o.in_buf[0]].grad_off)), o.i[2], stream);
+        break;
+      }
+      case OP_SHUFFLE_BWD: {     // i[0], i[1]: 0 = no gradient wanted, 1 = store, 2 = accumulate (operand a, b)
+        lhn_view a = mkview(P, ws, o.in_buf[0], o.in_coff[0], o.in_C[0]);
+        lhn_view b = mkview(P, ws, o.in_buf[1], o.in_coff[1], o.in_C[1]);
+        lhn_view d = mkview(P, ws, o.out_buf, o.out_coff, o.out_C);
+        rc = lhn_shuffle2_bwd(&a, &b, &d, reinterpret_cast<const float*>(at(ws, P->bufs[o.out_buf].grad_off)),
+                              o.i[0] ? reinterpret_cast<float*>(at(ws, P->bufs[o.in_buf[0]].grad_off)) : nullptr, o.i[0] == 2,
+                              o.i[1] ? reinterpret_cast<float*>(at(ws, P->bufs[o.in_buf[1]].grad_off)) : nullptr, o.i[1] == 2, stream);
         break;
       }
       case OP_GATE_REDUCE: {
@@ -509,11 +543,11 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
       }
       case OP_SE_MLP_BWD: {  // p: w1, w2 (params) | dw1, db1, dw2, db2 (grads); ws: pooled, save, -, dgate; i[0] = J
         const lhn_buf& b = P->bufs[o.out_buf];
-        rc = lhn_se_mlp_bwd(reinterpret_cast<const float*>(at(ws, o.ws[0])), prm<const float>(params, o.p[0]),
-                            prm<const float>(params, o.p[1]), reinterpret_cast<const float*>(at(ws, o.ws[1])),
-                            reinterpret_cast<const float*>(at(ws, o.ws[3])), reinterpret_cast<float*>(at(ws, b.dpool_off)), b.C,
-                            o.out_coff, b.H, b.W, prm<float>(grads, o.p[2]), prm<float>(grads, o.p[3]), prm<float>(grads, o.p[4]),
-                            prm<float>(grads, o.p[5]), b.N, o.out_C, o.i[0], stream);
+        rc = lhn_se_mlp_bwd2(reinterpret_cast<const float*>(at(ws, o.ws[0])), prm<const float>(params, o.p[0]),
+                             prm<const float>(params, o.p[1]), reinterpret_cast<const float*>(at(ws, o.ws[1])),
+                             reinterpret_cast<const float*>(at(ws, o.ws[3])), reinterpret_cast<float*>(at(ws, b.dpool_off)), b.C,
+                             o.out_coff, b.H, b.W, prm<float>(grads, o.p[2]), prm<float>(grads, o.p[3]), prm<float>(grads, o.p[4]),
+                             prm<float>(grads, o.p[5]), b.N, o.out_C, o.i[0], o.i[1], stream);
         break;
       }
       default:

@@ -1,6 +1,6 @@
 """Model registry -- models/__init__.py:11-26 restricted to the hot path."""
 
-__all__ = ["litehandnet", "litehourglass", "mynet", "hourglass"]
+__all__ = ["litehandnet", "litehourglass", "mynet", "hourglass", "litehrnet"]
 
 
 def get_model(cfg):
@@ -15,5 +15,8 @@ def get_model(cfg):
     if name == "hourglass":
         from .hourglassnet import HourglassNet
         return HourglassNet(cfg)
+    if name == "litehrnet":
+        from .lite_hrnet import LiteHRNet
+        return LiteHRNet(cfg)
     from .liteHandNet import LiteHandNet
     return LiteHandNet(cfg)

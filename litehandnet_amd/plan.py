@@ -24,9 +24,11 @@ from . import _lib
 from ._lib import Buf, Op
 
 # op kinds (must match csrc/lhn_plan.cpp)
-STEM, PW, DW, KXK, FINALIZE, EW, MAXPOOL, AVGPOOL, CA_MLP, TABLE_FILL, MEMSET, ATT_MLP, SE_MLP = range(1, 14)
-STEM_BWD, PW_BWD, DW_BWD, KXK_BWD, BN_BWD, EW_BWD, MAXPOOL_BWD, AVGPOOL_BWD, GATE_REDUCE, CA_MLP_BWD, ATT_MLP_BWD, SE_MLP_BWD = range(101, 113)
+STEM, PW, DW, KXK, FINALIZE, EW, MAXPOOL, AVGPOOL, CA_MLP, TABLE_FILL, MEMSET, ATT_MLP, SE_MLP, SHUFFLE = range(1, 15)
+STEM_BWD, PW_BWD, DW_BWD, KXK_BWD, BN_BWD, EW_BWD, MAXPOOL_BWD, AVGPOOL_BWD, GATE_REDUCE, CA_MLP_BWD, ATT_MLP_BWD, SE_MLP_BWD, SHUFFLE_BWD = range(101, 114)
 SLOPE_SILU = 2.0       # LHN_SLOPE_SILU in include/lhn.h: the combine applies SiLU instead of a leaky ReLU
+SLOPE_RELU_SIGMOID = 3.0   # LHN_SLOPE_RELU_SIGMOID: sigmoid(relu(v)) (lite_hrnet.py: nn.ReLU followed by nn.Sigmoid)
+EW_MUL, EW_BILINEAR = 1, 2   # EwSrcs.mode bits: product of the sources / bilinear (align_corners) resampling of smaller ones
 
 ALIGN = 256
 STAT_REPLICAS = 32     # LHN_STAT_REPLICAS in include/lhn.h
@@ -182,7 +184,7 @@ class PlanBuilder:
         return -1 if t is None else self.state_index[id(t)]
 
     # ------------------------------------------------------------------ forward emitters
-    def conv(self, x, conv, bn=None, slope=1.0, out=None, nchw_out=False, stack=None):
+    def conv(self, x, conv, bn=None, slope=1.0, out=None, nchw_out=False, stack=None, bn_repeat=1):
         """conv (+ train/eval BatchNorm + leaky slope as a pending transform).  Returns the output view.
         1x1 convolutions take any channel counts: views are padded to multiples of 4 (a 21-feature head is a 24-channel
         NHWC buffer whose last channels are exact zeros) and the library slices wide ones.  `stack = (i, S)`: the NCHW output
@@ -207,8 +209,7 @@ class PlanBuilder:
         if kind == PW:
             assert cin_g <= x.C < cin_g + 4, (cin_g, x.C)
             if not nchw_out:
-                cpad = (cout + 3) // 4 * 4
-                assert cpad == cout or bn is None, "a padded output has no BatchNorm"
+                cpad = (cout + 3) // 4 * 4          # (a BatchNorm behind a padded output owns the first `cout` columns)
         elif kind == KXK:
             assert cin_g == x.C, (cin_g, x.C)
         xs = self.lazy_sources(x)
@@ -231,15 +232,16 @@ class PlanBuilder:
             self.real(out)
         rec = dict(op=kind, x=x, out=out, conv=conv, bn=bn, slope=float(slope), k=kh, stride=s, pad=p, dil=d,
                    nchw=nchw_out, stack=(0, 1) if stack is None else (int(stack[0]), int(stack[1])),
-                   wrc=(cout if cpad != cout else 0, cin_g if cin_g != x.C else 0), xs=xs)
+                   wrc=(cout if cpad != cout else 0, cin_g if cin_g != x.C else 0), xs=xs, bn_repeat=int(bn_repeat))
         if kind == KXK:
             rec["wt"] = self._ws("misc", 9 * cout * cin_g * 4)      # tap-major weight scratch (lhn_conv_kxk_*: wt_scratch)
         if bn is not None:
-            rec["stats"] = self._ws("zf", STAT_REPLICAS * 2 * cout * 8)
+            sc = max(cout, cpad)        # statistics are laid out for the (padded) output view
+            rec["stats"] = self._ws("zf", STAT_REPLICAS * 2 * sc * 8)
             rec["cnt"] = self._ws("zf", 4)
-            rec["save"] = self._ws("misc", 2 * cout * 4)
+            rec["save"] = self._ws("misc", 2 * sc * 4)
             if self.with_backward:
-                rec["sums"] = self._ws("zb", STAT_REPLICAS * 2 * cout * 8)
+                rec["sums"] = self._ws("zb", STAT_REPLICAS * 2 * sc * 8)
                 rec["bcnt"] = self._ws("zb", 4)
                 self.bufs[out.buf].coef = True
         self.recs.append(rec)
@@ -292,10 +294,22 @@ class PlanBuilder:
                 self.bufs[p.buf].lazy = None
         return x
 
-    def ew(self, srcs, out_slope=1.0, out=None, lazy=False):
-        """out = lrelu_{out_slope}(sum of sources); smaller sources are nearest-upsampled.  Plain output.
-        lazy=True (plain same-size sum into a fresh buffer): see lazy_sources()."""
+    def ew(self, srcs, out_slope=1.0, out=None, lazy=False, mode=0, coefs=None):
+        """out = act(sum of sources); smaller sources are nearest-upsampled.  Plain output.
+        lazy=True (plain same-size sum into a fresh buffer): see lazy_sources().
+        mode EW_MUL: product instead of sum (exactly two single-buffer sources); EW_BILINEAR: smaller sources are resampled
+        bilinearly with align_corners=True.  coefs: one factor per source."""
         assert 1 <= len(srcs) <= 3
+        if mode or coefs is not None:
+            srcs = [self.real(self.single(t)) for t in srcs]
+            assert not (mode & EW_MUL) or len(srcs) == 2
+            H, W = max(t.H for t in srcs), max(t.W for t in srcs)
+            if out is None:
+                out = self.new(H, W, srcs[0].C)
+            assert not isinstance(out, TCat) and all(t.C == out.C for t in srcs)
+            self.recs.append(dict(op=EW, srcs=list(srcs), out=self.real(out), slope=float(out_slope), mode=int(mode),
+                                  coefs=None if coefs is None else [float(c) for c in coefs]))
+            return out
         if lazy and out is None and out_slope == 1.0 and not any(isinstance(t, TCat) for t in srcs) and \
                 all((t.H, t.W, t.C) == (srcs[0].H, srcs[0].W, srcs[0].C) and t.buf >= 0 for t in srcs):
             flat = []
@@ -343,13 +357,25 @@ class PlanBuilder:
         self.recs.append(dict(op=MAXPOOL, x=x, out=out))
         return out
 
-    def avgpool(self, x, OH, OW):
-        """adaptive_avg_pool2d of the consumed value -> a plain [N,OH,OW,C] buffer (one per part of a multi-part x)."""
+    def avgpool(self, x, OH, OW, out=None):
+        """adaptive_avg_pool2d of the consumed value -> a plain [N,OH,OW,C] buffer (one per part of a multi-part x), or into the
+        channel slice `out` of an existing one (the pooled branches of CrossResolutionWeighting land side by side)."""
         x = self.real(x)
         if isinstance(x, TCat):
+            assert out is None
             return TCat([self.avgpool(p, OH, OW) for p in x.parts])
-        out = self.new(OH, OW, x.C)
+        if out is None:
+            out = self.new(OH, OW, x.C)
+        assert (out.H, out.W, out.C) == (OH, OW, x.C)
         self.recs.append(dict(op=AVGPOOL, x=x, out=out, OH=OH, OW=OW, ca=False))
+        return out
+
+    def shuffle2(self, a, b):
+        """channel_shuffle(torch.cat([a, b], 1), 2) (lite_hrnet.py:29-52): a new plain buffer with a / b interleaved."""
+        a, b = self.real(self.single(a)), self.real(self.single(b))
+        assert (a.H, a.W, a.C) == (b.H, b.W, b.C) and a.C % 2 == 0 and a.coff % 2 == 0 and b.coff % 2 == 0
+        out = self.new(a.H, a.W, 2 * a.C)
+        self.recs.append(dict(op=SHUFFLE, a=a, b=b, out=out))
         return out
 
     def channel_attention(self, y, ca):
@@ -387,14 +413,17 @@ class PlanBuilder:
         b.gate = True
         return y
 
-    def se_attention(self, y, se):
-        """SEBlock (common.py:23-37) on the WHOLE buffer behind `y` (square maps: avg_pool2d(kernel=W) is global)."""
+    def se_attention(self, y, se, convs=None, mode=0):
+        """SEBlock (common.py:23-37) on the WHOLE buffer behind `y` (square maps: avg_pool2d(kernel=W) is global).
+        convs = (down, up) Conv2d modules when they are not `se.down` / `se.up`; mode 1 = SpatialWeighting of
+        lite_hrnet.py:55-74 (global average pool, sigmoid(relu(.)) after both convolutions)."""
         b = self.bufs[y.buf]
         assert y.coff == 0 and y.C == b.C and not b.gate, "attention gates a whole, ungated buffer"
-        if y.H != y.W:
+        if y.H != y.W and mode == 0:
             raise _lib.LhnError("SEBlock pools with kernel_size = width: only square maps are built")
-        Cc, J = y.C, se.down.weight.shape[0]
-        rec = dict(op=SE_MLP, y=y, se=se, J=J, pooled=self._ws("misc", self.N * Cc * 4),
+        down, up = convs if convs is not None else (se.down, se.up)
+        Cc, J = y.C, down.weight.shape[0]
+        rec = dict(op=SE_MLP, y=y, se=se, down=down, up=up, mode=int(mode), J=J, pooled=self._ws("misc", self.N * Cc * 4),
                    save=self._ws("misc", self.N * (J + Cc) * 4))
         if self.with_backward:
             rec["dgate"] = self._ws("misc", self.N * Cc * 4)
@@ -477,7 +506,8 @@ class PlanBuilder:
         training run), the reader lists the producer in pend[slot].  Anything else keeps the separate launch."""
         self.deferred = 0
         for i, o in enumerate(fwd):
-            if o.kind not in (STEM, PW, DW, KXK) or o.p[2] < 0 or o.out_buf < 0 or o.ws[0] < 0 or o.out_C > 128:
+            if o.kind not in (STEM, PW, DW, KXK) or o.p[2] < 0 or o.out_buf < 0 or o.ws[0] < 0 or o.out_C > 128 or \
+                    (o.kind == PW and o.i[2] > 0) or o.f[3] > 1:
                 continue
             lo, hi = o.out_coff, o.out_coff + o.out_C
             if self.bufs[o.out_buf].C > 256:
@@ -490,6 +520,8 @@ class PlanBuilder:
                     slots = [k for k in slots if k == 0]
                 elif r.kind == EW:
                     slots = [k for k in slots if k < r.i[0]]
+                elif r.kind == SHUFFLE:
+                    slots = [k for k in slots if k < 2]          # a reader whose kernel cannot finalize: no deferral
                 elif r.kind not in (PW, DW, KXK):
                     slots = []
                 if not slots:
@@ -553,7 +585,7 @@ class PlanBuilder:
                     pbn = (self._p(bn.weight), self._p(bn.bias), self._p(bn.running_mean), self._p(bn.running_var),
                            self._p(bn.num_batches_tracked))
                     wsl = (stats, self._abs(r["save"]), self._abs(r["cnt"]))
-                    fl = (bn.eps, bn.momentum, r["slope"])
+                    fl = (bn.eps, bn.momentum, r["slope"], float(r.get("bn_repeat", 1)))
                 else:
                     pbn, wsl, fl = (-1, -1, -1, -1, -1), (stats,), ()
                 cb = self._p(getattr(conv, "bias", None)) if bn is not None else -1   # biased conv + BN: bias goes to the finalize
@@ -580,12 +612,19 @@ class PlanBuilder:
                     # flattened operand list -- an operand that is itself a lazy sum has never been written
                     fl = r["flat"]
                     fwd.append(mk(EW, ins=[t for t, _ in fl], out=r["out"], i=(len(fl), 1), f=(r["slope"], 0.0, 0.0, 0.0) + tuple(c for _, c in fl)))
+                elif r.get("mode") or r.get("coefs") is not None:
+                    cf = r["coefs"] or [1.0] * len(r["srcs"])
+                    fwd.append(mk(EW, ins=r["srcs"], out=r["out"], i=(len(r["srcs"]), 1, r.get("mode", 0)),
+                                  f=(r["slope"], 0.0, 0.0, 0.0) + tuple(cf)))
                 else:
                     fwd.append(mk(EW, ins=r["srcs"], out=r["out"], i=(len(r["srcs"]),), f=(r["slope"],)))
+            elif k == SHUFFLE:
+                fwd.append(mk(SHUFFLE, ins=(r["a"], r["b"]), out=r["out"]))
             elif k == MAXPOOL:
                 fwd.append(mk(MAXPOOL, ins=(r["x"],), out=r["out"]))
             elif k == AVGPOOL:
-                fwd.append(mk(AVGPOOL, ins=(r["x"],), ws=(self.bufs[r["out"].buf].off["data"],), i=(r["OH"], r["OW"], 0)))
+                ob = self.bufs[r["out"].buf]
+                fwd.append(mk(AVGPOOL, ins=(r["x"],), ws=(ob.off["data"],), i=(r["OH"], r["OW"], 0, ob.C, r["out"].coff)))
             elif k == TABLE_FILL:
                 fwd.append(mk(TABLE_FILL, out=r["out"], p=(self._p(r["bias"]),), i=(1,), f=(1.0, 0.0, r["slope"])))
             elif k == CA_MLP and hasattr(r["ca"], "rbr_reparam"):
@@ -600,11 +639,10 @@ class PlanBuilder:
                               ws=(self._abs(r["pooled"]), self._abs(r["save"]), self._abs(r["mask"])),
                               f=(1e-5, 0.1)))
             elif k == SE_MLP:
-                y, se = r["y"], r["se"]
+                y, dn, up = r["y"], r["down"], r["up"]
                 fwd.append(mk(AVGPOOL, ins=(y,), ws=(self._abs(r["pooled"]),), i=(1, 1, 1)))
-                fwd.append(mk(SE_MLP, out=y, p=(self._p(se.down.weight), self._p(se.down.bias), self._p(se.up.weight),
-                                               self._p(se.up.bias)),
-                              ws=(self._abs(r["pooled"]), self._abs(r["save"])), i=(r["J"],)))
+                fwd.append(mk(SE_MLP, out=y, p=(self._p(dn.weight), self._p(dn.bias), self._p(up.weight), self._p(up.bias)),
+                              ws=(self._abs(r["pooled"]), self._abs(r["save"])), i=(r["J"], r["mode"])))
             elif k == ATT_MLP:
                 y, att = r["y"], r["att"]
                 bn, dw, lin = att[1], att[3], att[6]
@@ -644,11 +682,12 @@ class PlanBuilder:
             # copy launch disappears (MSRB: the gated branch buffer of every residual add).
             uses = {}
             for r in self.recs:
-                for t in ([r["x"]] if r["op"] in (PW, DW, KXK, MAXPOOL, AVGPOOL) else r["srcs"] if r["op"] == EW else []):
+                for t in ([r["x"]] if r["op"] in (PW, DW, KXK, MAXPOOL, AVGPOOL) else r["srcs"] if r["op"] == EW else
+                          [r["a"], r["b"]] if r["op"] == SHUFFLE else []):
                     uses.setdefault(t.buf, []).append(r)
             aliased = set()
             for r in reversed(self.recs):
-                if r["op"] != EW or r["slope"] != 1.0:
+                if r["op"] != EW or r["slope"] != 1.0 or r.get("mode") or r.get("coefs") is not None:
                     continue
                 out = r["out"]
                 ob = self.bufs[out.buf]
@@ -681,7 +720,8 @@ class PlanBuilder:
                                        f=(1.0, 0.0, 0.0, 0.0) + tuple(c for _, c in fl)))
                     if bn is not None:
                         body.append(mk(BN_BWD, out=out, p=(self._p(bn.weight), self._p(bn.weight), self._p(bn.bias)),
-                                       ws=(self._abs(r["sums"]), self._abs(r["save"]), self._abs(r["bcnt"]))))
+                                       ws=(self._abs(r["sums"]), self._abs(r["save"]), self._abs(r["bcnt"])),
+                                       i=(r["wrc"][0] if k == PW else 0,)))
                     if k == STEM:
                         body.append(mk(STEM_BWD, out=out, p=(pw, pw), i=(r["k"], r["stride"], r["pad"], x.H, x.W, use_coef)))
                         continue
@@ -702,26 +742,46 @@ class PlanBuilder:
                     else:
                         body.append(mk(KXK_BWD, ins=(x,), out=out, p=(pw, pw), ws=(-1, -1, -1, self._abs(r["wt"])),
                                        i=(r["stride"], 0, mode, 0, 0, use_coef)))
+                elif k == EW and (r.get("mode") or r.get("coefs") is not None):
+                    md, srcs = r.get("mode", 0), r["srcs"]
+                    if r.get("coefs") is not None and any(c != 1.0 for c in r["coefs"]):
+                        raise _lib.LhnError("a combine with coefficients is forward-only")
+                    for j, s in enumerate(srcs):
+                        if s.buf == self._no_grad_buf:
+                            continue
+                        gm = self._grad_mode(written, s)
+                        acc = 1 if gm == 2 else 0
+                        if md & EW_MUL:
+                            body.append(mk(EW_BWD, ins=(s, srcs[1 - j]), out=r["out"], i=(acc, 1), f=(r["slope"],)))
+                        elif (md & EW_BILINEAR) and (s.H, s.W) != (r["out"].H, r["out"].W):
+                            body.append(mk(EW_BWD, ins=(s,), out=r["out"], i=(acc, 2), f=(r["slope"],)))
+                        else:
+                            body.append(mk(EW_BWD, ins=(s,), out=r["out"], i=(acc,), f=(r["slope"],)))
                 elif k == EW:
                     for s in r["srcs"]:
                         if s.buf == self._no_grad_buf or (s.buf in aliased and self.bufs[s.buf].off["grad"] == self.bufs[r["out"].buf].off["grad"]):
                             continue
                         mode = self._grad_mode(written, s)
                         body.append(mk(EW_BWD, ins=(s,), out=r["out"], i=(1 if mode == 2 else 0,), f=(r["slope"],)))
+                elif k == SHUFFLE:
+                    ma = 0 if r["a"].buf == self._no_grad_buf else self._grad_mode(written, r["a"])
+                    mb = 0 if r["b"].buf == self._no_grad_buf else self._grad_mode(written, r["b"])
+                    body.append(mk(SHUFFLE_BWD, ins=(r["a"], r["b"]), out=r["out"], i=(ma, mb)))
                 elif k == MAXPOOL:
                     mode = self._grad_mode(written, r["x"])
                     body.append(mk(MAXPOOL_BWD, ins=(r["x"],), out=r["out"], i=(1 if mode == 2 else 0,)))
                 elif k == AVGPOOL:
                     mode = self._grad_mode(written, r["x"])
-                    body.append(mk(AVGPOOL_BWD, ins=(r["x"],), ws=(self.bufs[r["out"].buf].off["grad"],),
-                                   i=(r["OH"], r["OW"], 1 if mode == 2 else 0)))
+                    ob = self.bufs[r["out"].buf]
+                    body.append(mk(AVGPOOL_BWD, ins=(r["x"],), ws=(ob.off["grad"],),
+                                   i=(r["OH"], r["OW"], 1 if mode == 2 else 0, ob.C, r["out"].coff)))
                 elif k == SE_MLP:
-                    y, se = r["y"], r["se"]
+                    y, dn, up = r["y"], r["down"], r["up"]
                     body.append(mk(GATE_REDUCE, out=y, ws=(-1, -1, -1, self._abs(r["dgate"]))))
                     body.append(mk(SE_MLP_BWD, out=y,
-                                   p=(self._p(se.down.weight), self._p(se.up.weight), self._p(se.down.weight),
-                                      self._p(se.down.bias), self._p(se.up.weight), self._p(se.up.bias)),
-                                   ws=(self._abs(r["pooled"]), self._abs(r["save"]), -1, self._abs(r["dgate"])), i=(r["J"],)))
+                                   p=(self._p(dn.weight), self._p(up.weight), self._p(dn.weight),
+                                      self._p(dn.bias), self._p(up.weight), self._p(up.bias)),
+                                   ws=(self._abs(r["pooled"]), self._abs(r["save"]), -1, self._abs(r["dgate"])), i=(r["J"], r["mode"])))
                 elif k == ATT_MLP:
                     y, att = r["y"], r["att"]
                     bn, dw, lin = att[1], att[3], att[6]
@@ -758,6 +818,10 @@ class PlanBuilder:
                         o.i[4] = 2
                     elif o.kind in (EW_BWD, MAXPOOL_BWD) and o.in_buf[0] in self._needs_zero_grad:
                         o.i[0] = 1
+                    elif o.kind == SHUFFLE_BWD:
+                        for q in range(2):
+                            if o.in_buf[q] in self._needs_zero_grad and o.i[q]:
+                                o.i[q] = 2
                     elif o.kind == AVGPOOL_BWD and o.in_buf[0] in self._needs_zero_grad:
                         o.i[2] = 1
             bwd += body
@@ -822,6 +886,11 @@ class CompiledPlan:
             t[0].fill_(1.0)
             t[1].zero_()
             t[2].fill_(1.0)
+            if "coef" in b.off:     # dy = A du + B y + C: identity until a BatchNorm backward writes its slice (padded
+                c = self.view_f32(b.off["coef"], 3 * b.C).view(3, b.C)      # channels of a 7 / 17 / 37-wide one never are)
+                c[0].fill_(1.0)
+                c[1].zero_()
+                c[2].zero_()
         self.state_tensors = state_tensors
         self._params = (C.c_void_p * len(state_tensors))()
         self._grads = (C.c_void_p * len(state_tensors))()

@@ -6,10 +6,11 @@
   model_H{1,2}_*.npz   hourglass (models/pose_estimation/hourglassnet.py), num_stack 1 and 2: forward [N,S,K,H,W], loss,
                        gradient norms -- same recipe as make_golden.py::_model_case
 
+  model_L18_*.npz      Lite-HRNet depth 18 (models/pose_estimation/lite_hrnet.py): forward, loss, gradient norms, running statistics
   random_flip.npz      TopDownRandomFlip (datasets/data_pipeline/RandomFlip.py:28-100) of the REAL reference
   candidates.npz       HeatmapParser.candidate_bbox arithmetic on torch.topk (class un-importable: restated)
 
-    python tests/golden/make_golden_r2.py [decoder|hourglass|flip|topk|all]
+    python tests/golden/make_golden_r2.py [decoder|hourglass|litehrnet|flip|topk|all]
 """
 import os
 import sys
@@ -145,6 +146,9 @@ def main():
     if what in ("hourglass", "all"):
         from make_golden_r2_models import hourglass_fixtures
         hourglass_fixtures(ref_models, RefLoss)
+    if what in ("litehrnet", "all"):
+        from make_golden_r2_models import litehrnet_fixtures
+        litehrnet_fixtures(ref_models, RefLoss)
 
 
 if __name__ == "__main__":

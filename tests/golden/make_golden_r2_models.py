@@ -35,3 +35,16 @@ def hourglass_fixtures(ref_models, RefLoss):
                "ora_loss": _stacked(torch_ref.distance_loss, lw)}
         _model_case(r, o, n, size, seed, f"H{ns}_{size}", out)
         print(f"hourglass num_stack={ns}: {npar} parameters")
+
+
+def litehrnet_fixtures(ref_models, RefLoss):
+    """Lite-HRNet (models/pose_estimation/lite_hrnet.py), depth 18: the REAL reference vs the oracle restatement (forward,
+    TopdownHeatmapLoss, gradient norms, running statistics -- including the fuse layers the reference evaluates twice per
+    forward), known answer 1,483,873 parameters (test_models_performance.ipynb:276-279)."""
+    cfg = litehandnet_cfg("L", depth=18)
+    out = {"ref_loss": RefLoss(cfg), "ora_loss": torch_ref.TopdownHeatmapLoss(cfg)}
+    for n, size, seed in ((4, 128, 41), (2, 256, 42)):
+        r, o = ref_models.get_model(cfg), torch_ref.get_model(cfg)
+        assert type(r).__name__ == "LiteHRNet" and list(r.state_dict()) == list(o.state_dict())
+        assert sum(p.numel() for p in r.parameters()) == 1483873
+        _model_case(r, o, n, size, seed, f"L18_{size}", out)

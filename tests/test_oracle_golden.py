@@ -328,3 +328,15 @@ def test_flip_and_candidates_fixtures(golden_dir):
             assert np.array_equal(g["images"][i], g["out_images"][i]) and np.array_equal(g["joints"][i], g["out_joints"][i])
     c = np.load(os.path.join(golden_dir, "candidates.npz"))
     assert np.array_equal(onp.candidate_bbox(c["centre"], c["sizes"], int(c["k"]), float(c["image_size"])), c["candidates"])
+
+
+def test_litehrnet_fixture(golden_dir):
+    """oracle.torch_ref.LiteHRNet against the REAL reference's vectors (make_golden_r2_models.py): forward bit-for-bit,
+    known parameter count 1,483,873 (test_models_performance.ipynb:276-279)."""
+    g = np.load(os.path.join(golden_dir, "model_L18_128.npz"))
+    m = torch_ref.get_model(litehandnet_cfg("L", depth=18))
+    assert sum(p.numel() for p in m.parameters()) == 1483873
+    m.load_state_dict(synth.synth_state_dict(m, int(g["seed"])))
+    m.train()
+    y = m(synth.synth_images(int(g["n"]), int(g["size"]), int(g["seed"])))
+    assert np.abs(y.detach().numpy() - g["heatmap"]).max() <= 1e-5 * np.abs(g["heatmap"]).max()
