@@ -566,6 +566,25 @@ class PlanBuilder:
         ranges.append((lo, hi))
         return 2
 
+    def _covered(self, written, t):
+        """The backward op of t's producer is about to READ d(t): channels nobody wrote (an output only partly consumed) must
+        read as zero -> the gradient buffer is zero-filled at the start of the backward and every write accumulates."""
+        if t is None or isinstance(t, TCat) or t.buf < 0:
+            return
+        buf = t.buf
+        while buf in self._alias_of:            # an aliased gradient buffer is written through the combine it aliases
+            buf = self._alias_of[buf]
+        if buf != t.buf:
+            return
+        cur, hi = t.coff, t.coff + t.C
+        for a, b in sorted(written.get(t.buf, [])):
+            if a > cur:
+                break
+            cur = max(cur, b)
+        if cur < hi:
+            self._needs_zero_grad.add(t.buf)
+            written.setdefault(t.buf, []).append((t.coff, hi))
+
     def finalize(self):
         self._layout()
         N = self.N
@@ -686,6 +705,7 @@ class PlanBuilder:
                           [r["a"], r["b"]] if r["op"] == SHUFFLE else []):
                     uses.setdefault(t.buf, []).append(r)
             aliased = set()
+            self._alias_of = {}
             for r in reversed(self.recs):
                 if r["op"] != EW or r["slope"] != 1.0 or r.get("mode") or r.get("coefs") is not None:
                     continue
@@ -703,10 +723,13 @@ class PlanBuilder:
                         continue
                     tb.off["grad"] = ob.off["grad"]
                     aliased.add(t.buf)
+                    self._alias_of[t.buf] = out.buf
             self.grad_aliases = len(aliased)
             materialised = set()
             for r in reversed(self.recs):
                 k = r["op"]
+                if k in (STEM, PW, DW, KXK, EW, SHUFFLE, MAXPOOL, AVGPOOL) and not (k == PW and r.get("nchw")) and r["out"] is not self.out_ref:
+                    self._covered(written, r["out"])
                 if k in (STEM, PW, DW, KXK):
                     conv, bn, x, out = r["conv"], r["bn"], r["x"], r["out"]
                     pw = self._p(conv.weight)
