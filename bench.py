@@ -22,13 +22,14 @@ sys.path.insert(0, ROOT)
 
 # algorithmic HBM bytes per image, fp32: 4 B x sum over convs of (in + out) elements
 ALG_FWD_BYTES = {"B": 76.42e6, "A": 98.07e6, "M": 82.59e6,   # M = `mynet` (pose_hg_ms_att.py), scripts/dump_plan.py M
-                 "H": 220.14e6}                              # hourglass, 2 stacks, C = 256 (config/hourglass/_2_*_h2.py)
-ALG_FWD_FLOPS = {"B": 0.757e9, "A": 2.560e9, "M": 2.220e9, "H": 16.745e9}   # conv FLOPs per image, forward
+                 "H": 220.14e6,                              # hourglass, 2 stacks, C = 256 (config/hourglass/_2_*_h2.py)
+                 "L": 96.23e6}                               # Lite-HRNet-18 (config/litehrnet/_2_*_18.py)
+ALG_FWD_FLOPS = {"B": 0.757e9, "A": 2.560e9, "M": 2.220e9, "H": 16.745e9, "L": 0.634e9}   # conv FLOPs per image, forward
 LOSS_BYTES = (8 + 4) * 21 * 64 * 64          # loss fwd reads o,t; bwd writes g (per image)
 HBM_PEAK_GBS = 8000.0                        # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable copy rate)
 MFMA_FP32_PEAK_TF = 157.3                    # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
 VARIANT_NAME = {"B": "MSRB hourglass litehourglass.py", "A": "registered liteHandNet.py, reduction 4", "M": "mynet pose_hg_ms_att.py",
-                "H": "stacked hourglass hourglassnet.py, 2 stacks, C=256"}
+                "H": "stacked hourglass hourglassnet.py, 2 stacks, C=256", "L": "Lite-HRNet-18 lite_hrnet.py"}
 
 
 def source_sha16():
@@ -257,7 +258,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--variant", default="B", choices=["A", "B", "M", "H"])
+    ap.add_argument("--variant", default="B", choices=["A", "B", "M", "H", "L"])
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline variant only (skip variant A and the per-kernel rooflines)")
@@ -287,7 +288,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(step_ms, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"litehandnet variant {args.variant} ({VARIANT_NAME[args.variant]}) "
-                               f"C={256 if args.variant == 'H' else 128}, 256x256x3 -> 21x64x64, per-GPU batch {B}, train-mode BN, fwd + TopdownHeatmapLoss + bwd + fused Adam",
+                               f"C={ {'H': 256, 'L': '40..320'}.get(args.variant, 128) }, 256x256x3 -> 21x64x64, per-GPU batch {B}, train-mode BN, fwd + TopdownHeatmapLoss + bwd + fused Adam",
                    "global_batch": world * B, "parallelism": f"dp{world}", "ca_dropout": args.dropout},
         "roofline": forward_roofline(args.variant, B, fwd_ms, copy_gbs),
         "roofline_train_step": {"bound": "hbm", "achieved": round(train_alg / (step_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,

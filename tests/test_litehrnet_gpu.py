@@ -101,7 +101,10 @@ def test_iterative_head_bilinear(dev):
 
 def test_stem(dev):
     from litehandnet_amd import lite_hrnet as lh
-    _check_block(lh.StemModule(3, 32, 32, 1), torch_ref.LHStemModule(3, 32, 32, 1), _x(2, 3, 64, 64, seed=13), dev, seed=14, no_dx=True)
+
+    class Stem(lh.StemModule):
+        consumes_image = True          # the block reads the NCHW image itself (3-channel stem kernel), like the full model
+    _check_block(Stem(3, 32, 32, 1), torch_ref.LHStemModule(3, 32, 32, 1), _x(2, 3, 64, 64, seed=13), dev, seed=14, no_dx=True)
 
 
 def test_state_dict_contract_litehrnet(dev):
