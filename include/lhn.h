@@ -339,6 +339,13 @@ int lhn_conv_pw_bwd2(const lhn_view* x, const float* w, const lhn_view* y, const
 int lhn_conv_dw_bwd(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx,
                     int dx_accumulate, float* dw, int k, int stride, int pad, int dil, int nrep, int64_t rep_stride,
                     void* stream);
+/* ... and, when this convolution is the only reader of x and x is the output of a convolution + BatchNorm, the
+ * BatchNorm-backward sums of THAT producer (sum du, sum du * xhat into bn_sums[LHN_STAT_REPLICAS][2][bn_C] at channel
+ * bn_coff, mean / invstd from bn_save) -- the kernel has d(x), the raw x and its table in hand; lhn_bn_bwd_reduce of the
+ * producer is then skipped.  3x3, stride 1, dilation 1, dx stored (not accumulated), x ungated.  bn_sums NULL: lhn_conv_dw_bwd. */
+int lhn_conv_dw_bwd2(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx, int dx_accumulate,
+                     float* dw, int k, int stride, int pad, int dil, int nrep, int64_t rep_stride, double* bn_sums,
+                     const float* bn_save, int bn_C, int bn_coff, void* stream);
 int lhn_conv_stem_bwd(const float* img, const lhn_view* y, const lhn_gradview* gy, float* dw, int Hi, int Wi,
                       int k, int stride, int pad, int nrep, int64_t rep_stride, void* stream);
 /* NOTE: lhn_conv_kxk_bwd and the large-channel path of lhn_conv_pw_bwd CONSUME gy->dz (it is overwritten in place

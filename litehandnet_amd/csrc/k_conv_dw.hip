@@ -204,8 +204,9 @@ struct DwExtra {
 
 int lhn_dwk_fwd_lds(const lhn_view* x, const float* w, const lhn_view* y, double* stats, int k, int dil, lhn_bnfin fin,
                     hipStream_t s, const DwExtra* ex);
+struct DwBnSum;
 int lhn_dwk_bwd_lds(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx, int dx_acc,
-                    float* dw, int k, int dil, int nrep, int64_t rep_stride, hipStream_t s);
+                    float* dw, int k, int dil, int nrep, int64_t rep_stride, hipStream_t s, const DwBnSum* bs);
 static bool lhn_dw_force_gather() {
   static int v = -1;
   if (v < 0) {
@@ -476,6 +477,25 @@ __global__ void __launch_bounds__(256) k_stem_bwd(const float* __restrict__ img,
   }
 }
 
+static int dw_bwd_fused(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx, float* dw, int k,
+                        int dil, int nrep, int64_t rep_stride, double* bn_sums, const float* bn_save, int bn_C, int bn_coff, hipStream_t s);
+
+extern "C" int lhn_conv_dw_bwd2(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx,
+                                int dx_accumulate, float* dw, int k, int stride, int pad, int dil, int nrep, int64_t rep_stride,
+                                double* bn_sums, const float* bn_save, int bn_C, int bn_coff, void* stream) {
+  if (!bn_sums) return lhn_conv_dw_bwd(x, w, y, gy, dx, dx_accumulate, dw, k, stride, pad, dil, nrep, rep_stride, stream);
+  if (nrep < 1) nrep = 1;
+  LHN_CHECK_ARG(lhn_view_ok(x) && lhn_view_ok(y) && gy && gy->dz && w && dw && dx && bn_save && lhn_no_pend(x) && lhn_no_pend(y),
+                "lhn_conv_dw_bwd2: bad view / null pointer");
+  LHN_CHECK_ARG(!dx_accumulate && !x->gate && stride == 1 && pad == dil * (k - 1) / 2 && x->C % 32 == 0 && x->W >= 8 && x->C == y->C &&
+                    bn_coff >= 0 && bn_coff + x->C <= bn_C,
+                "lhn_conv_dw_bwd2: fused BatchNorm sums need this convolution to be the only, ungated, stride-1 reader of x (dx stored)");
+  const int rc = dw_bwd_fused(x, w, y, gy, dx, dw, k, dil, nrep, rep_stride, bn_sums, bn_save, bn_C, bn_coff, (hipStream_t)stream);
+  LHN_CHECK_ARG(rc == 1, "lhn_conv_dw_bwd2: fused BatchNorm sums are built for the 3x3 / dilation 1 kernel (k=%d dil=%d)", k, dil);
+  LHN_CHECK_LAUNCH("lhn_conv_dw_bwd2");
+  return 0;
+}
+
 extern "C" int lhn_conv_dw_bwd(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx,
                                int dx_accumulate, float* dw, int k, int stride, int pad, int dil, int nrep, int64_t rep_stride,
                                void* stream) {
@@ -485,7 +505,7 @@ extern "C" int lhn_conv_dw_bwd(const lhn_view* x, const float* w, const lhn_view
   LHN_CHECK_ARG(k == 1 || k == 3 || k == 7, "lhn_conv_dw_bwd: k=%d (1, 3 or 7)", k);
   hipStream_t s = (hipStream_t)stream;
   if (w && dw && stride == 1 && pad == dil * (k - 1) / 2 && x->C % 32 == 0 && x->W >= 8 && !lhn_dw_force_gather() &&
-      lhn_dwk_bwd_lds(x, w, y, gy, dx, dx_accumulate, dw, k, dil, nrep, rep_stride, s)) {
+      lhn_dwk_bwd_lds(x, w, y, gy, dx, dx_accumulate, dw, k, dil, nrep, rep_stride, s, nullptr)) {
     LHN_CHECK_LAUNCH("lhn_conv_dw_bwd");
     return 0;
   }
@@ -718,10 +738,21 @@ __global__ void __launch_bounds__(256) k_dwk_fwd_lds(lhn_view x, const float* __
 //   dx[h,w]   = sum_taps dy[h+P-a*DIL, w+P-b*DIL] * wgt[a][b]
 //   dW[a][b] += sum_{h,w in tile} dy[h,w] * x[h-P+a*DIL, w-P+b*DIL]
 // K = 3 keeps all 9 dW accumulators in registers; K = 7 keeps the per-tile partials in LDS (dws) instead.
-template <int K, int DIL>
+// BNS: the input x is the output of a convolution + BatchNorm whose ONLY reader is this depthwise convolution (RepBasicUnit:
+// 1x1 -> 3x3 depthwise, litehourglass.py:58-60).  The kernel then holds everything the producer's BatchNorm backward needs
+// -- d(value of x) (the dx it just computed), the raw x, its table -- and accumulates sum(du), sum(du * xhat) per channel
+// into the producer's replicated sums: the separate lhn_bn_bwd_reduce pass (re-reads x and dx: 134 MB, 20 us per unit at
+// 64x64) disappears.
+struct DwBnSum {
+  double* sums;          // [LHN_STAT_REPLICAS][2][C] of the producer's BatchNorm backward, or NULL
+  const float* save;     // [2][C] mean | invstd of the producer
+  int C, coff;           // producer channels; channel of the producer that x's first channel is
+};
+
+template <int K, int DIL, bool BNS = false>
 __global__ void __launch_bounds__(256) k_dwk_bwd_lds(lhn_view x, const float* __restrict__ w, lhn_view y, lhn_gradview gy,
                                                      float* __restrict__ dx, int dx_acc, float* __restrict__ dw, int tiles_h,
-                                                     int tiles_w, int cgroups, int nrep, int64_t rep_stride, int ps) {
+                                                     int tiles_w, int cgroups, int nrep, int64_t rep_stride, int ps, DwBnSum bs) {
   constexpr int TH = 8, TW = 16, KK = K * K;
   constexpr bool REGACC = (K == 3);
   using T = DwTile<K, DIL, TH, TW>;
@@ -731,6 +762,8 @@ __global__ void __launch_bounds__(256) k_dwk_bwd_lds(lhn_view x, const float* __
   f4* red = tx + T::PIX * 8;                    // [256]
   f4* wl = red + 256;                           // [KK][8]
   f4* dws = wl + KK * 8;                        // [KK][8]  (K = 7 only) block-level dW partials
+  f4* traw = dws + KK * 8;                      // [TH*TW][8] raw x of the tile interior (BNS only)
+  f4* tmi = traw + TH * TW * 8;                 // [2][8] mean | invstd of this block's channel group (BNS only)
   const int tid = threadIdx.x, c4 = tid & 7, pl = tid >> 3;
   const int colw = pl & 15, rpar = pl >> 4;
   const int ntile = y.N * ps * ps * tiles_h * tiles_w * cgroups;      // ps: see k_dwk_fwd_lds
@@ -746,6 +779,11 @@ __global__ void __launch_bounds__(256) k_dwk_bwd_lds(lhn_view x, const float* __
   f4 accw[REGACC ? KK : 1];
 #pragma unroll
   for (int k = 0; k < (REGACC ? KK : 1); ++k) accw[k] = (f4){0.f, 0.f, 0.f, 0.f};
+  f4 sdu = (f4){0.f, 0.f, 0.f, 0.f}, sdux = sdu;
+  if (BNS && tid < 16) {
+    const int kind = tid >> 3, cc = tid & 7;
+    tmi[tid] = *reinterpret_cast<const f4*>(bs.save + kind * bs.C + bs.coff + cg * 32 + 4 * cc);
+  }
   for (int t = blockIdx.x; t < ntile; t += gridDim.x) {
     int r = t / cgroups;
     const int tw = r % tiles_w;
@@ -790,6 +828,7 @@ __global__ void __launch_bounds__(256) k_dwk_bwd_lds(lhn_view x, const float* __
           const f4 z = (f4){0.f, 0.f, 0.f, 0.f};
           tx[i * 8 + c4] = inb ? vx : z;
           tdy[i * 8 + c4] = inb ? vy : z;
+          if (BNS && ph >= T::P && ph < T::P + TH && pw >= T::P && pw < T::P + TW) traw[((ph - T::P) * TW + pw - T::P) * 8 + c4] = rx[it];
         }
       }
     }
@@ -811,6 +850,13 @@ __global__ void __launch_bounds__(256) k_dwk_bwd_lds(lhn_view x, const float* __
               accx += tdy[centre - off] * wl[(a * K + b) * 8 + c4];
               accw[REGACC ? a * K + b : 0] += dyc * tx[centre + off];
             }
+          if (BNS) {          // accx is the complete d(value of x): this kernel is x's only reader (host-checked, dx_acc == 0)
+            const f4 raw = traw[(rr * TW + colw) * 8 + c4];
+            const f4 u = raw * xxf.sc + xxf.sh;
+            const f4 du = accx * (f4){u.x > 0.f ? 1.f : xxf.sl.x, u.y > 0.f ? 1.f : xxf.sl.y, u.z > 0.f ? 1.f : xxf.sl.z, u.w > 0.f ? 1.f : xxf.sl.w};
+            sdu += du;
+            sdux += du * ((raw - tmi[c4]) * tmi[8 + c4]);
+          }
           if (dx) {
             float* o = dx + ((size_t)(n * x.H + pa + ps * hh) * x.W + pb + ps * wcol) * x.cstride + cx;
             if (dx_acc) accx += *reinterpret_cast<const f4*>(o);
@@ -870,6 +916,10 @@ __global__ void __launch_bounds__(256) k_dwk_bwd_lds(lhn_view x, const float* __
         __syncthreads();
       }
     }
+  }
+  if (BNS) {           // BatchNorm-backward sums of the producer: same block reduction as the forward statistics
+    double* st = bs.sums + (size_t)((blockIdx.x / cgroups) % LHN_STAT_REPLICAS) * 2 * bs.C + bs.coff + cg * 32;
+    lhn_block_stat_atomics(sdu, sdux, 8, red, st, st + bs.C);
   }
   // ---- flush dW
   float* dwr = dw + (size_t)((blockIdx.x / cgroups) % nrep) * rep_stride;
@@ -935,18 +985,20 @@ static void launch_dwk_fwd(const lhn_view* x, const float* w, const lhn_view* y,
   (void)lhn_kernel_cfg(cfg, &k_dwk_fwd_lds<K, DIL, NS>, lds, 4, nullptr);
   hipLaunchKernelGGL((k_dwk_fwd_lds<K, DIL, NS>), dim3(dw3_grid(ntile, cg, per_cu * 2)), dim3(256), lds, s, *x, w, *y, stats, th, tw, cg, fin, ps, ex);
 }
-template <int K, int DIL>
+template <int K, int DIL, bool BNS = false>
 static void launch_dwk_bwd(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx, int dx_acc,
-                           float* dw, int nrep, int64_t rep_stride, hipStream_t s, int ps = 1) {
+                           float* dw, int nrep, int64_t rep_stride, hipStream_t s, int ps = 1, const DwBnSum* bsp = nullptr) {
   constexpr int TH = 8, TW = 16, P = DIL * (K - 1) / 2;
+  DwBnSum bs;
+  if (bsp) bs = *bsp; else { bs.sums = nullptr; bs.save = nullptr; bs.C = bs.coff = 0; }
   const int cg = x->C / 32;
   const int sh = (x->H + ps - 1) / ps, sw = (x->W + ps - 1) / ps;
   const int th = (sh + TH - 1) / TH, tw = (sw + TW - 1) / TW, ntile = x->N * ps * ps * th * tw * cg;
-  const size_t lds = (size_t)((TH + 2 * P) * (TW + 2 * P) * 16 + 256 + 2 * K * K * 8) * 16;
+  const size_t lds = (size_t)((TH + 2 * P) * (TW + 2 * P) * 16 + 256 + 2 * K * K * 8 + (BNS ? TH * TW * 8 + 16 : 0)) * 16;
   static LhnKernelCfg cfg;
-  (void)lhn_kernel_cfg(cfg, &k_dwk_bwd_lds<K, DIL>, lds, 4, nullptr);
-  hipLaunchKernelGGL((k_dwk_bwd_lds<K, DIL>), dim3(dw3_grid(ntile, cg, 4)), dim3(256), lds, s, *x, w, *y, *gy, dx, dx_acc, dw, th, tw,
-                     cg, nrep, rep_stride, ps);
+  (void)lhn_kernel_cfg(cfg, &k_dwk_bwd_lds<K, DIL, BNS>, lds, 4, nullptr);
+  hipLaunchKernelGGL((k_dwk_bwd_lds<K, DIL, BNS>), dim3(dw3_grid(ntile, cg, 4)), dim3(256), lds, s, *x, w, *y, *gy, dx, dx_acc, dw, th, tw,
+                     cg, nrep, rep_stride, ps, bs);
 }
 
 // returns 1 if an LDS-tiled kernel was launched
@@ -966,7 +1018,12 @@ int lhn_dwk_fwd_lds(const lhn_view* x, const float* w, const lhn_view* y, double
   return 1;
 }
 int lhn_dwk_bwd_lds(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx, int dx_acc,
-                    float* dw, int k, int dil, int nrep, int64_t rep_stride, hipStream_t s) {
+                    float* dw, int k, int dil, int nrep, int64_t rep_stride, hipStream_t s, const DwBnSum* bs) {
+  if (bs && bs->sums) {        // fused BatchNorm-backward sums of the producer: the 3x3 / dilation 1 instance only
+    if (!(k == 3 && dil == 1 && dx && !dx_acc)) return 0;
+    launch_dwk_bwd<3, 1, true>(x, w, y, gy, dx, dx_acc, dw, nrep, rep_stride, s, 1, bs);
+    return 1;
+  }
   if (k == 3 && dil == 1) launch_dwk_bwd<3, 1>(x, w, y, gy, dx, dx_acc, dw, nrep, rep_stride, s);
   else if (k == 3 && dil == 2 && x->W >= 16) launch_dwk_bwd<3, 1>(x, w, y, gy, dx, dx_acc, dw, nrep, rep_stride, s, 2);
   else if (k == 3 && dil == 2) launch_dwk_bwd<3, 2>(x, w, y, gy, dx, dx_acc, dw, nrep, rep_stride, s);
@@ -987,4 +1044,14 @@ static int dw_fwd_extra(const lhn_view* x, const float* w, const lhn_view* y, do
   ex.pend[0] = lhn_pends_of(x);
   ex.pend[1] = lhn_pends_of(extra);
   return lhn_dwk_fwd_lds(x, w, y, stats, k, dil, fin, s, &ex);
+}
+
+static int dw_bwd_fused(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx, float* dw, int k,
+                        int dil, int nrep, int64_t rep_stride, double* bn_sums, const float* bn_save, int bn_C, int bn_coff, hipStream_t s) {
+  DwBnSum bs;
+  bs.sums = bn_sums;
+  bs.save = bn_save;
+  bs.C = bn_C;
+  bs.coff = bn_coff;
+  return lhn_dwk_bwd_lds(x, w, y, gy, dx, 0, dw, k, dil, nrep, rep_stride, s, &bs);
 }

@@ -430,8 +430,11 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
         lhn_view y = mkview(P, ws, o.out_buf, o.out_coff, o.out_C);
         lhn_gradview g = mkgrad(P, ws, o.out_buf, o.i[5] != 0);
         float* dx = o.i[4] ? reinterpret_cast<float*>(at(ws, P->bufs[o.in_buf[0]].grad_off)) : nullptr;
-        rc = lhn_conv_dw_bwd(&x, prm<const float>(params, o.p[0]), &y, &g, dx, o.i[4] == 2, prm<float>(grads, o.p[1]), o.i[0],
-                             o.i[1], o.i[2], o.i[3], nrep, rstr, stream);
+        // ws[4], ws[5] >= 0: BatchNorm-backward sums / saved statistics of the convolution that produced x, i[6] its channel
+        // count, i[7] the producer channel of x's first channel (see lhn_conv_dw_bwd2)
+        rc = lhn_conv_dw_bwd2(&x, prm<const float>(params, o.p[0]), &y, &g, dx, o.i[4] == 2, prm<float>(grads, o.p[1]), o.i[0],
+                              o.i[1], o.i[2], o.i[3], nrep, rstr, o.ws[4] >= 0 ? reinterpret_cast<double*>(at(ws, o.ws[4])) : nullptr,
+                              o.ws[5] >= 0 ? reinterpret_cast<const float*>(at(ws, o.ws[5])) : nullptr, o.i[6], o.i[7], stream);
         break;
       }
       case OP_KXK_BWD: {
@@ -457,10 +460,10 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
         fin.dbeta = prm<float>(grads, o.p[2]);
         fin.count = (double)b.N * b.H * b.W * cscale;
         fin.cstride = b.C; fin.coff = o.out_coff; fin.C = o.out_C;
-        if (fin.counter && fuse_finalize() && whole) {
+        if (fin.counter && fuse_finalize() && whole && !o.i[1]) {
           rc = lhn_bn_bwd_reduce(&y, &g, save, sums, &fin, stream);
         } else {
-          if (h0) rc = lhn_bn_bwd_reduce(&y, &g, save, sums, nullptr, stream);
+          if (h0 && !o.i[1]) rc = lhn_bn_bwd_reduce(&y, &g, save, sums, nullptr, stream);      // i[1]: sums come from the reader's backward
           if (!rc && h1)
             rc = lhn_bn_bwd_finalize2(sums, fin.gamma, save, fin.coef, b.C, o.out_coff, o.i[0] > 0 ? o.i[0] : o.out_C, o.out_C, fin.count,
                                       fin.dgamma, fin.dbeta, pscale, stream);      // i[0]: real channels of a padded output

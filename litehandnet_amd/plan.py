@@ -135,7 +135,9 @@ class PlanBuilder:
         return self.in_ref
 
     def slice(self, x, coff, C):
-        assert 0 <= coff and coff + C <= x.C and coff % 4 == 0 and C % 4 == 0, (coff, C, x)
+        if not (0 <= coff and coff + C <= x.C and coff % 4 == 0 and C % 4 == 0):
+            raise _lib.LhnError(f"channel slice [{coff}:{coff + C}] of {x.C} channels: slices start and end on multiples of 4 "
+                                "(the kernels move 4 channels per thread)")
         if isinstance(x, TCat):
             out, lo = [], 0
             for p in x.parts:
@@ -726,10 +728,15 @@ class PlanBuilder:
                     self._alias_of[t.buf] = out.buf
             self.grad_aliases = len(aliased)
             materialised = set()
+            fuse_sums = os.environ.get("LHN_FUSE_BN_SUMS", "1") != "0"
+            self.fused_bn_sums = 0
+            for r in self.recs:
+                r.pop("sums_by_reader", None)
             for r in reversed(self.recs):
                 k = r["op"]
-                if k in (STEM, PW, DW, KXK, EW, SHUFFLE, MAXPOOL, AVGPOOL) and not (k == PW and r.get("nchw")) and r["out"] is not self.out_ref:
-                    self._covered(written, r["out"])
+                if k in (STEM, PW, DW, KXK, EW, SHUFFLE, MAXPOOL, AVGPOOL) and not (k == PW and r.get("nchw")) and \
+                        not (self.out_ref is not None and not isinstance(r["out"], TCat) and r["out"].buf == self.out_ref.buf):
+                    self._covered(written, r["out"])      # (the block output's gradient is written by the engine, not by an op)
                 if k in (STEM, PW, DW, KXK):
                     conv, bn, x, out = r["conv"], r["bn"], r["x"], r["out"]
                     pw = self._p(conv.weight)
@@ -744,7 +751,7 @@ class PlanBuilder:
                     if bn is not None:
                         body.append(mk(BN_BWD, out=out, p=(self._p(bn.weight), self._p(bn.weight), self._p(bn.bias)),
                                        ws=(self._abs(r["sums"]), self._abs(r["save"]), self._abs(r["bcnt"])),
-                                       i=(r["wrc"][0] if k == PW else 0,)))
+                                       i=(r["wrc"][0] if k == PW else 0, 1 if r.get("sums_by_reader") else 0)))
                     if k == STEM:
                         body.append(mk(STEM_BWD, out=out, p=(pw, pw), i=(r["k"], r["stride"], r["pad"], x.H, x.W, use_coef)))
                         continue
@@ -760,8 +767,24 @@ class PlanBuilder:
                                        i=(r["stride"], 1 if r["nchw"] else 0, mode, r["wrc"][0], r["wrc"][1], use_coef,
                                           r["stack"][0], r["stack"][1])))
                     elif k == DW:
-                        body.append(mk(DW_BWD, ins=(x,), out=out, p=(pw, pw),
-                                       i=(r["k"], r["stride"], r["pad"], r["dil"], mode, use_coef)))
+                        # the producer's BatchNorm-backward sums ride in this kernel when it is the only reader of x
+                        # (RepBasicUnit 1x1 -> 3x3 depthwise; include/lhn.h: lhn_conv_dw_bwd2)
+                        prod, xb = None, self.bufs[x.buf]
+                        if (fuse_sums and mode == 1 and r["k"] == 3 and r["stride"] == 1 and r["pad"] == 1 and r["dil"] == 1 and
+                                x.C % 32 == 0 and x.W >= 8 and not xb.gate and not xb.dpool and xb.lazy is None and
+                                conv.weight is not None and len(uses.get(x.buf, ())) == 1 and x.buf not in aliased):
+                            for q in self.recs:
+                                if q["op"] in (PW, DW, KXK) and q["bn"] is not None and q["out"].buf == x.buf and \
+                                        (q["out"].coff, q["out"].C) == (x.coff, x.C) and not q["wrc"][0] and q.get("bn_repeat", 1) == 1:
+                                    prod = q
+                        if prod is not None:
+                            prod["sums_by_reader"] = True
+                            self.fused_bn_sums += 1
+                            body.append(mk(DW_BWD, ins=(x,), out=out, p=(pw, pw), ws=(-1, -1, -1, -1, self._abs(prod["sums"]), self._abs(prod["save"])),
+                                           i=(r["k"], r["stride"], r["pad"], r["dil"], mode, use_coef, x.C, 0)))
+                        else:
+                            body.append(mk(DW_BWD, ins=(x,), out=out, p=(pw, pw),
+                                           i=(r["k"], r["stride"], r["pad"], r["dil"], mode, use_coef)))
                     else:
                         body.append(mk(KXK_BWD, ins=(x,), out=out, p=(pw, pw), ws=(-1, -1, -1, self._abs(r["wt"])),
                                        i=(r["stride"], 0, mode, 0, 0, use_coef)))

@@ -608,12 +608,15 @@ def test_width_256(dev):
 
 
 def test_unsupported_width_fails_loudly(dev):
-    """A width the elementwise kernels do not tile (C / 4 not a power of two) must raise LhnError on the first forward --
-    never fall back to anything else."""
+    """A width whose halves are not multiples of 4 channels (input_channel = 100: RepBasicUnit splits 50 / 50) must raise
+    LhnError on the first forward -- never fall back to anything else.  (Widths like 96 run: any multiple of 8.)"""
     from litehandnet_amd import _lib, get_model
-    m = get_model(litehandnet_cfg("B", channels=96)).to(dev).train()
-    with pytest.raises(_lib.LhnError):
+    m = get_model(litehandnet_cfg("B", channels=100)).to(dev).train()
+    with pytest.raises(_lib.LhnError, match="multiples of 4"):
         m(torch.zeros(2, 3, 64, 64, device=dev))
+    m96 = get_model(litehandnet_cfg("B", channels=96)).to(dev).train()
+    with torch.no_grad():
+        assert torch.isfinite(m96(torch.randn(2, 3, 64, 64, device=dev))).all()
 
 
 def test_unsupported_inputs_fail_loudly(dev):

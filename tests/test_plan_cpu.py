@@ -189,3 +189,23 @@ def test_deferred_finalizes(monkeypatch):
     _, p0, _ = _build("B", backward=False)
     cb, cf, _, nf, _ = p0.finalize()
     assert all(cf[i].i[7] == 0 and all(cf[i].pend[k][e] == -1 for k in range(3) for e in range(2)) for i in range(nf))
+
+
+def test_bn_backward_sums_ride_in_the_reader(monkeypatch):
+    """RepBasicUnit's 1x1 -> 3x3 depthwise: the depthwise backward is the only reader of the 1x1's output, so it also
+    accumulates that BatchNorm's backward sums (lhn_conv_dw_bwd2) and the producer's BN_BWD op skips its reduce pass:
+    18 of variant B's 52, none where the reader is not a stride-1 3x3 depthwise; LHN_FUSE_BN_SUMS=0 switches it off."""
+    from litehandnet_amd.plan import BN_BWD, DW_BWD
+    _, pb, _ = _build("B", backward=True)
+    cb, cf, cbw, nf, nb = pb.finalize()
+    bwd = [cbw[i] for i in range(nb)]
+    fused = [o for o in bwd if o.kind == DW_BWD and o.ws[4] >= 0]
+    skipped = [o for o in bwd if o.kind == BN_BWD and o.i[1] == 1]
+    assert pb.fused_bn_sums == len(fused) == len(skipped) == 18
+    assert {o.ws[4] for o in fused} == {o.ws[0] for o in skipped}          # the same sums buffers
+    for o in fused:
+        assert o.i[4] == 1 and o.i[0] == 3 and o.i[1] == 1 and o.i[3] == 1 and o.ws[5] >= 0        # dx stored, 3x3 s1 d1
+    monkeypatch.setenv("LHN_FUSE_BN_SUMS", "0")
+    _, p0, _ = _build("B", backward=True)
+    p0.finalize()
+    assert p0.fused_bn_sums == 0
