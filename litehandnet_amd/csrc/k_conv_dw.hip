@@ -496,6 +496,25 @@ extern "C" int lhn_conv_dw_bwd2(const lhn_view* x, const float* w, const lhn_vie
   return 0;
 }
 
+static int dw_bwd_addends(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx, int dx_acc, float* dw,
+                          int k, int dil, int nrep, int64_t rep_stride, const float* a0, const float* a1, hipStream_t s);
+
+extern "C" int lhn_conv_dw_bwd3(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx,
+                                int dx_accumulate, float* dw, int k, int stride, int pad, int dil, int nrep, int64_t rep_stride,
+                                const float* dx_add0, const float* dx_add1, void* stream) {
+  if (!dx_add0 && !dx_add1) return lhn_conv_dw_bwd(x, w, y, gy, dx, dx_accumulate, dw, k, stride, pad, dil, nrep, rep_stride, stream);
+  if (nrep < 1) nrep = 1;
+  LHN_CHECK_ARG(lhn_view_ok(x) && lhn_view_ok(y) && gy && gy->dz && w && dw && dx && lhn_no_pend(x) && lhn_no_pend(y),
+                "lhn_conv_dw_bwd3: bad view / null pointer");
+  LHN_CHECK_ARG(stride == 1 && pad == dil * (k - 1) / 2 && x->C % 32 == 0 && x->W >= 8 && x->C == y->C,
+                "lhn_conv_dw_bwd3: gradient addends need the tiled stride-1 kernel (C %% 32 == 0, W >= 8)");
+  const int rc = dw_bwd_addends(x, w, y, gy, dx, dx_accumulate, dw, k, dil, nrep, rep_stride, dx_add0 ? dx_add0 : dx_add1,
+                                dx_add0 ? dx_add1 : nullptr, (hipStream_t)stream);
+  LHN_CHECK_ARG(rc == 1, "lhn_conv_dw_bwd3: no tiled kernel for k=%d dil=%d", k, dil);
+  LHN_CHECK_LAUNCH("lhn_conv_dw_bwd3");
+  return 0;
+}
+
 extern "C" int lhn_conv_dw_bwd(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx,
                                int dx_accumulate, float* dw, int k, int stride, int pad, int dil, int nrep, int64_t rep_stride,
                                void* stream) {
@@ -747,6 +766,8 @@ struct DwBnSum {
   double* sums;          // [LHN_STAT_REPLICAS][2][C] of the producer's BatchNorm backward, or NULL
   const float* save;     // [2][C] mean | invstd of the producer
   int C, coff;           // producer channels; channel of the producer that x's first channel is
+  const float* add[2];   // gradient buffers (dx's geometry) whose values join the stored dx: d(sum) of residual adds that
+                         // read x, so that no separate elementwise pass copies / accumulates them (NULL: none)
 };
 
 template <int K, int DIL, bool BNS = false>
@@ -860,6 +881,8 @@ __global__ void __launch_bounds__(256) k_dwk_bwd_lds(lhn_view x, const float* __
           if (dx) {
             float* o = dx + ((size_t)(n * x.H + pa + ps * hh) * x.W + pb + ps * wcol) * x.cstride + cx;
             if (dx_acc) accx += *reinterpret_cast<const f4*>(o);
+            if (bs.add[0]) accx += *reinterpret_cast<const f4*>(bs.add[0] + (o - dx));
+            if (bs.add[1]) accx += *reinterpret_cast<const f4*>(bs.add[1] + (o - dx));
             *reinterpret_cast<f4*>(o) = accx;
           }
         }
@@ -878,6 +901,8 @@ __global__ void __launch_bounds__(256) k_dwk_bwd_lds(lhn_view x, const float* __
                 accx += tdy[centre - ((a * DIL - T::P) * T::WW + (b * DIL - T::P)) * 8] * wl[(a * K + b) * 8 + c4];
             float* o = dx + ((size_t)(n * x.H + pa + ps * hh) * x.W + pb + ps * wcol) * x.cstride + cx;
             if (dx_acc) accx += *reinterpret_cast<const f4*>(o);
+            if (bs.add[0]) accx += *reinterpret_cast<const f4*>(bs.add[0] + (o - dx));
+            if (bs.add[1]) accx += *reinterpret_cast<const f4*>(bs.add[1] + (o - dx));
             *reinterpret_cast<f4*>(o) = accx;
           }
         }
@@ -990,7 +1015,7 @@ static void launch_dwk_bwd(const lhn_view* x, const float* w, const lhn_view* y,
                            float* dw, int nrep, int64_t rep_stride, hipStream_t s, int ps = 1, const DwBnSum* bsp = nullptr) {
   constexpr int TH = 8, TW = 16, P = DIL * (K - 1) / 2;
   DwBnSum bs;
-  if (bsp) bs = *bsp; else { bs.sums = nullptr; bs.save = nullptr; bs.C = bs.coff = 0; }
+  if (bsp) bs = *bsp; else { bs.sums = nullptr; bs.save = nullptr; bs.C = bs.coff = 0; bs.add[0] = bs.add[1] = nullptr; }
   const int cg = x->C / 32;
   const int sh = (x->H + ps - 1) / ps, sw = (x->W + ps - 1) / ps;
   const int th = (sh + TH - 1) / TH, tw = (sw + TW - 1) / TW, ntile = x->N * ps * ps * th * tw * cg;
@@ -1024,10 +1049,10 @@ int lhn_dwk_bwd_lds(const lhn_view* x, const float* w, const lhn_view* y, const 
     launch_dwk_bwd<3, 1, true>(x, w, y, gy, dx, dx_acc, dw, nrep, rep_stride, s, 1, bs);
     return 1;
   }
-  if (k == 3 && dil == 1) launch_dwk_bwd<3, 1>(x, w, y, gy, dx, dx_acc, dw, nrep, rep_stride, s);
-  else if (k == 3 && dil == 2 && x->W >= 16) launch_dwk_bwd<3, 1>(x, w, y, gy, dx, dx_acc, dw, nrep, rep_stride, s, 2);
-  else if (k == 3 && dil == 2) launch_dwk_bwd<3, 2>(x, w, y, gy, dx, dx_acc, dw, nrep, rep_stride, s);
-  else if (k == 7 && dil == 1) launch_dwk_bwd<7, 1>(x, w, y, gy, dx, dx_acc, dw, nrep, rep_stride, s);
+  if (k == 3 && dil == 1) launch_dwk_bwd<3, 1>(x, w, y, gy, dx, dx_acc, dw, nrep, rep_stride, s, 1, bs);
+  else if (k == 3 && dil == 2 && x->W >= 16) launch_dwk_bwd<3, 1>(x, w, y, gy, dx, dx_acc, dw, nrep, rep_stride, s, 2, bs);
+  else if (k == 3 && dil == 2) launch_dwk_bwd<3, 2>(x, w, y, gy, dx, dx_acc, dw, nrep, rep_stride, s, 1, bs);
+  else if (k == 7 && dil == 1) launch_dwk_bwd<7, 1>(x, w, y, gy, dx, dx_acc, dw, nrep, rep_stride, s, 1, bs);
   else return 0;
   return 1;
 }
@@ -1046,6 +1071,17 @@ static int dw_fwd_extra(const lhn_view* x, const float* w, const lhn_view* y, do
   return lhn_dwk_fwd_lds(x, w, y, stats, k, dil, fin, s, &ex);
 }
 
+static int dw_bwd_addends(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx, int dx_acc, float* dw,
+                          int k, int dil, int nrep, int64_t rep_stride, const float* a0, const float* a1, hipStream_t s) {
+  DwBnSum bs;
+  bs.sums = nullptr;
+  bs.save = nullptr;
+  bs.C = bs.coff = 0;
+  bs.add[0] = a0;
+  bs.add[1] = a1;
+  return lhn_dwk_bwd_lds(x, w, y, gy, dx, dx_acc, dw, k, dil, nrep, rep_stride, s, &bs);
+}
+
 static int dw_bwd_fused(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx, float* dw, int k,
                         int dil, int nrep, int64_t rep_stride, double* bn_sums, const float* bn_save, int bn_C, int bn_coff, hipStream_t s) {
   DwBnSum bs;
@@ -1053,5 +1089,6 @@ static int dw_bwd_fused(const lhn_view* x, const float* w, const lhn_view* y, co
   bs.save = bn_save;
   bs.C = bn_C;
   bs.coff = bn_coff;
+  bs.add[0] = bs.add[1] = nullptr;
   return lhn_dwk_bwd_lds(x, w, y, gy, dx, 0, dw, k, dil, nrep, rep_stride, s, &bs);
 }

@@ -432,6 +432,13 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
         float* dx = o.i[4] ? reinterpret_cast<float*>(at(ws, P->bufs[o.in_buf[0]].grad_off)) : nullptr;
         // ws[4], ws[5] >= 0: BatchNorm-backward sums / saved statistics of the convolution that produced x, i[6] its channel
         // count, i[7] the producer channel of x's first channel (see lhn_conv_dw_bwd2)
+        // ws[2], ws[3] >= 0: gradients of residual sums that read x, added to the stored dx (lhn_conv_dw_bwd3)
+        if (o.ws[2] >= 0 || o.ws[3] >= 0) {
+          rc = lhn_conv_dw_bwd3(&x, prm<const float>(params, o.p[0]), &y, &g, dx, o.i[4] == 2, prm<float>(grads, o.p[1]), o.i[0], o.i[1],
+                                o.i[2], o.i[3], nrep, rstr, o.ws[2] >= 0 ? reinterpret_cast<const float*>(at(ws, o.ws[2])) : nullptr,
+                                o.ws[3] >= 0 ? reinterpret_cast<const float*>(at(ws, o.ws[3])) : nullptr, stream);
+          break;
+        }
         rc = lhn_conv_dw_bwd2(&x, prm<const float>(params, o.p[0]), &y, &g, dx, o.i[4] == 2, prm<float>(grads, o.p[1]), o.i[0],
                               o.i[1], o.i[2], o.i[3], nrep, rstr, o.ws[4] >= 0 ? reinterpret_cast<double*>(at(ws, o.ws[4])) : nullptr,
                               o.ws[5] >= 0 ? reinterpret_cast<const float*>(at(ws, o.ws[5])) : nullptr, o.i[6], o.i[7], stream);

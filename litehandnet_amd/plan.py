@@ -728,6 +728,45 @@ class PlanBuilder:
                     self._alias_of[t.buf] = out.buf
             self.grad_aliases = len(aliased)
             materialised = set()
+            # Gradient addends: a plain residual sum O = S + ... hands d(O) to every source.  When S's other readers are
+            # tiled depthwise convolutions whose input slices tile S exactly (MSRB: `out` feeds the two dilated 3x3 halves
+            # and the running sum, litehourglass.py:41-49), those convolutions' backward kernels add d(O) while storing
+            # their dx (include/lhn.h: lhn_conv_dw_bwd3) and the sum's copy / accumulate pass over S's gradient disappears.
+            pending_add, self.grad_addends = {}, 0
+            if os.environ.get("LHN_GRAD_ADDENDS", "1") != "0":
+                order = {id(q): j for j, q in enumerate(self.recs)}
+
+                def plain_sum(q):
+                    return q["op"] == EW and q["slope"] == 1.0 and not q.get("mode") and q.get("coefs") is None and \
+                        not isinstance(q["out"], TCat)
+
+                for sb, rd in uses.items():
+                    if sb < 0 or sb in aliased or sb == self._no_grad_buf:
+                        continue
+                    sums = [q for q in rd if plain_sum(q)]
+                    dws = [q for q in rd if not plain_sum(q)]
+                    if not sums or not dws or len(sums) > 2:
+                        continue
+                    if not all(q["op"] == DW and q["conv"].weight is not None and q["stride"] == 1 and q["k"] == 3 and
+                               q["pad"] == q["dil"] and q["x"].C % 32 == 0 and q["x"].W >= 8 and not isinstance(q["x"], TCat)
+                               for q in dws):
+                        continue
+                    if min(order[id(q)] for q in sums) < max(order[id(q)] for q in dws):
+                        continue
+                    spans = sorted((q["x"].coff, q["x"].coff + q["x"].C) for q in dws)
+                    lo, hi = spans[0][0], spans[-1][1]
+                    if any(a[1] != b[0] for a, b in zip(spans, spans[1:])):
+                        continue
+                    adds = []
+                    for q in sums:
+                        mine = [t for t in q["srcs"] if not isinstance(t, TCat) and t.buf == sb]
+                        o = q["out"]
+                        if len(mine) != 1 or (mine[0].coff, mine[0].C) != (lo, hi - lo) or (mine[0].H, mine[0].W) != (o.H, o.W) or \
+                                self.bufs[o.buf].C != self.bufs[sb].C:
+                            break
+                        adds.append((id(q), o.buf, o.coff - lo))
+                    else:
+                        pending_add[sb] = adds
             fuse_sums = os.environ.get("LHN_FUSE_BN_SUMS", "1") != "0"
             self.fused_bn_sums = 0
             for r in self.recs:
@@ -777,7 +816,13 @@ class PlanBuilder:
                                 if q["op"] in (PW, DW, KXK) and q["bn"] is not None and q["out"].buf == x.buf and \
                                         (q["out"].coff, q["out"].C) == (x.coff, x.C) and not q["wrc"][0] and q.get("bn_repeat", 1) == 1:
                                     prod = q
-                        if prod is not None:
+                        adds = pending_add.get(x.buf)
+                        if adds and need_dx:
+                            self.grad_addends += 1
+                            offs = [self.bufs[ob].off["grad"] + 4 * sh for _, ob, sh in adds]
+                            body.append(mk(DW_BWD, ins=(x,), out=out, p=(pw, pw), ws=(-1, -1, offs[0], offs[1] if len(offs) > 1 else -1),
+                                           i=(r["k"], r["stride"], r["pad"], r["dil"], mode, use_coef)))
+                        elif prod is not None:
                             prod["sums_by_reader"] = True
                             self.fused_bn_sums += 1
                             body.append(mk(DW_BWD, ins=(x,), out=out, p=(pw, pw), ws=(-1, -1, -1, -1, self._abs(prod["sums"]), self._abs(prod["save"])),
@@ -807,6 +852,8 @@ class PlanBuilder:
                     for s in r["srcs"]:
                         if s.buf == self._no_grad_buf or (s.buf in aliased and self.bufs[s.buf].off["grad"] == self.bufs[r["out"].buf].off["grad"]):
                             continue
+                        if any(a[0] == id(r) for a in pending_add.get(s.buf, ())):
+                            continue                # d(out) joins s's gradient inside the depthwise backward kernels that read s
                         mode = self._grad_mode(written, s)
                         body.append(mk(EW_BWD, ins=(s,), out=r["out"], i=(1 if mode == 2 else 0,), f=(r["slope"],)))
                 elif k == SHUFFLE:

@@ -209,3 +209,29 @@ def test_bn_backward_sums_ride_in_the_reader(monkeypatch):
     _, p0, _ = _build("B", backward=True)
     p0.finalize()
     assert p0.fused_bn_sums == 0
+
+
+def test_residual_sum_gradients_ride_in_the_depthwise_backward(monkeypatch):
+    """MSRB (litehourglass.py:41-49): `out` feeds the two dilated depthwise halves and the running sum(s).  The sums' output
+    gradients are added by those depthwise backward kernels while they store dx (lhn_conv_dw_bwd3): no EW_BWD op writes the
+    gradient of such a buffer, every one of its channels is written exactly once (stored), and LHN_GRAD_ADDENDS=0 restores
+    the separate passes."""
+    from litehandnet_amd.plan import DW_BWD, EW_BWD
+    _, pb, _ = _build("B", backward=True)
+    cb, cf, cbw, nf, nb = pb.finalize()
+    bwd = [cbw[i] for i in range(nb)]
+    withadd = [o for o in bwd if o.kind == DW_BWD and (o.ws[2] >= 0 or o.ws[3] >= 0)]
+    assert pb.grad_addends == len(withadd) == 8                # 2 MSRBs x 2 rounds x 2 halves
+    assert sum(1 for o in withadd if o.ws[3] >= 0) == 4        # the MSRB input collects two sums, the first running sum one
+    bufs = {o.in_buf[0] for o in withadd}
+    assert not [o for o in bwd if o.kind == EW_BWD and o.in_buf[0] in bufs]
+    for b in bufs:
+        spans = sorted((o.in_coff[0], o.in_coff[0] + o.in_C[0]) for o in withadd if o.in_buf[0] == b)
+        assert spans == [(0, 64), (64, 128)] and all(o.i[4] == 1 for o in withadd if o.in_buf[0] == b)
+    grads = {cb[j].grad_off for j in range(len(pb.bufs))}
+    assert all(o.ws[2] in grads and (o.ws[3] < 0 or o.ws[3] in grads) for o in withadd)
+    n_ew = sum(1 for o in bwd if o.kind == EW_BWD)
+    monkeypatch.setenv("LHN_GRAD_ADDENDS", "0")
+    _, p0, _ = _build("B", backward=True)
+    _, _, cbw0, _, nb0 = p0.finalize()
+    assert p0.grad_addends == 0 and sum(1 for i in range(nb0) if cbw0[i].kind == EW_BWD) == n_ew + 6
