@@ -209,6 +209,10 @@ typedef struct lhn_pw_opts {
   int32_t n_extra;              /* 0..2 */
   const lhn_view* extra;
   float coef[3];
+  /* with extra sources: the summed input is ALSO written here (plain values; same pixels and channel count as x).  A
+   * training forward leaves the sum where the backward's weight gradient reads it -- one write instead of a separate
+   * elementwise pass that re-reads every operand.  NULL: not written. */
+  const lhn_view* sum_out;
 } lhn_pw_opts;
 int lhn_conv_pw_fwd2(const lhn_view* x, const float* w, const float* bias, const lhn_view* y, double* stats, int stride,
                      float* y_nchw, const lhn_bnfin* fin, const lhn_pw_opts* opts, void* stream);
@@ -218,6 +222,9 @@ int lhn_conv_dw_fwd(const lhn_view* x, const float* w /*[C,1,k,k]*/, const lhn_v
  * round reads `out + ca(cat)` (litehourglass.py:41-45) without an elementwise pass in between.  extra == NULL: lhn_conv_dw_fwd. */
 int lhn_conv_dw_fwd2(const lhn_view* x, const float* w, const lhn_view* y, double* stats, int k, int stride, int pad, int dil,
                      const lhn_bnfin* fin, const lhn_view* extra, const float* coef2 /*host, 2 floats*/, void* stream);
+/* ... and sum_out (or NULL): the summed input is also written there, see lhn_pw_opts.sum_out. */
+int lhn_conv_dw_fwd3(const lhn_view* x, const float* w, const lhn_view* y, double* stats, int k, int stride, int pad, int dil,
+                     const lhn_bnfin* fin, const lhn_view* extra, const float* coef2, const lhn_view* sum_out, void* stream);
 int lhn_conv_stem_fwd(const float* img /*[N,3,Hi,Wi]*/, const float* w /*[Cout,3,k,k]*/, const lhn_view* y,
                       double* stats, int Hi, int Wi, int k, int stride, int pad, const lhn_bnfin* fin, void* stream);
 /* wt_scratch: optional 9*Cout*Cin floats of caller-owned scratch; the call re-lays the OIHW weights tap-major into it

@@ -200,6 +200,8 @@ struct DwExtra {
   float coef[2];
   int n;             // 0 or 1
   lhn_pends pend[2]; // BatchNorms to finalize first: [0] = x, [1] = v (see lhn_pend)
+  float* sum_out;    // the summed input (tile interiors) is also written here, or NULL (lhn_pw_opts.sum_out)
+  int so_cstride, so_coff;
 };
 
 int lhn_dwk_fwd_lds(const lhn_view* x, const float* w, const lhn_view* y, double* stats, int k, int dil, lhn_bnfin fin,
@@ -217,21 +219,33 @@ static bool lhn_dw_force_gather() {
 }
 
 static int dw_fwd_extra(const lhn_view* x, const float* w, const lhn_view* y, double* stats, int k, int stride, int pad, int dil,
-                        lhn_bnfin fin, const lhn_view* extra, const float* coef, hipStream_t s);
+                        lhn_bnfin fin, const lhn_view* extra, const float* coef, const lhn_view* so, hipStream_t s);
 
-extern "C" int lhn_conv_dw_fwd2(const lhn_view* x, const float* w, const lhn_view* y, double* stats, int k, int stride,
-                                int pad, int dil, const lhn_bnfin* finp, const lhn_view* extra, const float* coef2, void* stream) {
-  if (!extra) return lhn_conv_dw_fwd(x, w, y, stats, k, stride, pad, dil, finp, stream);
+extern "C" int lhn_conv_dw_fwd3(const lhn_view* x, const float* w, const lhn_view* y, double* stats, int k, int stride,
+                                int pad, int dil, const lhn_bnfin* finp, const lhn_view* extra, const float* coef2,
+                                const lhn_view* sum_out, void* stream) {
+  if (!extra) {
+    LHN_CHECK_ARG(!sum_out, "lhn_conv_dw_fwd3: sum_out without a second source");
+    return lhn_conv_dw_fwd(x, w, y, stats, k, stride, pad, dil, finp, stream);
+  }
   lhn_bnfin fin;
   if (finp && stats) fin = *finp; else fin.counter = nullptr;
   LHN_CHECK_ARG(lhn_view_ok(x) && lhn_view_ok(y) && lhn_view_ok(extra) && w && coef2, "lhn_conv_dw_fwd2: bad view / null pointer");
   LHN_CHECK_ARG(extra->C == x->C && extra->N == x->N && extra->H == x->H && extra->W == x->W, "lhn_conv_dw_fwd2: extra source geometry");
   LHN_CHECK_ARG(x->C == y->C && y->N == x->N && y->H == x->H && y->W == x->W, "lhn_conv_dw_fwd2: same-size output");
-  const int rc = dw_fwd_extra(x, w, y, stats, k, stride, pad, dil, fin, extra, coef2, (hipStream_t)stream);
+  LHN_CHECK_ARG(!sum_out || (sum_out->data && sum_out->C == x->C && sum_out->N == x->N && sum_out->H == x->H && sum_out->W == x->W &&
+                             sum_out->cstride % 4 == 0 && sum_out->coff % 4 == 0 && sum_out->coff + sum_out->C <= sum_out->cstride),
+                "lhn_conv_dw_fwd3: sum_out geometry (same pixels and channels as x)");
+  const int rc = dw_fwd_extra(x, w, y, stats, k, stride, pad, dil, fin, extra, coef2, sum_out, (hipStream_t)stream);
   LHN_CHECK_ARG(rc == 1, "lhn_conv_dw_fwd2: a second source needs k=3, stride 1, 'same' padding, C %% 32 == 0, W >= 8 (got k=%d s=%d C=%d W=%d)",
                 k, stride, x->C, y->W);
   LHN_CHECK_LAUNCH("lhn_conv_dw_fwd2");
   return 0;
+}
+
+extern "C" int lhn_conv_dw_fwd2(const lhn_view* x, const float* w, const lhn_view* y, double* stats, int k, int stride,
+                                int pad, int dil, const lhn_bnfin* finp, const lhn_view* extra, const float* coef2, void* stream) {
+  return lhn_conv_dw_fwd3(x, w, y, stats, k, stride, pad, dil, finp, extra, coef2, nullptr, stream);
 }
 
 extern "C" int lhn_conv_dw_fwd(const lhn_view* x, const float* w, const lhn_view* y, double* stats, int k, int stride,
@@ -252,6 +266,7 @@ extern "C" int lhn_conv_dw_fwd(const lhn_view* x, const float* w, const lhn_view
   ex0.n = 0;
   ex0.pend[0] = px;
   ex0.pend[1].n = 0;
+  ex0.sum_out = nullptr;
   if (w && stride == 1 && pad == dil * (k - 1) / 2 && x->C % 32 == 0 && y->W >= 8 && !lhn_dw_force_gather() &&
       lhn_dwk_fwd_lds(x, w, y, stats, k, dil, fin, s, &ex0)) {
   } else if (k == 3)
@@ -681,7 +696,12 @@ __global__ void __launch_bounds__(256) k_dwk_fwd_lds(lhn_view x, const float* __
         const int ih = h0 + ph, iw = w0 + pw;
         const bool inb = ih >= 0 && ih < SH && iw >= 0 && iw < SW;
         f4 v = lhn_apply_xf(raw[it], xf) * gate;
-        if (NS > 1) v += lhn_apply_xf(raw2[it], xf2) * gate2;
+        if (NS > 1) {
+          v += lhn_apply_xf(raw2[it], xf2) * gate2;
+          if (ex.sum_out && inb && ph >= T::P && ph < T::P + TH && pw >= T::P && pw < T::P + TW)
+            *reinterpret_cast<f4*>(ex.sum_out + ((size_t)(n * x.H + pa + ps * ih) * x.W + pb + ps * iw) * ex.so_cstride + ex.so_coff +
+                                   cg * 32 + 4 * c4) = v;
+        }
         tile[i * 8 + c4] = inb ? v : (f4){0.f, 0.f, 0.f, 0.f};
       }
     }
@@ -999,7 +1019,7 @@ template <int K, int DIL, int NS = 1>
 static void launch_dwk_fwd(const lhn_view* x, const float* w, const lhn_view* y, double* stats, lhn_bnfin fin, hipStream_t s, int ps = 1,
                            const DwExtra* exp = nullptr) {
   DwExtra ex;
-  if (exp) ex = *exp; else { ex.n = 0; ex.pend[0].n = ex.pend[1].n = 0; }
+  if (exp) ex = *exp; else { ex.n = 0; ex.pend[0].n = ex.pend[1].n = 0; ex.sum_out = nullptr; }
   constexpr int TH = 8, TW = 32, P = DIL * (K - 1) / 2;
   const int cg = x->C / 32;
   const int sh = (y->H + ps - 1) / ps, sw = (y->W + ps - 1) / ps;       // largest parity sub-lattice
@@ -1058,7 +1078,7 @@ int lhn_dwk_bwd_lds(const lhn_view* x, const float* w, const lhn_view* y, const 
 }
 
 static int dw_fwd_extra(const lhn_view* x, const float* w, const lhn_view* y, double* stats, int k, int stride, int pad, int dil,
-                        lhn_bnfin fin, const lhn_view* extra, const float* coef, hipStream_t s) {
+                        lhn_bnfin fin, const lhn_view* extra, const float* coef, const lhn_view* so, hipStream_t s) {
   if (!(stride == 1 && pad == dil * (k - 1) / 2 && x->C % 32 == 0 && y->W >= 8)) return 0;
   if (!lhn_pend_ok(x) || !lhn_pend_ok(extra)) return 0;
   DwExtra ex;
@@ -1068,6 +1088,9 @@ static int dw_fwd_extra(const lhn_view* x, const float* w, const lhn_view* y, do
   ex.n = 1;
   ex.pend[0] = lhn_pends_of(x);
   ex.pend[1] = lhn_pends_of(extra);
+  ex.sum_out = so ? so->data : nullptr;
+  ex.so_cstride = so ? so->cstride : 0;
+  ex.so_coff = so ? so->coff : 0;
   return lhn_dwk_fwd_lds(x, w, y, stats, k, dil, fin, s, &ex);
 }
 

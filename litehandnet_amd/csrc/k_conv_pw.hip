@@ -52,6 +52,8 @@ struct PwExtra {
   float coef[3];
   int n;             // number of EXTRA sources in v (0..2)
   lhn_pends pend[3]; // BatchNorms to finalize first: [0] = x, [1..2] = v[0..1] (see lhn_pend)
+  float* sum_out;    // the summed input is ALSO written here (NULL: not): training needs it once, for the weight gradient
+  int so_cstride, so_coff;
 };
 
 template <int CIN, int NT, int NS = 1>
@@ -130,6 +132,7 @@ __global__ void __launch_bounds__(256, NS > 1 ? 1 : ((CIN == 64 && NT == 2) || (
               if (ex.v[e].gate) u *= *reinterpret_cast<const f4*>(ex.v[e].gate + (int64_t)(m / HoWo) * ex.v[e].cstride + ecabs[e]);
               v += u * ex.coef[e + 1];
             }
+          if (ex.sum_out) *reinterpret_cast<f4*>(ex.sum_out + (int64_t)m * ex.so_cstride + ex.so_coff + 4 * c4) = v;
         }
       }
       *reinterpret_cast<f4*>(As + row * LDA + 4 * c4) = v;
@@ -247,7 +250,7 @@ static int launch_pw_fwd(const lhn_view* x, const float* w, const float* bias, c
                          int stride, float* y_nchw, int cout, const lhn_bnfin* fin, const PwGeom& geo, hipStream_t s,
                          const PwExtra* exp = nullptr) {
   PwExtra ex;
-  if (exp) ex = *exp; else { ex.n = 0; ex.pend[0].n = ex.pend[1].n = ex.pend[2].n = 0; }
+  if (exp) ex = *exp; else { ex.n = 0; ex.pend[0].n = ex.pend[1].n = ex.pend[2].n = 0; ex.sum_out = nullptr; }
   lhn_bnfin f;
   if (fin && stats) f = *fin; else f.counter = nullptr;
   const int M = y->N * y->H * y->W;
@@ -337,6 +340,7 @@ k_pw_fwd_wr(lhn_view x, const float* __restrict__ w, const float* __restrict__ b
               if (ex.v[e].gate) u *= *reinterpret_cast<const f4*>(ex.v[e].gate + (int64_t)n * ex.v[e].cstride + ecabs[e]);
               v += u * ex.coef[e + 1];
             }
+          if (ex.sum_out) *reinterpret_cast<f4*>(ex.sum_out + (int64_t)m * ex.so_cstride + ex.so_coff + 4 * c4) = v;
         }
       }
       *reinterpret_cast<f4*>(As + row * LDA + 4 * c4) = v;
@@ -414,7 +418,7 @@ template <int CIN, int NCOT, int NS>
 static int launch_pw_fwd_wr(const lhn_view* x, const float* w, const float* bias, const lhn_view* y, double* stats, int cout,
                             hipStream_t s, const PwExtra* exp) {
   PwExtra ex;
-  if (exp) ex = *exp; else { ex.n = 0; ex.pend[0].n = ex.pend[1].n = ex.pend[2].n = 0; }
+  if (exp) ex = *exp; else { ex.n = 0; ex.pend[0].n = ex.pend[1].n = ex.pend[2].n = 0; ex.sum_out = nullptr; }
   constexpr int BM = 32 * (4 / NCOT);
   const int M = y->N * y->H * y->W, ntiles = (M + BM - 1) / BM;
   const size_t lds = (size_t)2 * BM * (CIN + 4) * sizeof(float);
@@ -504,6 +508,8 @@ extern "C" int lhn_conv_pw_fwd2(const lhn_view* x, const float* w, const float* 
   const bool single = Cin <= 128 && Cout <= 128;
   PwExtra ex;
   ex.n = 0;
+  ex.sum_out = nullptr;
+  ex.so_cstride = ex.so_coff = 0;
   LHN_CHECK_ARG(lhn_pend_ok(x), "lhn_conv_pw_fwd: bad pending BatchNorm on the input view");
   ex.pend[0] = lhn_pends_of(x);
   ex.pend[1].n = ex.pend[2].n = 0;
@@ -518,6 +524,17 @@ extern "C" int lhn_conv_pw_fwd2(const lhn_view* x, const float* w, const float* 
       ex.pend[e + 1] = lhn_pends_of(v);
     }
     for (int e = 0; e < 3; ++e) ex.coef[e] = opts->coef[e];
+    if (opts->sum_out) {
+      const lhn_view* so = opts->sum_out;
+      LHN_CHECK_ARG(so->data && so->C == Cin && so->N == x->N && so->H == x->H && so->W == x->W && so->cstride % 4 == 0 && so->coff % 4 == 0 &&
+                        so->coff + so->C <= so->cstride && Cout <= 128 && Cin % 4 == 0,
+                    "lhn_conv_pw_fwd: sum_out geometry (same pixels and channels as x, one output slice)");
+      ex.sum_out = so->data;
+      ex.so_cstride = so->cstride;
+      ex.so_coff = so->coff;
+    }
+  } else {
+    LHN_CHECK_ARG(!(opts && opts->sum_out), "lhn_conv_pw_fwd: sum_out without extra sources");
   }
   for (int co0 = 0; co0 < Cout; co0 += 128) {
     const int cc = Cout - co0 < 128 ? Cout - co0 : 128;

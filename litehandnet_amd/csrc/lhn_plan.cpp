@@ -259,6 +259,16 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
           po.extra = extra;
           for (int e = 0; e < 3; ++e) po.coef[e] = o.f[4 + e];
         }
+        // ws[4] >= 0 (plans with a backward): the summed input is also written to the buffer at that byte offset, ws[5] = pixel
+        // stride * 65536 + first channel (lhn_pw_opts.sum_out)
+        lhn_view sumv;
+        if (o.i[6] > 1 && o.ws[4] >= 0) {
+          sumv = x;
+          sumv.data = reinterpret_cast<float*>(at(ws, o.ws[4]));
+          sumv.table = nullptr; sumv.gate = nullptr; sumv.pend = nullptr;
+          sumv.cstride = (int)(o.ws[5] >> 16); sumv.coff = (int)(o.ws[5] & 0xffff);
+          po.sum_out = &sumv;
+        }
         if (nchw && o.i[5] > 1) {
           const int64_t khw = (int64_t)o.out_C * y.H * y.W;
           nchw += (int64_t)o.i[4] * khw;
@@ -287,9 +297,18 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
           extra = mkview(P, ws, o.in_buf[1], o.in_coff[1], o.in_C[1]);
           if (has_pend && pd[1].n) extra.pend = &pd[1];
         }
-        if (h0) rc = lhn_conv_dw_fwd2(&x, prm<const float>(params, o.p[0]), &y,
+        lhn_view sumv;           // ws[4], ws[5]: see OP_PW
+        const bool so = o.i[6] > 1 && o.ws[4] >= 0;
+        if (so) {
+          sumv = x;
+          sumv.data = reinterpret_cast<float*>(at(ws, o.ws[4]));
+          sumv.table = nullptr; sumv.gate = nullptr; sumv.pend = nullptr;
+          sumv.cstride = (int)(o.ws[5] >> 16); sumv.coff = (int)(o.ws[5] & 0xffff);
+        }
+        if (h0) rc = lhn_conv_dw_fwd3(&x, prm<const float>(params, o.p[0]), &y,
                               (training && o.ws[0] >= 0) ? reinterpret_cast<double*>(at(ws, o.ws[0])) : nullptr, o.i[0], o.i[1], o.i[2], o.i[3],
-                              (bn && training && fuse_finalize() && whole) ? &fin : nullptr, o.i[6] > 1 ? &extra : nullptr, coef2, stream);
+                              (bn && training && fuse_finalize() && whole) ? &fin : nullptr, o.i[6] > 1 ? &extra : nullptr, coef2,
+                              so ? &sumv : nullptr, stream);
         if (!rc && bn && h1 && !skip_tables && !deferred && !(training && fuse_finalize() && whole))
           rc = sep_finalize(fin, reinterpret_cast<const double*>(at(ws, o.ws[0])), training, stream, 0, (int)o.f[3]);
         break;

@@ -595,11 +595,37 @@ class PlanBuilder:
         # ---------------- forward
         if self.ar["zf"].size:
             fwd.append(mk(MEMSET, ws=(self.arena_base["zf"], self.ar["zf"].size)))
+        # Plans with a backward: a convolution that sums a lazy residual on load also WRITES the sum (lhn_pw_opts.sum_out) when
+        # the readers' channel slices cover the buffer -- the weight gradients of the backward then find it in memory and the
+        # re-materialising combine (which re-reads every operand) is not needed.  LHN_SUM_OUT=0: re-materialise.
+        self.sum_out = {}               # id(conv record) -> (byte offset of the sum's buffer, pixel stride * 65536 + channel)
+        self._sum_written = set()       # lazy buffers complete after the forward
+        if self.with_backward and os.environ.get("LHN_SUM_OUT", "1") != "0":
+            cover = {}
+            for r in self.recs:
+                if r["op"] not in (PW, DW) or isinstance(r["x"], TCat):
+                    continue
+                x = r["x"]
+                if self._xs(r)[1] < 2 or (r["op"] == PW and (x.C > 128 or r["out"].C > 128)):
+                    continue
+                spans = cover.setdefault(x.buf, [])
+                if any(a < x.coff + x.C and x.coff < b for a, b, _ in spans):
+                    continue
+                spans.append((x.coff, x.coff + x.C, r))
+            for b, spans in cover.items():
+                spans.sort(key=lambda t: t[0])
+                C = self.bufs[b].C
+                if spans[0][0] != 0 or spans[-1][1] != C or any(p[1] != q[0] for p, q in zip(spans, spans[1:])):
+                    continue
+                self._sum_written.add(b)
+                for lo, hi, r in spans:
+                    self.sum_out[id(r)] = (self.bufs[b].off["data"], C * 65536 + lo)
         for r in self.recs:
             k = r["op"]
             if k in (STEM, PW, DW, KXK):
                 conv, bn, x, out = r["conv"], r["bn"], r["x"], r["out"]
                 stats = self._abs(r.get("stats"))
+                so = self.sum_out.get(id(r), (-1, -1))
                 pw = self._p(conv.weight)
                 # a trailing BatchNorm rides on the conv op: the last workgroup of the conv finalizes the table
                 if bn is not None:
@@ -615,12 +641,13 @@ class PlanBuilder:
                 elif k == PW:
                     o = TRef(-1, 0, out.C, out.H, out.W) if r["nchw"] else out
                     xv, nx, cf = self._xs(r)
-                    fwd.append(mk(PW, ins=xv, out=o, p=(pw, self._p(conv.bias)) + pbn, ws=wsl,
+                    fwd.append(mk(PW, ins=xv, out=o, p=(pw, self._p(conv.bias)) + pbn, ws=(tuple(wsl) + (-1,) * 4)[:4] + so,
                                   i=(r["stride"], 1 if r["nchw"] else 0, r["wrc"][0], r["wrc"][1], r["stack"][0], r["stack"][1], nx),
                                   f=(tuple(fl) + (0.0,) * 4)[:4] + tuple(cf)))
                 elif k == DW:
                     xv, nx, cf = self._xs(r)
-                    fwd.append(mk(DW, ins=xv, out=out, p=(pw, cb) + pbn, ws=wsl, i=(r["k"], r["stride"], r["pad"], r["dil"], 0, 0, nx),
+                    fwd.append(mk(DW, ins=xv, out=out, p=(pw, cb) + pbn, ws=(tuple(wsl) + (-1,) * 4)[:4] + so,
+                                  i=(r["k"], r["stride"], r["pad"], r["dil"], 0, 0, nx),
                                   f=(tuple(fl) + (0.0,) * 4)[:4] + tuple(cf)))
                 else:
                     fwd.append(mk(KXK, ins=(x,), out=out, p=(pw, cb) + pbn, ws=(tuple(wsl) + (-1, -1, -1))[:3] + (self._abs(r["wt"]),),
@@ -781,7 +808,7 @@ class PlanBuilder:
                     pw = self._p(conv.weight)
                     use_coef = 1 if bn is not None else 0
                     lz = self.bufs[x.buf].lazy if x.buf >= 0 else None
-                    if lz is not None and x.buf not in materialised:
+                    if lz is not None and x.buf not in materialised and x.buf not in self._sum_written:
                         # the weight gradient needs the summed input: written once per backward, whole buffer
                         materialised.add(x.buf)
                         fl = lz["flat"]

@@ -132,11 +132,24 @@ def test_two_part_pass_through():
     assert not pb._needs_zero_grad
 
 
-def test_lazy_sums_are_summed_on_load():
+def test_lazy_sums_are_summed_on_load(monkeypatch):
     """MSRB's residual sums (litehourglass.py:41-49) and MSAB's `m + x` (liteHandNet.py:164) are not launched in forward:
-    their readers list the operands (2 for the depthwise 3x3, 3 with a doubled coefficient for the closing 1x1); the
-    backward list materialises each of them exactly once before the first reader's backward op."""
+    their readers list the operands (2 for the depthwise 3x3, 3 with a doubled coefficient for the closing 1x1).  In a plan
+    with a backward the readers also write the sum (lhn_pw_opts.sum_out; their slices tile the buffer) so the backward has
+    no combine to launch; with LHN_SUM_OUT=0 the backward list materialises each sum exactly once."""
     from litehandnet_amd.plan import DW, EW, PW
+    _, pb, _ = _build("B", backward=True)
+    cb, cf, cbw, nf, nb = pb.finalize()
+    fwd = [cf[i] for i in range(nf)]
+    writers = [o for o in fwd if o.kind in (DW, PW) and o.i[6] > 1]
+    assert len(writers) == 6 and all(o.ws[4] >= 0 for o in writers) and len(pb._sum_written) == 4
+    datas = {cb[j].data_off: j for j in pb._sum_written}
+    for o in writers:
+        j = datas[o.ws[4]]
+        assert o.ws[5] >> 16 == cb[j].C and (o.ws[5] & 0xffff) == o.in_coff[0]
+    assert not [cbw[i] for i in range(nb) if cbw[i].kind == EW]
+    assert not [o for o in fwd if o.ws[4] >= 0 and o.kind in (DW, PW) and o.i[6] <= 1]
+    monkeypatch.setenv("LHN_SUM_OUT", "0")
     _, pb, _ = _build("B", backward=True)
     lazy = [r for r in pb.recs if r["op"] == EW and r.get("lazy")]
     assert len(lazy) == 4                                           # 2 MSRBs x 2 rounds
