@@ -599,8 +599,11 @@ struct DwTile {
 template <int K, int DIL, int NS = 1>
 __global__ void __launch_bounds__(256) k_dwk_fwd_lds(lhn_view x, const float* __restrict__ w, lhn_view y,
                                                      double* __restrict__ stats, int tiles_h, int tiles_w, int cgroups,
-                                                     lhn_bnfin fin, int ps, DwExtra ex) {
+                                                     lhn_bnfin fin, int ps, DwExtra ex, int xchunk) {
   constexpr int TH = 8, TW = 32, KK = K * K;
+  // XCD-aware tile order: blocks are dealt round-robin over the 8 XCDs, so logical block (b % 8) * xchunk + b / 8 gives each
+  // XCD a CONTIGUOUS run of tiles -- neighbouring tiles (which share their halo rows / columns) then meet in one L2
+  const int bid = xchunk ? (int)(blockIdx.x & 7) * xchunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
   using T = DwTile<K, DIL, TH, TW>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   f4* tile = reinterpret_cast<f4*>(smem);                  // [PIX][8] float4
@@ -611,7 +614,7 @@ __global__ void __launch_bounds__(256) k_dwk_fwd_lds(lhn_view x, const float* __
   // dilation-1 convolutions on the parity sub-lattices (pixels (2i+a, 2j+b) only meet pixels of the same parity): the halo
   // shrinks from (TH+4)(TW+4) to (TH+2)(TW+2) and every pixel still is one contiguous 128-byte channel group.
   const int ntile = y.N * ps * ps * tiles_h * tiles_w * cgroups;
-  const int cg = blockIdx.x % cgroups;                     // grid % cgroups == 0 (host): fixed per block
+  const int cg = bid % cgroups;                            // grid % cgroups == 0 (host): fixed per block
   const int cin = x.coff + cg * 32 + 4 * c4, cout = y.coff + cg * 32 + 4 * c4;
   const int cin2 = NS > 1 ? ex.v.coff + cg * 32 + 4 * c4 : 0;
   Xf4 xf, xf2;        // filled after the first tile's loads have been issued (pending BatchNorms are finalized meanwhile)
@@ -663,7 +666,7 @@ __global__ void __launch_bounds__(256) k_dwk_fwd_lds(lhn_view x, const float* __
       raw2[it] = *reinterpret_cast<const f4*>(xin2 + ((size_t)min(ih, x.H - 1) * x.W + min(iw, x.W - 1)) * ex.v.cstride);
     }
   };
-  int t = blockIdx.x;
+  int t = bid;
   if (t < ntile) issue(t);
   // (the tile region is free until the first commit, which follows a barrier)
   xf = lhn_load_xf_t(lhn_resolve_table(x, ex.pend[0], smem), x.cstride, cin);
@@ -766,7 +769,7 @@ __global__ void __launch_bounds__(256) k_dwk_fwd_lds(lhn_view x, const float* __
   }
   if (stats) {
     const int C = x.C;
-    double* st = stats + (size_t)((blockIdx.x / cgroups) % LHN_STAT_REPLICAS) * 2 * C + cg * 32;
+    double* st = stats + (size_t)((bid / cgroups) % LHN_STAT_REPLICAS) * 2 * C + cg * 32;
     lhn_block_stat_atomics_d(sd, qd, 8, reinterpret_cast<double*>(red), st, st + C);
     if (fin.counter && lhn_last_block(fin.counter)) lhn_bn_finalize_block(fin, stats);
   }
@@ -793,8 +796,9 @@ struct DwBnSum {
 template <int K, int DIL, bool BNS = false>
 __global__ void __launch_bounds__(256) k_dwk_bwd_lds(lhn_view x, const float* __restrict__ w, lhn_view y, lhn_gradview gy,
                                                      float* __restrict__ dx, int dx_acc, float* __restrict__ dw, int tiles_h,
-                                                     int tiles_w, int cgroups, int nrep, int64_t rep_stride, int ps, DwBnSum bs) {
+                                                     int tiles_w, int cgroups, int nrep, int64_t rep_stride, int ps, DwBnSum bs, int xchunk) {
   constexpr int TH = 8, TW = 16, KK = K * K;
+  const int bid = xchunk ? (int)(blockIdx.x & 7) * xchunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;     // see k_dwk_fwd_lds
   constexpr bool REGACC = (K == 3);
   using T = DwTile<K, DIL, TH, TW>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -808,7 +812,7 @@ __global__ void __launch_bounds__(256) k_dwk_bwd_lds(lhn_view x, const float* __
   const int tid = threadIdx.x, c4 = tid & 7, pl = tid >> 3;
   const int colw = pl & 15, rpar = pl >> 4;
   const int ntile = y.N * ps * ps * tiles_h * tiles_w * cgroups;      // ps: see k_dwk_fwd_lds
-  const int cg = blockIdx.x % cgroups;
+  const int cg = bid % cgroups;
   const int cx = x.coff + cg * 32 + 4 * c4, cy = y.coff + cg * 32 + 4 * c4;
   const Xf4 xxf = lhn_load_xf(x, cx), yxf = lhn_load_xf(y, cy);
   const Gr4 ygr = lhn_load_coef(gy, y.cstride, cy);
@@ -825,7 +829,7 @@ __global__ void __launch_bounds__(256) k_dwk_bwd_lds(lhn_view x, const float* __
     const int kind = tid >> 3, cc = tid & 7;
     tmi[tid] = *reinterpret_cast<const f4*>(bs.save + kind * bs.C + bs.coff + cg * 32 + 4 * cc);
   }
-  for (int t = blockIdx.x; t < ntile; t += gridDim.x) {
+  for (int t = bid; t < ntile; t += gridDim.x) {
     int r = t / cgroups;
     const int tw = r % tiles_w;
     r /= tiles_w;
@@ -963,11 +967,11 @@ __global__ void __launch_bounds__(256) k_dwk_bwd_lds(lhn_view x, const float* __
     }
   }
   if (BNS) {           // BatchNorm-backward sums of the producer: same block reduction as the forward statistics
-    double* st = bs.sums + (size_t)((blockIdx.x / cgroups) % LHN_STAT_REPLICAS) * 2 * bs.C + bs.coff + cg * 32;
+    double* st = bs.sums + (size_t)((bid / cgroups) % LHN_STAT_REPLICAS) * 2 * bs.C + bs.coff + cg * 32;
     lhn_block_stat_atomics(sdu, sdux, 8, red, st, st + bs.C);
   }
   // ---- flush dW
-  float* dwr = dw + (size_t)((blockIdx.x / cgroups) % nrep) * rep_stride;
+  float* dwr = dw + (size_t)((bid / cgroups) % nrep) * rep_stride;
   if (REGACC) {
     // lanes of a wave that share c4 (lane bits 3..5 differ) meet by xor-shuffles, the four waves through LDS (the dy tile
     // is dead by now), then one thread per (tap, c4) adds four floats
@@ -1007,6 +1011,18 @@ __global__ void __launch_bounds__(256) k_dwk_bwd_lds(lhn_view x, const float* __
   }
 }
 
+// blocks per XCD when the XCD-aware tile order applies (grid a multiple of 8 and of 8 * cgroups), else 0 = plain order.
+// Measured on MI355X (variant B, bs64 256x256): giving each XCD a contiguous run of tiles is SLOWER than the plain
+// round-robin order -- forward 3.08 vs 2.93 ms, train step 9.66 vs 9.55 ms: the halo re-reads already hit the Infinity
+// Cache, while eight XCDs each streaming one contiguous region load the HBM channels less evenly.  Off unless LHN_XCD_ORDER=1.
+static int dw3_xchunk(int grid, int cgroups) {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("LHN_XCD_ORDER");
+    on = (e && e[0] == '1') ? 1 : 0;
+  }
+  return (on && grid % (8 * cgroups) == 0) ? grid / 8 : 0;
+}
 static int dw3_grid(int ntile, int cgroups, int per_cu) {
   int g = lhn_num_cus() * per_cu;
   g -= g % cgroups;
@@ -1028,7 +1044,8 @@ static void launch_dwk_fwd(const lhn_view* x, const float* w, const lhn_view* y,
   const int per_cu = lds > 80 * 1024 ? 1 : (lds > 52 * 1024 ? 2 : 3);
   static LhnKernelCfg cfg;
   (void)lhn_kernel_cfg(cfg, &k_dwk_fwd_lds<K, DIL, NS>, lds, 4, nullptr);
-  hipLaunchKernelGGL((k_dwk_fwd_lds<K, DIL, NS>), dim3(dw3_grid(ntile, cg, per_cu * 2)), dim3(256), lds, s, *x, w, *y, stats, th, tw, cg, fin, ps, ex);
+  const int grid = dw3_grid(ntile, cg, per_cu * 2);
+  hipLaunchKernelGGL((k_dwk_fwd_lds<K, DIL, NS>), dim3(grid), dim3(256), lds, s, *x, w, *y, stats, th, tw, cg, fin, ps, ex, dw3_xchunk(grid, cg));
 }
 template <int K, int DIL, bool BNS = false>
 static void launch_dwk_bwd(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx, int dx_acc,
@@ -1042,8 +1059,9 @@ static void launch_dwk_bwd(const lhn_view* x, const float* w, const lhn_view* y,
   const size_t lds = (size_t)((TH + 2 * P) * (TW + 2 * P) * 16 + 256 + 2 * K * K * 8 + (BNS ? TH * TW * 8 + 16 : 0)) * 16;
   static LhnKernelCfg cfg;
   (void)lhn_kernel_cfg(cfg, &k_dwk_bwd_lds<K, DIL, BNS>, lds, 4, nullptr);
-  hipLaunchKernelGGL((k_dwk_bwd_lds<K, DIL, BNS>), dim3(dw3_grid(ntile, cg, 4)), dim3(256), lds, s, *x, w, *y, *gy, dx, dx_acc, dw, th, tw,
-                     cg, nrep, rep_stride, ps, bs);
+  const int grid = dw3_grid(ntile, cg, 4);
+  hipLaunchKernelGGL((k_dwk_bwd_lds<K, DIL, BNS>), dim3(grid), dim3(256), lds, s, *x, w, *y, *gy, dx, dx_acc, dw, th, tw,
+                     cg, nrep, rep_stride, ps, bs, dw3_xchunk(grid, cg));
 }
 
 // returns 1 if an LDS-tiled kernel was launched
