@@ -356,7 +356,7 @@ int lhn_conv_dw_bwd2(const lhn_view* x, const float* w, const lhn_view* y, const
 /* ... and with up to two gradient ADDENDS: dx = [dx +] dgrad + dx_add0 + dx_add1, where dx_add* point at buffers of dx's
  * geometry (same pixel stride; the pointer already carries any channel shift).  They are the output gradients of residual
  * sums that read x (litehourglass.py:41-49: `out = out + ca(cat)`): the sum's backward costs no pass of its own.  Needs the
- * tiled kernel (stride 1, "same" padding, C % 32 == 0, W >= 8).  Both NULL: lhn_conv_dw_bwd. */
+ * tiled kernel (stride 1, "same" padding, W >= 8).  Both NULL: lhn_conv_dw_bwd. */
 int lhn_conv_dw_bwd3(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx, int dx_accumulate,
                      float* dw, int k, int stride, int pad, int dil, int nrep, int64_t rep_stride, const float* dx_add0,
                      const float* dx_add1, void* stream);

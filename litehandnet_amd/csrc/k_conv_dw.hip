@@ -237,7 +237,7 @@ extern "C" int lhn_conv_dw_fwd3(const lhn_view* x, const float* w, const lhn_vie
                              sum_out->cstride % 4 == 0 && sum_out->coff % 4 == 0 && sum_out->coff + sum_out->C <= sum_out->cstride),
                 "lhn_conv_dw_fwd3: sum_out geometry (same pixels and channels as x)");
   const int rc = dw_fwd_extra(x, w, y, stats, k, stride, pad, dil, fin, extra, coef2, sum_out, (hipStream_t)stream);
-  LHN_CHECK_ARG(rc == 1, "lhn_conv_dw_fwd2: a second source needs k=3, stride 1, 'same' padding, C %% 32 == 0, W >= 8 (got k=%d s=%d C=%d W=%d)",
+  LHN_CHECK_ARG(rc == 1, "lhn_conv_dw_fwd2: a second source needs k=3, stride 1, 'same' padding, W >= 8 (got k=%d s=%d C=%d W=%d)",
                 k, stride, x->C, y->W);
   LHN_CHECK_LAUNCH("lhn_conv_dw_fwd2");
   return 0;
@@ -267,7 +267,7 @@ extern "C" int lhn_conv_dw_fwd(const lhn_view* x, const float* w, const lhn_view
   ex0.pend[0] = px;
   ex0.pend[1].n = 0;
   ex0.sum_out = nullptr;
-  if (w && stride == 1 && pad == dil * (k - 1) / 2 && x->C % 32 == 0 && y->W >= 8 && !lhn_dw_force_gather() &&
+  if (w && stride == 1 && pad == dil * (k - 1) / 2 && x->C % 4 == 0 && y->W >= 8 && !lhn_dw_force_gather() &&
       lhn_dwk_fwd_lds(x, w, y, stats, k, dil, fin, s, &ex0)) {
   } else if (k == 3)
     hipLaunchKernelGGL((k_dw_fwd<3>), dim3(grid), dim3(256), lds, s, *x, w, *y, stats, stride, pad, dil, fin, px);
@@ -521,8 +521,8 @@ extern "C" int lhn_conv_dw_bwd3(const lhn_view* x, const float* w, const lhn_vie
   if (nrep < 1) nrep = 1;
   LHN_CHECK_ARG(lhn_view_ok(x) && lhn_view_ok(y) && gy && gy->dz && w && dw && dx && lhn_no_pend(x) && lhn_no_pend(y),
                 "lhn_conv_dw_bwd3: bad view / null pointer");
-  LHN_CHECK_ARG(stride == 1 && pad == dil * (k - 1) / 2 && x->C % 32 == 0 && x->W >= 8 && x->C == y->C,
-                "lhn_conv_dw_bwd3: gradient addends need the tiled stride-1 kernel (C %% 32 == 0, W >= 8)");
+  LHN_CHECK_ARG(stride == 1 && pad == dil * (k - 1) / 2 && x->C % 4 == 0 && x->W >= 8 && x->C == y->C,
+                "lhn_conv_dw_bwd3: gradient addends need the tiled stride-1 kernel (W >= 8)");
   const int rc = dw_bwd_addends(x, w, y, gy, dx, dx_accumulate, dw, k, dil, nrep, rep_stride, dx_add0 ? dx_add0 : dx_add1,
                                 dx_add0 ? dx_add1 : nullptr, (hipStream_t)stream);
   LHN_CHECK_ARG(rc == 1, "lhn_conv_dw_bwd3: no tiled kernel for k=%d dil=%d", k, dil);
@@ -538,7 +538,7 @@ extern "C" int lhn_conv_dw_bwd(const lhn_view* x, const float* w, const lhn_view
   LHN_CHECK_ARG(x->C == y->C && x->C % 4 == 0 && x->C <= 512, "lhn_conv_dw_bwd: channels");
   LHN_CHECK_ARG(k == 1 || k == 3 || k == 7, "lhn_conv_dw_bwd: k=%d (1, 3 or 7)", k);
   hipStream_t s = (hipStream_t)stream;
-  if (w && dw && stride == 1 && pad == dil * (k - 1) / 2 && x->C % 32 == 0 && x->W >= 8 && !lhn_dw_force_gather() &&
+  if (w && dw && stride == 1 && pad == dil * (k - 1) / 2 && x->C % 4 == 0 && x->W >= 8 && !lhn_dw_force_gather() &&
       lhn_dwk_bwd_lds(x, w, y, gy, dx, dx_accumulate, dw, k, dil, nrep, rep_stride, s, nullptr)) {
     LHN_CHECK_LAUNCH("lhn_conv_dw_bwd");
     return 0;
@@ -615,11 +615,16 @@ __global__ void __launch_bounds__(256) k_dwk_fwd_lds(lhn_view x, const float* __
   // shrinks from (TH+4)(TW+4) to (TH+2)(TW+2) and every pixel still is one contiguous 128-byte channel group.
   const int ntile = y.N * ps * ps * tiles_h * tiles_w * cgroups;
   const int cg = bid % cgroups;                            // grid % cgroups == 0 (host): fixed per block
-  const int cin = x.coff + cg * 32 + 4 * c4, cout = y.coff + cg * 32 + 4 * c4;
-  const int cin2 = NS > 1 ? ex.v.coff + cg * 32 + 4 * c4 : 0;
+  // C % 32 != 0 (lite_hrnet.py: 20 / 40 / 80 channels): the last group has cvalid < 8 float4 lanes; the others load the
+  // group's first lane again (valid memory) and neither store nor count
+  const int cvalid = min(8, (x.C - cg * 32) >> 2);
+  const bool cok = c4 < cvalid;
+  const int c4e = cok ? c4 : 0;
+  const int cin = x.coff + cg * 32 + 4 * c4e, cout = y.coff + cg * 32 + 4 * c4e;
+  const int cin2 = NS > 1 ? ex.v.coff + cg * 32 + 4 * c4e : 0;
   Xf4 xf, xf2;        // filled after the first tile's loads have been issued (pending BatchNorms are finalized meanwhile)
   for (int i = tid; i < KK * 8; i += 256) {
-    const int k = i >> 3, cc = cg * 32 + 4 * (i & 7);
+    const int k = i >> 3, cc = cg * 32 + 4 * min(i & 7, cvalid - 1);
     wl[i] = (f4){w[(cc + 0) * KK + k], w[(cc + 1) * KK + k], w[(cc + 2) * KK + k], w[(cc + 3) * KK + k]};
   }
   double sd[4] = {0, 0, 0, 0}, qd[4] = {0, 0, 0, 0};      // per-tile fp32 partials promoted to double (see k_conv_pw.hip)
@@ -701,7 +706,7 @@ __global__ void __launch_bounds__(256) k_dwk_fwd_lds(lhn_view x, const float* __
         f4 v = lhn_apply_xf(raw[it], xf) * gate;
         if (NS > 1) {
           v += lhn_apply_xf(raw2[it], xf2) * gate2;
-          if (ex.sum_out && inb && ph >= T::P && ph < T::P + TH && pw >= T::P && pw < T::P + TW)
+          if (ex.sum_out && cok && inb && ph >= T::P && ph < T::P + TH && pw >= T::P && pw < T::P + TW)
             *reinterpret_cast<f4*>(ex.sum_out + ((size_t)(n * x.H + pa + ps * ih) * x.W + pb + ps * iw) * ex.so_cstride + ex.so_coff +
                                    cg * 32 + 4 * c4) = v;
         }
@@ -713,7 +718,7 @@ __global__ void __launch_bounds__(256) k_dwk_fwd_lds(lhn_view x, const float* __
     const int wo = tw * TW + pl;
     f4 s = (f4){0.f, 0.f, 0.f, 0.f}, q = s, kk = s;      // shifted by the tile's first value (see TileStat)
     int cnt = 0;
-    if (wo < SW) {
+    if (wo < SW && cok) {
       const f4* col = tile + (pl + T::P) * 8 + c4;    // centre column of this thread, tile row 0
       float* yout = y.data + ((size_t)(n * y.H + pa + ps * th * TH) * y.W + pb + ps * wo) * y.cstride + cout;
       if (K == 3 && DIL == 1) {
@@ -770,7 +775,7 @@ __global__ void __launch_bounds__(256) k_dwk_fwd_lds(lhn_view x, const float* __
   if (stats) {
     const int C = x.C;
     double* st = stats + (size_t)((bid / cgroups) % LHN_STAT_REPLICAS) * 2 * C + cg * 32;
-    lhn_block_stat_atomics_d(sd, qd, 8, reinterpret_cast<double*>(red), st, st + C);
+    lhn_block_stat_atomics_d(sd, qd, 8, reinterpret_cast<double*>(red), st, st + C, cvalid);
     if (fin.counter && lhn_last_block(fin.counter)) lhn_bn_finalize_block(fin, stats);
   }
 }
@@ -813,11 +818,14 @@ __global__ void __launch_bounds__(256) k_dwk_bwd_lds(lhn_view x, const float* __
   const int colw = pl & 15, rpar = pl >> 4;
   const int ntile = y.N * ps * ps * tiles_h * tiles_w * cgroups;      // ps: see k_dwk_fwd_lds
   const int cg = bid % cgroups;
-  const int cx = x.coff + cg * 32 + 4 * c4, cy = y.coff + cg * 32 + 4 * c4;
+  const int cvalid = min(8, (x.C - cg * 32) >> 2);          // see k_dwk_fwd_lds
+  const bool cok = c4 < cvalid;
+  const int c4e = cok ? c4 : 0;
+  const int cx = x.coff + cg * 32 + 4 * c4e, cy = y.coff + cg * 32 + 4 * c4e;
   const Xf4 xxf = lhn_load_xf(x, cx), yxf = lhn_load_xf(y, cy);
   const Gr4 ygr = lhn_load_coef(gy, y.cstride, cy);
   for (int i = tid; i < KK * 8; i += 256) {
-    const int k = i >> 3, cc = cg * 32 + 4 * (i & 7);
+    const int k = i >> 3, cc = cg * 32 + 4 * min(i & 7, cvalid - 1);
     wl[i] = (f4){w[(cc + 0) * KK + k], w[(cc + 1) * KK + k], w[(cc + 2) * KK + k], w[(cc + 3) * KK + k]};
     if (!REGACC) dws[i] = (f4){0.f, 0.f, 0.f, 0.f};
   }
@@ -902,7 +910,7 @@ __global__ void __launch_bounds__(256) k_dwk_bwd_lds(lhn_view x, const float* __
             sdu += du;
             sdux += du * ((raw - tmi[c4]) * tmi[8 + c4]);
           }
-          if (dx) {
+          if (dx && cok) {
             float* o = dx + ((size_t)(n * x.H + pa + ps * hh) * x.W + pb + ps * wcol) * x.cstride + cx;
             if (dx_acc) accx += *reinterpret_cast<const f4*>(o);
             if (bs.add[0]) accx += *reinterpret_cast<const f4*>(bs.add[0] + (o - dx));
@@ -916,7 +924,7 @@ __global__ void __launch_bounds__(256) k_dwk_bwd_lds(lhn_view x, const float* __
       if (dx)
         for (int j = 0; j < TH / 2; ++j) {
           const int rr = 2 * j + rpar, hh = th * TH + rr;
-          if (wcol < SW && hh < SH) {
+          if (wcol < SW && hh < SH && cok) {
             const int centre = ((rr + T::P) * T::WW + colw + T::P) * 8 + c4;
             f4 accx = (f4){0.f, 0.f, 0.f, 0.f};
             for (int a = 0; a < K; ++a)
@@ -993,16 +1001,19 @@ __global__ void __launch_bounds__(256) k_dwk_bwd_lds(lhn_view x, const float* __
       const int k = tid >> 3, cc = tid & 7;
       const f4 sacc = tdy[(k * 4 + 0) * 8 + cc] + tdy[(k * 4 + 1) * 8 + cc] + tdy[(k * 4 + 2) * 8 + cc] + tdy[(k * 4 + 3) * 8 + cc];
       const int cb = cg * 32 + 4 * cc;
-      atomicAdd(dwr + (cb + 0) * KK + k, sacc.x);
-      atomicAdd(dwr + (cb + 1) * KK + k, sacc.y);
-      atomicAdd(dwr + (cb + 2) * KK + k, sacc.z);
-      atomicAdd(dwr + (cb + 3) * KK + k, sacc.w);
+      if (cc < cvalid) {
+        atomicAdd(dwr + (cb + 0) * KK + k, sacc.x);
+        atomicAdd(dwr + (cb + 1) * KK + k, sacc.y);
+        atomicAdd(dwr + (cb + 2) * KK + k, sacc.z);
+        atomicAdd(dwr + (cb + 3) * KK + k, sacc.w);
+      }
     }
   } else {
     __syncthreads();
     for (int i = tid; i < KK * 8; i += 256) {
       const int k = i >> 3, cb = cg * 32 + 4 * (i & 7);
       const f4 v = dws[i];
+      if ((i & 7) >= cvalid) continue;
       atomicAdd(dwr + (cb + 0) * KK + k, v.x);
       atomicAdd(dwr + (cb + 1) * KK + k, v.y);
       atomicAdd(dwr + (cb + 2) * KK + k, v.z);
@@ -1037,7 +1048,7 @@ static void launch_dwk_fwd(const lhn_view* x, const float* w, const lhn_view* y,
   DwExtra ex;
   if (exp) ex = *exp; else { ex.n = 0; ex.pend[0].n = ex.pend[1].n = 0; ex.sum_out = nullptr; }
   constexpr int TH = 8, TW = 32, P = DIL * (K - 1) / 2;
-  const int cg = x->C / 32;
+  const int cg = (x->C + 31) / 32;
   const int sh = (y->H + ps - 1) / ps, sw = (y->W + ps - 1) / ps;       // largest parity sub-lattice
   const int th = (sh + TH - 1) / TH, tw = (sw + TW - 1) / TW, ntile = y->N * ps * ps * th * tw * cg;
   const size_t lds = (size_t)((TH + 2 * P) * (TW + 2 * P) * 8 + 512 + K * K * 8) * 16;
@@ -1053,7 +1064,7 @@ static void launch_dwk_bwd(const lhn_view* x, const float* w, const lhn_view* y,
   constexpr int TH = 8, TW = 16, P = DIL * (K - 1) / 2;
   DwBnSum bs;
   if (bsp) bs = *bsp; else { bs.sums = nullptr; bs.save = nullptr; bs.C = bs.coff = 0; bs.add[0] = bs.add[1] = nullptr; }
-  const int cg = x->C / 32;
+  const int cg = (x->C + 31) / 32;
   const int sh = (x->H + ps - 1) / ps, sw = (x->W + ps - 1) / ps;
   const int th = (sh + TH - 1) / TH, tw = (sw + TW - 1) / TW, ntile = x->N * ps * ps * th * tw * cg;
   const size_t lds = (size_t)((TH + 2 * P) * (TW + 2 * P) * 16 + 256 + 2 * K * K * 8 + (BNS ? TH * TW * 8 + 16 : 0)) * 16;
@@ -1097,7 +1108,7 @@ int lhn_dwk_bwd_lds(const lhn_view* x, const float* w, const lhn_view* y, const 
 
 static int dw_fwd_extra(const lhn_view* x, const float* w, const lhn_view* y, double* stats, int k, int stride, int pad, int dil,
                         lhn_bnfin fin, const lhn_view* extra, const float* coef, const lhn_view* so, hipStream_t s) {
-  if (!(stride == 1 && pad == dil * (k - 1) / 2 && x->C % 32 == 0 && y->W >= 8)) return 0;
+  if (!(stride == 1 && pad == dil * (k - 1) / 2 && x->C % 4 == 0 && y->W >= 8)) return 0;
   if (!lhn_pend_ok(x) || !lhn_pend_ok(extra)) return 0;
   DwExtra ex;
   ex.v = *extra;

@@ -310,7 +310,7 @@ static __device__ __forceinline__ lhn_bnfin lhn_nofin() {
 // C4 in {8, 16, 32}: lanes of a wave that share c4 meet by xor-shuffles, the four waves through `red` (>= 8*C4 float4 of
 // LDS that nobody else is using), then 8*C4 threads add one double each into st0[4*c4+j] (sums) / st1[4*c4+j] (second sums).
 // Replaces a C4-thread serial loop over 256/C4 LDS rows that cost 4-10 us per launch.
-__device__ __forceinline__ void lhn_block_stat_atomics(f4 s, f4 q, int C4, f4* red, double* st0, double* st1) {
+__device__ __forceinline__ void lhn_block_stat_atomics(f4 s, f4 q, int C4, f4* red, double* st0, double* st1, int nvalid = 64) {
   for (int o = C4; o < 64; o <<= 1) {
     s.x += __shfl_xor(s.x, o, 64); s.y += __shfl_xor(s.y, o, 64); s.z += __shfl_xor(s.z, o, 64); s.w += __shfl_xor(s.w, o, 64);
     q.x += __shfl_xor(q.x, o, 64); q.y += __shfl_xor(q.y, o, 64); q.z += __shfl_xor(q.z, o, 64); q.w += __shfl_xor(q.w, o, 64);
@@ -330,7 +330,7 @@ __device__ __forceinline__ void lhn_block_stat_atomics(f4 s, f4 q, int C4, f4* r
       const f4 a = red[(wv * C4 + cc) * 2 + kind];
       v += (double)(jj == 0 ? a.x : jj == 1 ? a.y : jj == 2 ? a.z : a.w);
     }
-    atomicAdd((kind ? st1 : st0) + 4 * cc + jj, v);
+    if (cc < nvalid) atomicAdd((kind ? st1 : st0) + 4 * cc + jj, v);      // nvalid: channel groups that exist (tail of C % 32)
   }
 }
 
@@ -468,7 +468,7 @@ __device__ __forceinline__ void lhn_unshift4(double (&sd)[4], double (&qd)[4], f
 // The same reduction for DOUBLE per-thread sums (convolution epilogues promote their per-tile fp32 partials to double: a
 // running fp32 sum of squares over thousands of pixels loses the variance when |mean| >> sigma).  red: >= 32*C4 doubles.
 __device__ __forceinline__ void lhn_block_stat_atomics_d(const double (&s)[4], const double (&q)[4], int C4, double* red,
-                                                         double* st0, double* st1) {
+                                                         double* st0, double* st1, int nvalid = 64) {
   double v[8] = {s[0], s[1], s[2], s[3], q[0], q[1], q[2], q[3]};
   for (int o = C4; o < 64; o <<= 1) {
 #pragma unroll
@@ -486,7 +486,7 @@ __device__ __forceinline__ void lhn_block_stat_atomics_d(const double (&s)[4], c
     double t = 0;
 #pragma unroll
     for (int wv = 0; wv < 4; ++wv) t += red[(wv * C4 + cc) * 8 + kind * 4 + jj];
-    atomicAdd((kind ? st1 : st0) + 4 * cc + jj, t);
+    if (cc < nvalid) atomicAdd((kind ? st1 : st0) + 4 * cc + jj, t);
   }
 }
 

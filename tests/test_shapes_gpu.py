@@ -22,6 +22,10 @@ CASES = [
     (32, 32, 3, 1, 2, 2, 32, "lrelu", 1, 17, 33),
     (32, 32, 3, 2, 1, 1, 32, None, 2, 15, 15),
     (128, 128, 3, 1, 1, 1, 128, "lrelu", 2, 8, 40),
+    (20, 20, 3, 1, 1, 1, 20, None, 2, 9, 11),             # channel tails of the tiled depthwise kernels (C % 32 != 0)
+    (40, 40, 3, 1, 2, 2, 40, "lrelu", 1, 17, 33),
+    (72, 72, 3, 1, 1, 1, 72, "lrelu", 3, 8, 8),
+    (36, 36, 3, 1, 2, 2, 36, None, 2, 10, 12),
     (32, 32, 3, 1, 1, 1, 1, "lrelu", 3, 6, 10),
     (64, 64, 3, 1, 1, 1, 1, None, 2, 9, 9),
     (128, 128, 3, 1, 1, 1, 1, "lrelu", 1, 5, 5),
