@@ -184,6 +184,109 @@ __global__ void __launch_bounds__(256) k_stem_fwd(const float* __restrict__ img,
   }
 }
 
+
+// ------------------------------------------------------------------ stem forward, 3x3 -> 32 features (the stems of
+// litehourglass.py / liteHandNet.py / lite_hrnet.py).  thread = one output pixel, ALL 32 features: the 27 image taps are
+// loaded once per pixel (the generic kernel above loads them once per 8 features) and every tap meets its 32 weights as
+// eight LDS-broadcast float4 (same address in every lane) feeding packed fp32 FMAs.  Statistics: shifted by the block's
+// first pixel (see TileStat), reduced in the shifted domain, un-shifted in double once per block.
+template <int CO>
+__global__ void __launch_bounds__(256) k_stem3_fwd(const float* __restrict__ img, const float* __restrict__ w, lhn_view y,
+                                                   double* __restrict__ stats, int Hi, int Wi, int stride, int pad, lhn_bnfin fin) {
+  constexpr int C4 = CO / 4, T = 27;
+  __shared__ f4 Ws[T][C4];
+  __shared__ f4 kks[C4];
+  __shared__ float red[4][2 * CO];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < T * CO; i += 256) {
+    const int co = i / T, t = i - co * T;
+    reinterpret_cast<float*>(Ws)[t * CO + co] = w[i];
+  }
+  __syncthreads();
+  const int64_t total = (int64_t)y.N * y.H * y.W;
+  const int iters = (int)((total + (int64_t)gridDim.x * 256 - 1) / ((int64_t)gridDim.x * 256));      // uniform trip count
+  f4 s[C4], q[C4];
+#pragma unroll
+  for (int j = 0; j < C4; ++j) s[j] = q[j] = (f4){0.f, 0.f, 0.f, 0.f};
+  int64_t nvalid = 0;                                                  // pixels of this BLOCK (uniform)
+  for (int it = 0; it < iters; ++it) {
+    const int64_t base = ((int64_t)it * gridDim.x + blockIdx.x) * 256;
+    nvalid += base >= total ? 0 : (total - base < 256 ? total - base : 256);
+    const int64_t pix = base + tid;
+    const bool ok = pix < total;
+    const int64_t pc = ok ? pix : total - 1;
+    const int wo = (int)(pc % y.W);
+    const int64_t r = pc / y.W;
+    const int ho = (int)(r % y.H), n = (int)(r / y.H);
+    f4 acc[C4];
+#pragma unroll
+    for (int j = 0; j < C4; ++j) acc[j] = (f4){0.f, 0.f, 0.f, 0.f};
+    // (c, kh) as a real loop: fully unrolled, the scheduler issues all 216 weight reads up front and spills 1.9 KB per lane
+#pragma unroll 1
+    for (int ckh = 0; ckh < 9; ++ckh) {
+      const int c = ckh / 3, kh = ckh - 3 * c;
+      const float* plane = img + ((int64_t)n * 3 + c) * Hi * Wi;
+      const int ih = ho * stride - pad + kh;
+      const int ihc = min(max(ih, 0), Hi - 1);
+      float v[3];
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int iw = wo * stride - pad + kw;
+        const int iwc = min(max(iw, 0), Wi - 1);
+        const float t = plane[(int64_t)ihc * Wi + iwc];
+        v[kw] = (ih == ihc && iw == iwc) ? t : 0.f;
+      }
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const f4 v4 = (f4){v[kw], v[kw], v[kw], v[kw]};
+#pragma unroll
+        for (int j = 0; j < C4; ++j) acc[j] += v4 * Ws[ckh * 3 + kw][j];
+      }
+    }
+    if (it == 0) {               // block-common shift: the first pixel's features (pixel blockIdx.x * 256 exists: grid <= tiles)
+      if (tid == 0)
+#pragma unroll
+        for (int j = 0; j < C4; ++j) kks[j] = acc[j];
+      __syncthreads();
+    }
+    if (ok) {
+      float* o = y.data + pix * y.cstride + y.coff;
+#pragma unroll
+      for (int j = 0; j < C4; ++j) {
+        *reinterpret_cast<f4*>(o + 4 * j) = acc[j];
+        const f4 d = acc[j] - kks[j];
+        s[j] += d;
+        q[j] += d * d;
+      }
+    }
+  }
+  if (stats) {
+#pragma unroll
+    for (int j = 0; j < C4; ++j)
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        s[j].x += __shfl_xor(s[j].x, o, 64); s[j].y += __shfl_xor(s[j].y, o, 64); s[j].z += __shfl_xor(s[j].z, o, 64); s[j].w += __shfl_xor(s[j].w, o, 64);
+        q[j].x += __shfl_xor(q[j].x, o, 64); q[j].y += __shfl_xor(q[j].y, o, 64); q[j].z += __shfl_xor(q[j].z, o, 64); q[j].w += __shfl_xor(q[j].w, o, 64);
+      }
+    if (lane == 0)
+#pragma unroll
+      for (int j = 0; j < C4; ++j) {
+        *reinterpret_cast<f4*>(&red[wave][4 * j]) = s[j];
+        *reinterpret_cast<f4*>(&red[wave][CO + 4 * j]) = q[j];
+      }
+    __syncthreads();
+    if (tid < CO) {
+      const double S = (double)red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+      const double Q = (double)red[0][CO + tid] + red[1][CO + tid] + red[2][CO + tid] + red[3][CO + tid];
+      const double k0 = (double)reinterpret_cast<const float*>(kks)[tid], cnt = (double)nvalid;
+      double* st = stats + (size_t)(blockIdx.x % LHN_STAT_REPLICAS) * 2 * CO;
+      atomicAdd(st + tid, S + cnt * k0);
+      atomicAdd(st + CO + tid, Q + 2.0 * k0 * S + cnt * k0 * k0);
+    }
+    if (fin.counter && lhn_last_block(fin.counter)) lhn_bn_finalize_block(fin, stats);
+  }
+}
+
 static inline int grid_for(int64_t items_per_block_total, int per_block, int cap_per_cu) {
   int64_t g = (items_per_block_total + per_block - 1) / per_block;
   const int64_t cap = (int64_t)lhn_num_cus() * cap_per_cu;
@@ -292,8 +395,12 @@ extern "C" int lhn_conv_stem_fwd(const float* img, const float* w, const lhn_vie
   LHN_CHECK_ARG(y->H == Ho && y->W == Wo, "lhn_conv_stem_fwd: output %dx%d, expected %dx%d", y->H, y->W, Ho, Wo);
   const int PL = 256 / (y->C / 8);
   const size_t lds = (size_t)(3 * k * k * y->C) * 4 + 256 * 16 * 4;
-  hipLaunchKernelGGL(k_stem_fwd, dim3(grid_for((int64_t)y->N * Ho * Wo, PL, 8)), dim3(256), lds, (hipStream_t)stream, img,
-                     w, *y, stats, Hi, Wi, k, stride, pad, fin);
+  if (k == 3 && y->C == 32 && !lhn_dw_force_gather())
+    hipLaunchKernelGGL((k_stem3_fwd<32>), dim3(grid_for((int64_t)y->N * Ho * Wo, 256, 4)), dim3(256), 0, (hipStream_t)stream, img, w, *y,
+                       stats, Hi, Wi, stride, pad, fin);
+  else
+    hipLaunchKernelGGL(k_stem_fwd, dim3(grid_for((int64_t)y->N * Ho * Wo, PL, 8)), dim3(256), lds, (hipStream_t)stream, img,
+                       w, *y, stats, Hi, Wi, k, stride, pad, fin);
   LHN_CHECK_LAUNCH("lhn_conv_stem_fwd");
   return 0;
 }
@@ -492,6 +599,87 @@ __global__ void __launch_bounds__(256) k_stem_bwd(const float* __restrict__ img,
   }
 }
 
+
+// ------------------------------------------------------------------ stem weight gradient, 3x3 -> 32 features, on MFMA:
+// dW[co][tap] = sum_pixels dy[pixel][co] * patch[pixel][tap] is a (32 x 27) = dY^T (32 x P) * V (P x 27) GEMM with the
+// pixels as K.  Per 256-pixel tile the block parks dy (formed on the fly from dz, raw y and the BatchNorm-backward
+// coefficients) and the im2col patch (27 taps, padded to 32 zero columns) in LDS; every wave then runs 32
+// v_mfma_f32_32x32x2_f32 over its 64 pixels into one 32x32 accumulator that lives across the whole launch.
+__global__ void __launch_bounds__(256) k_stem3_bwd_mfma(const float* __restrict__ img, lhn_view y, lhn_gradview gy, float* __restrict__ dw,
+                                                        int Hi, int Wi, int stride, int pad, int nrep, int64_t rep_stride) {
+  constexpr int CO = 32, LDY = CO + 4, LDV = 33;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* dYs = smem;                     // [256][LDY] pixel-major dy; reused for the final cross-wave sum (4096 floats)
+  float* Vs = smem + 256 * LDY;          // [256][LDV] pixel-major patch, columns 27..31 stay zero
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int c4 = tid & 7, prow = tid >> 3;
+  const int cy = y.coff + 4 * c4;
+  const Xf4 yxf = lhn_load_xf(y, cy);
+  const Gr4 ygr = lhn_load_coef(gy, y.cstride, cy);
+  for (int t = 27; t < 32; ++t) Vs[tid * LDV + t] = 0.f;
+  f16v acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int64_t total = (int64_t)y.N * y.H * y.W;
+  const int64_t ntiles = (total + 255) / 256;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    __syncthreads();                       // the previous tile's MFMA reads are done
+    // dy rows: thread = (4 features, pixel prow + 32 j)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int p = prow + 32 * j;
+      const int64_t pix = tile * 256 + p;
+      f4 v = (f4){0.f, 0.f, 0.f, 0.f};
+      if (pix < total) {
+        const int wo = (int)(pix % y.W);
+        const int64_t r = pix / y.W;
+        v = dw_load_dy(y, gy, yxf, ygr, pix, (int)(r / y.H), (int)(r % y.H), wo, cy);
+      }
+      *reinterpret_cast<f4*>(dYs + p * LDY + 4 * c4) = v;
+    }
+    // patch rows: thread = pixel
+    {
+      const int64_t pix = tile * 256 + tid;
+      const int64_t pc = pix < total ? pix : total - 1;
+      const int wo = (int)(pc % y.W);
+      const int64_t r = pc / y.W;
+      const int ho = (int)(r % y.H), n = (int)(r / y.H);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float* plane = img + ((int64_t)n * 3 + c) * Hi * Wi;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+          const int ih = ho * stride - pad + kh, ihc = min(max(ih, 0), Hi - 1);
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const int iw = wo * stride - pad + kw, iwc = min(max(iw, 0), Wi - 1);
+            const float v = plane[(int64_t)ihc * Wi + iwc];
+            Vs[tid * LDV + c * 9 + kh * 3 + kw] = (ih == ihc && iw == iwc) ? v : 0.f;      // (rows past the end meet dy = 0)
+          }
+        }
+      }
+    }
+    __syncthreads();
+    const float* ar = dYs + (wave * 64 + lh) * LDY + l31;
+    const float* br = Vs + (wave * 64 + lh) * LDV + l31;
+#pragma unroll 8
+    for (int ks = 0; ks < 32; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[2 * ks * LDY], br[2 * ks * LDV], acc, 0, 0, 0);
+  }
+  // cross-wave sum through LDS, then one float atomic per weight into this block's gradient replica
+  __syncthreads();
+  float* part = dYs;                                 // [4][16][64]
+#pragma unroll
+  for (int r = 0; r < 16; ++r) part[(wave * 16 + r) * 64 + lane] = acc[r];
+  __syncthreads();
+  dw += (size_t)(blockIdx.x % nrep) * rep_stride;
+  for (int i = tid; i < CO * 27; i += 256) {
+    const int co = i / 27, t = i - co * 27;
+    const int r = (co & 3) + 4 * (co >> 3), ln = t + 32 * ((co >> 2) & 1);      // accumulator row co = (r & 3) + 8 (r >> 2) + 4 lh
+    const float v = part[(0 * 16 + r) * 64 + ln] + part[(1 * 16 + r) * 64 + ln] + part[(2 * 16 + r) * 64 + ln] + part[(3 * 16 + r) * 64 + ln];
+    atomicAdd(dw + i, v);
+  }
+}
+
 static int dw_bwd_fused(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx, float* dw, int k,
                         int dil, int nrep, int64_t rep_stride, double* bn_sums, const float* bn_save, int bn_C, int bn_coff, hipStream_t s);
 
@@ -575,7 +763,19 @@ extern "C" int lhn_conv_stem_bwd(const float* img, const lhn_view* y, const lhn_
   LHN_CHECK_ARG(pow2(y->C / 4) && y->C <= 256 && (k == 1 || k == 3 || k == 7), "lhn_conv_stem_bwd: Cout=%d k=%d", y->C, k);
   const int PL = 256 / (y->C / 4);
   const int g = grid_for((int64_t)y->N * y->H * y->W, PL, 4);
-  if (k == 3)
+  if (k == 3 && y->C == 32 && !lhn_dw_force_gather()) {
+    const size_t lds = (size_t)256 * (36 + 33) * 4;
+    static LhnKernelCfg cfg;
+    int per_cu = 1;
+    if (!lhn_kernel_cfg(cfg, &k_stem3_bwd_mfma, lds, 2, &per_cu)) {
+      lhn_set_error("lhn_conv_stem_bwd: cannot reserve %zu B of LDS", lds);
+      return 2;
+    }
+    const int64_t ntiles = ((int64_t)y->N * y->H * y->W + 255) / 256;
+    int grid = lhn_num_cus() * per_cu;
+    if (grid > ntiles) grid = (int)ntiles;
+    hipLaunchKernelGGL(k_stem3_bwd_mfma, dim3(grid), dim3(256), lds, (hipStream_t)stream, img, *y, *gy, dw, Hi, Wi, stride, pad, nrep, rep_stride);
+  } else if (k == 3)
     hipLaunchKernelGGL((k_stem_bwd<3, 3>), dim3(g), dim3(256), 0, (hipStream_t)stream, img, *y, *gy, dw, Hi, Wi, stride, pad, nrep, rep_stride, 0);
   else if (k == 1)
     hipLaunchKernelGGL((k_stem_bwd<1, 1>), dim3(g), dim3(256), 0, (hipStream_t)stream, img, *y, *gy, dw, Hi, Wi, stride, pad, nrep, rep_stride, 0);

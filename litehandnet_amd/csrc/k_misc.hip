@@ -357,6 +357,27 @@ __global__ void __launch_bounds__(256) k_avgpool_fwd(lhn_view x, float* __restri
     *reinterpret_cast<f4*>(out + (int64_t)b * ostride + ocoff + 4 * threadIdx.x) = t * inv;
   }
 }
+// Small bins (<= 16 pixels: the 2x2 / 4x4 bins of lite_hrnet.py:56-60, every branch pooled to the smallest map): one THREAD
+// per (bin, 4 channels) instead of one workgroup per bin -- 65,536 workgroups of 4 pixels each took 121 us for a 42 MB map.
+__global__ void __launch_bounds__(256) k_avgpool_small(lhn_view x, float* __restrict__ out, int OH, int OW, int ostride, int ocoff) {
+  const int C4 = x.C >> 2;
+  const int64_t total = (int64_t)x.N * OH * OW * C4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c4 = (int)(i % C4);
+    const int64_t b = i / C4;
+    const int ow = (int)(b % OW), oh = (int)((b / OW) % OH), n = (int)(b / ((int64_t)OW * OH));
+    const int h0 = (oh * x.H) / OH, h1 = ((oh + 1) * x.H + OH - 1) / OH;
+    const int w0 = (ow * x.W) / OW, w1 = ((ow + 1) * x.W + OW - 1) / OW;
+    const int ca = x.coff + 4 * c4;
+    const Xf4 xf = lhn_load_xf(x, ca);
+    f4 s = (f4){0.f, 0.f, 0.f, 0.f};
+    for (int h = h0; h < h1; ++h)
+      for (int w = w0; w < w1; ++w)
+        s += lhn_apply_xf(*reinterpret_cast<const f4*>(x.data + ((int64_t)(n * x.H + h) * x.W + w) * x.cstride + ca), xf);
+    if (x.gate) s *= *reinterpret_cast<const f4*>(x.gate + (int64_t)n * x.cstride + ca);
+    *reinterpret_cast<f4*>(out + b * ostride + ocoff + 4 * c4) = s * (1.f / (float)((h1 - h0) * (w1 - w0)));
+  }
+}
 // d(value of x) (+)= sum over bins containing the pixel of dout[bin]/|bin|
 __global__ void __launch_bounds__(256) k_avgpool_bwd(lhn_view x, const float* __restrict__ dout, int OH, int OW,
                                                      float* __restrict__ dx, int accumulate, int ostride, int ocoff) {
@@ -862,7 +883,12 @@ int lhn_avgpool_fwd2(const lhn_view* x, float* out, int OH, int OW, int out_cstr
                 "lhn_avgpool_fwd: bad args");
   LHN_CHECK_ARG(x->C % 4 == 0 && x->C <= 1024, "lhn_avgpool_fwd: C=%d", x->C);
   LHN_CHECK_ARG(lhn_pend_ok(x), "lhn_avgpool_fwd: bad pending BatchNorm");
-  hipLaunchKernelGGL(k_avgpool_fwd, dim3(x->N * OH * OW), dim3(256), 0, (hipStream_t)stream, *x, out, OH, OW, lhn_pends_of(x), out_cstride, out_coff);
+  const int binmax = ((x->H + OH - 1) / OH + 1) * ((x->W + OW - 1) / OW + 1);
+  if (!x->pend && binmax <= 25) {          // bins of at most 4x4 (+1: adaptive bins may overlap by a pixel)
+    const int64_t total = (int64_t)x->N * OH * OW * (x->C / 4);
+    hipLaunchKernelGGL(k_avgpool_small, dim3(grid_cap((total + 255) / 256, 16)), dim3(256), 0, (hipStream_t)stream, *x, out, OH, OW, out_cstride, out_coff);
+  } else
+    hipLaunchKernelGGL(k_avgpool_fwd, dim3(x->N * OH * OW), dim3(256), 0, (hipStream_t)stream, *x, out, OH, OW, lhn_pends_of(x), out_cstride, out_coff);
   LHN_CHECK_LAUNCH("lhn_avgpool_fwd");
   return 0;
 }
