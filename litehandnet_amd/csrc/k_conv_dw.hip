@@ -186,102 +186,99 @@ __global__ void __launch_bounds__(256) k_stem_fwd(const float* __restrict__ img,
 
 
 // ------------------------------------------------------------------ stem forward, 3x3 -> 32 features (the stems of
-// litehourglass.py / liteHandNet.py / lite_hrnet.py).  thread = one output pixel, ALL 32 features: the 27 image taps are
-// loaded once per pixel (the generic kernel above loads them once per 8 features) and every tap meets its 32 weights as
-// eight LDS-broadcast float4 (same address in every lane) feeding packed fp32 FMAs.  Statistics: shifted by the block's
-// first pixel (see TileStat), reduced in the shifted domain, un-shifted in double once per block.
-template <int CO>
-__global__ void __launch_bounds__(256) k_stem3_fwd(const float* __restrict__ img, const float* __restrict__ w, lhn_view y,
-                                                   double* __restrict__ stats, int Hi, int Wi, int stride, int pad, lhn_bnfin fin) {
-  constexpr int C4 = CO / 4, T = 27;
-  __shared__ f4 Ws[T][C4];
-  __shared__ f4 kks[C4];
-  __shared__ float red[4][2 * CO];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int i = tid; i < T * CO; i += 256) {
-    const int co = i / T, t = i - co * T;
-    reinterpret_cast<float*>(Ws)[t * CO + co] = w[i];
-  }
-  __syncthreads();
-  const int64_t total = (int64_t)y.N * y.H * y.W;
-  const int iters = (int)((total + (int64_t)gridDim.x * 256 - 1) / ((int64_t)gridDim.x * 256));      // uniform trip count
-  f4 s[C4], q[C4];
+// litehourglass.py / liteHandNet.py / lite_hrnet.py) on MFMA: out[pixel][co] = patch[pixel][27 taps] * W^T is a GEMM with
+// K = 27 (padded to 32).  The block parks the im2col patch of a 256-pixel tile in LDS (thread = pixel: its 27 image taps are
+// loaded ONCE; the direct kernel k_stem_fwd re-reads them per group of 8 features and is bound by 216 LDS weight reads per
+// pixel: 125 us for a 184 MB problem); every wave holds all weights as 16 MFMA B registers and runs 2 x 16
+// v_mfma_f32_32x32x2_f32 over its 64 pixels.  The accumulator layout gives each lane ONE feature: stores are 128-byte rows,
+// statistics need no cross-lane work beyond the two lane halves.  The next tile's taps are loaded while this one computes.
+__global__ void __launch_bounds__(256) k_stem3_fwd_mfma(const float* __restrict__ img, const float* __restrict__ w, lhn_view y,
+                                                        double* __restrict__ stats, int Hi, int Wi, int stride, int pad, lhn_bnfin fin) {
+  constexpr int CO = 32, LDV = 36;
+  __shared__ __attribute__((aligned(16))) float Vs[256 * LDV];      // [pixel][tap], columns 27..31 stay zero
+  __shared__ double redd[4][2 * CO];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  // B fragments: MFMA step ks, lane (n = l31, k = lh) holds W[tap = 16 lh + ks][co = l31]  (the A reads use the same K order)
+  float wreg[16];
 #pragma unroll
-  for (int j = 0; j < C4; ++j) s[j] = q[j] = (f4){0.f, 0.f, 0.f, 0.f};
-  int64_t nvalid = 0;                                                  // pixels of this BLOCK (uniform)
-  for (int it = 0; it < iters; ++it) {
-    const int64_t base = ((int64_t)it * gridDim.x + blockIdx.x) * 256;
-    nvalid += base >= total ? 0 : (total - base < 256 ? total - base : 256);
-    const int64_t pix = base + tid;
-    const bool ok = pix < total;
-    const int64_t pc = ok ? pix : total - 1;
+  for (int ks = 0; ks < 16; ++ks) {
+    const int tap = 16 * lh + ks;
+    wreg[ks] = tap < 27 ? w[l31 * 27 + tap] : 0.f;
+  }
+  for (int t = 27; t < 32; ++t) Vs[tid * LDV + t] = 0.f;
+  const int64_t total = (int64_t)y.N * y.H * y.W;
+  const int64_t ntiles = (total + 255) / 256;
+  float v[27];
+  auto issue = [&](int64_t tile) __attribute__((always_inline)) {
+    const int64_t pix = tile * 256 + tid;
+    const int64_t pc = pix < total ? pix : total - 1;
     const int wo = (int)(pc % y.W);
     const int64_t r = pc / y.W;
     const int ho = (int)(r % y.H), n = (int)(r / y.H);
-    f4 acc[C4];
 #pragma unroll
-    for (int j = 0; j < C4; ++j) acc[j] = (f4){0.f, 0.f, 0.f, 0.f};
-    // (c, kh) as a real loop: fully unrolled, the scheduler issues all 216 weight reads up front and spills 1.9 KB per lane
-#pragma unroll 1
-    for (int ckh = 0; ckh < 9; ++ckh) {
-      const int c = ckh / 3, kh = ckh - 3 * c;
+    for (int c = 0; c < 3; ++c) {
       const float* plane = img + ((int64_t)n * 3 + c) * Hi * Wi;
-      const int ih = ho * stride - pad + kh;
-      const int ihc = min(max(ih, 0), Hi - 1);
-      float v[3];
 #pragma unroll
-      for (int kw = 0; kw < 3; ++kw) {
-        const int iw = wo * stride - pad + kw;
-        const int iwc = min(max(iw, 0), Wi - 1);
-        const float t = plane[(int64_t)ihc * Wi + iwc];
-        v[kw] = (ih == ihc && iw == iwc) ? t : 0.f;
-      }
+      for (int kh = 0; kh < 3; ++kh) {
+        const int ih = ho * stride - pad + kh, ihc = min(max(ih, 0), Hi - 1);
 #pragma unroll
-      for (int kw = 0; kw < 3; ++kw) {
-        const f4 v4 = (f4){v[kw], v[kw], v[kw], v[kw]};
-#pragma unroll
-        for (int j = 0; j < C4; ++j) acc[j] += v4 * Ws[ckh * 3 + kw][j];
+        for (int kw = 0; kw < 3; ++kw) {
+          const int iw = wo * stride - pad + kw, iwc = min(max(iw, 0), Wi - 1);
+          const float t = plane[(int64_t)ihc * Wi + iwc];
+          v[c * 9 + kh * 3 + kw] = (ih == ihc && iw == iwc) ? t : 0.f;
+        }
       }
     }
-    if (it == 0) {               // block-common shift: the first pixel's features (pixel blockIdx.x * 256 exists: grid <= tiles)
-      if (tid == 0)
+  };
+  float s = 0.f, q = 0.f, kk = 0.f;      // this lane's feature: shifted sums over its pixels (see TileStat)
+  int cnt = 0;
+  int64_t tile = blockIdx.x;
+  if (tile < ntiles) issue(tile);
+  for (; tile < ntiles; tile += gridDim.x) {
+    __syncthreads();                       // the previous tile's A reads are done
 #pragma unroll
-        for (int j = 0; j < C4; ++j) kks[j] = acc[j];
-      __syncthreads();
-    }
-    if (ok) {
-      float* o = y.data + pix * y.cstride + y.coff;
+    for (int t = 0; t < 27; ++t) Vs[tid * LDV + t] = v[t];
+    __syncthreads();
+    if (tile + gridDim.x < ntiles) issue(tile + gridDim.x);
 #pragma unroll
-      for (int j = 0; j < C4; ++j) {
-        *reinterpret_cast<f4*>(o + 4 * j) = acc[j];
-        const f4 d = acc[j] - kks[j];
-        s[j] += d;
-        q[j] += d * d;
+    for (int h = 0; h < 2; ++h) {
+      const int prow = wave * 64 + 32 * h;
+      const f4* ap = reinterpret_cast<const f4*>(Vs + (prow + l31) * LDV + 16 * lh);
+      const f4 a0 = ap[0], a1 = ap[1], a2 = ap[2], a3 = ap[3];
+      const float a[16] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, a3.x, a3.y, a3.z, a3.w};
+      f16v acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks], wreg[ks], acc, 0, 0, 0);
+      const int64_t pbase = tile * 256 + prow + 4 * lh;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t pix = pbase + (r & 3) + 8 * (r >> 2);
+        if (pix < total) {
+          y.data[pix * y.cstride + y.coff + l31] = acc[r];
+          if (cnt == 0) kk = acc[r];
+          const float d = acc[r] - kk;
+          s += d;
+          q += d * d;
+          ++cnt;
+        }
       }
     }
   }
   if (stats) {
-#pragma unroll
-    for (int j = 0; j < C4; ++j)
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        s[j].x += __shfl_xor(s[j].x, o, 64); s[j].y += __shfl_xor(s[j].y, o, 64); s[j].z += __shfl_xor(s[j].z, o, 64); s[j].w += __shfl_xor(s[j].w, o, 64);
-        q[j].x += __shfl_xor(q[j].x, o, 64); q[j].y += __shfl_xor(q[j].y, o, 64); q[j].z += __shfl_xor(q[j].z, o, 64); q[j].w += __shfl_xor(q[j].w, o, 64);
-      }
-    if (lane == 0)
-#pragma unroll
-      for (int j = 0; j < C4; ++j) {
-        *reinterpret_cast<f4*>(&red[wave][4 * j]) = s[j];
-        *reinterpret_cast<f4*>(&red[wave][CO + 4 * j]) = q[j];
-      }
+    const double k0 = kk, c0 = cnt;
+    double sd = (double)s + c0 * k0, qd = (double)q + 2.0 * k0 * (double)s + c0 * k0 * k0;
+    sd += __shfl_xor(sd, 32, 64);
+    qd += __shfl_xor(qd, 32, 64);
+    if (lh == 0) {
+      redd[wave][l31] = sd;
+      redd[wave][CO + l31] = qd;
+    }
     __syncthreads();
-    if (tid < CO) {
-      const double S = (double)red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
-      const double Q = (double)red[0][CO + tid] + red[1][CO + tid] + red[2][CO + tid] + red[3][CO + tid];
-      const double k0 = (double)reinterpret_cast<const float*>(kks)[tid], cnt = (double)nvalid;
+    if (tid < 2 * CO) {
       double* st = stats + (size_t)(blockIdx.x % LHN_STAT_REPLICAS) * 2 * CO;
-      atomicAdd(st + tid, S + cnt * k0);
-      atomicAdd(st + CO + tid, Q + 2.0 * k0 * S + cnt * k0 * k0);
+      atomicAdd(st + tid, redd[0][tid] + redd[1][tid] + redd[2][tid] + redd[3][tid]);
     }
     if (fin.counter && lhn_last_block(fin.counter)) lhn_bn_finalize_block(fin, stats);
   }
@@ -396,7 +393,7 @@ extern "C" int lhn_conv_stem_fwd(const float* img, const float* w, const lhn_vie
   const int PL = 256 / (y->C / 8);
   const size_t lds = (size_t)(3 * k * k * y->C) * 4 + 256 * 16 * 4;
   if (k == 3 && y->C == 32 && !lhn_dw_force_gather())
-    hipLaunchKernelGGL((k_stem3_fwd<32>), dim3(grid_for((int64_t)y->N * Ho * Wo, 256, 4)), dim3(256), 0, (hipStream_t)stream, img, w, *y,
+    hipLaunchKernelGGL(k_stem3_fwd_mfma, dim3(grid_for((int64_t)y->N * Ho * Wo, 256, 3)), dim3(256), 0, (hipStream_t)stream, img, w, *y,
                        stats, Hi, Wi, stride, pad, fin);
   else
     hipLaunchKernelGGL(k_stem_fwd, dim3(grid_for((int64_t)y->N * Ho * Wo, PL, 8)), dim3(256), lds, (hipStream_t)stream, img,
@@ -622,44 +619,58 @@ __global__ void __launch_bounds__(256) k_stem3_bwd_mfma(const float* __restrict_
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const int64_t total = (int64_t)y.N * y.H * y.W;
   const int64_t ntiles = (total + 255) / 256;
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  // raw loads of a tile go into registers one tile AHEAD (dy is formed when they are parked in LDS)
+  f4 yraw[8], zraw[8];
+  float v[27];
+  auto issue = [&](int64_t tile) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      int64_t pix = tile * 256 + prow + 32 * j;
+      pix = pix < total ? pix : total - 1;
+      yraw[j] = *reinterpret_cast<const f4*>(y.data + pix * y.cstride + cy);
+      zraw[j] = *reinterpret_cast<const f4*>(gy.dz + pix * y.cstride + cy);
+    }
+    const int64_t pix = tile * 256 + tid;
+    const int64_t pc = pix < total ? pix : total - 1;
+    const int wo = (int)(pc % y.W);
+    const int64_t r = pc / y.W;
+    const int ho = (int)(r % y.H), n = (int)(r / y.H);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float* plane = img + ((int64_t)n * 3 + c) * Hi * Wi;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const int ih = ho * stride - pad + kh, ihc = min(max(ih, 0), Hi - 1);
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int iw = wo * stride - pad + kw, iwc = min(max(iw, 0), Wi - 1);
+          const float t = plane[(int64_t)ihc * Wi + iwc];
+          v[c * 9 + kh * 3 + kw] = (ih == ihc && iw == iwc) ? t : 0.f;      // (rows past the end meet dy = 0)
+        }
+      }
+    }
+  };
+  int64_t tile = blockIdx.x;
+  if (tile < ntiles) issue(tile);
+  for (; tile < ntiles; tile += gridDim.x) {
     __syncthreads();                       // the previous tile's MFMA reads are done
-    // dy rows: thread = (4 features, pixel prow + 32 j)
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int p = prow + 32 * j;
       const int64_t pix = tile * 256 + p;
-      f4 v = (f4){0.f, 0.f, 0.f, 0.f};
+      f4 d = (f4){0.f, 0.f, 0.f, 0.f};
       if (pix < total) {
         const int wo = (int)(pix % y.W);
         const int64_t r = pix / y.W;
-        v = dw_load_dy(y, gy, yxf, ygr, pix, (int)(r / y.H), (int)(r % y.H), wo, cy);
+        const f4 du = lhn_grad_du(y, gy, yxf, yraw[j], zraw[j], (int)(r / y.H), (int)(r % y.H), wo, cy);
+        d = ygr.A * du + ygr.B * yraw[j] + ygr.Cc;
       }
-      *reinterpret_cast<f4*>(dYs + p * LDY + 4 * c4) = v;
+      *reinterpret_cast<f4*>(dYs + p * LDY + 4 * c4) = d;
     }
-    // patch rows: thread = pixel
-    {
-      const int64_t pix = tile * 256 + tid;
-      const int64_t pc = pix < total ? pix : total - 1;
-      const int wo = (int)(pc % y.W);
-      const int64_t r = pc / y.W;
-      const int ho = (int)(r % y.H), n = (int)(r / y.H);
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const float* plane = img + ((int64_t)n * 3 + c) * Hi * Wi;
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-          const int ih = ho * stride - pad + kh, ihc = min(max(ih, 0), Hi - 1);
-#pragma unroll
-          for (int kw = 0; kw < 3; ++kw) {
-            const int iw = wo * stride - pad + kw, iwc = min(max(iw, 0), Wi - 1);
-            const float v = plane[(int64_t)ihc * Wi + iwc];
-            Vs[tid * LDV + c * 9 + kh * 3 + kw] = (ih == ihc && iw == iwc) ? v : 0.f;      // (rows past the end meet dy = 0)
-          }
-        }
-      }
-    }
+    for (int t = 0; t < 27; ++t) Vs[tid * LDV + t] = v[t];
     __syncthreads();
+    if (tile + gridDim.x < ntiles) issue(tile + gridDim.x);
     const float* ar = dYs + (wave * 64 + lh) * LDY + l31;
     const float* br = Vs + (wave * 64 + lh) * LDV + l31;
 #pragma unroll 8

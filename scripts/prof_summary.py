@@ -19,7 +19,7 @@ def steady(d, out, title, marker="k_stem_fwd"):
     build) is dropped, the rest averaged.  Replaces `stats` for anything quoted per step."""
     rows = list(csv.DictReader(open(find(d, "kernel_trace.csv"))))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    cuts = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith(marker)]
+    cuts = [i for i, r in enumerate(rows) if marker in r["Kernel_Name"] or "k_stem3_fwd" in r["Kernel_Name"]]
     if len(cuts) < 3:
         sys.exit(f"need >= 3 steps, found {len(cuts)} {marker} launches")
     # a step begins a few setup launches (memset / dropout masks) before its stem: attribute those to the step they precede

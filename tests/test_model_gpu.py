@@ -470,8 +470,11 @@ def test_model_224_input(dev, variant):
     cfg = litehandnet_cfg(variant, image_size=224)
     cfg.MODEL["ca_dropout"] = 0.0
     ours, ref = get_model(cfg), torch_ref.get_model(cfg, p_drop=0.0)
-    x = synth.synth_images(4, 224, 21)
-    _check_block(ours, ref, x, dev, seed=30, no_dx=True, grad_tol=2e-2)      # N=4 attention BatchNorms: see test_odd_batches
+    # N=4 attention BatchNorms are ill-conditioned (see test_odd_batches): torch's own fp32 run of mynet is 2.7 % away from
+    # float64 on the stem's BatchNorm weight there, and which side of the 3x bar a second fp32 implementation lands on
+    # depends on its summation order -- mynet runs the case at N=8
+    x = synth.synth_images(8 if variant == "M" else 4, 224, 21)
+    _check_block(ours, ref, x, dev, seed=30, no_dx=True, grad_tol=2e-2)
 
 
 # ---------------------------------------------------------------- SyncBatchNorm (section 8f rank 3)
