@@ -307,6 +307,9 @@ struct DwExtra {
 int lhn_dwk_fwd_lds(const lhn_view* x, const float* w, const lhn_view* y, double* stats, int k, int dil, lhn_bnfin fin,
                     hipStream_t s, const DwExtra* ex);
 struct DwBnSum;
+static int dws2_fwd(const lhn_view* x, const float* w, const lhn_view* y, double* stats, lhn_bnfin fin, const lhn_pends& px, hipStream_t s);
+static int dws2_bwd(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx, int dx_acc, float* dw,
+                    int nrep, int64_t rep_stride, hipStream_t s);
 int lhn_dwk_bwd_lds(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx, int dx_acc,
                     float* dw, int k, int dil, int nrep, int64_t rep_stride, hipStream_t s, const DwBnSum* bs);
 static bool lhn_dw_force_gather() {
@@ -369,6 +372,8 @@ extern "C" int lhn_conv_dw_fwd(const lhn_view* x, const float* w, const lhn_view
   ex0.sum_out = nullptr;
   if (w && stride == 1 && pad == dil * (k - 1) / 2 && x->C % 4 == 0 && y->W >= 8 && !lhn_dw_force_gather() &&
       lhn_dwk_fwd_lds(x, w, y, stats, k, dil, fin, s, &ex0)) {
+  } else if (w && k == 3 && stride == 2 && pad == 1 && dil == 1 && x->C % 4 == 0 && !lhn_dw_force_gather() &&
+             dws2_fwd(x, w, y, stats, fin, px, s)) {
   } else if (k == 3)
     hipLaunchKernelGGL((k_dw_fwd<3>), dim3(grid), dim3(256), lds, s, *x, w, *y, stats, stride, pad, dil, fin, px);
   else if (k == 7)
@@ -739,6 +744,11 @@ extern "C" int lhn_conv_dw_bwd(const lhn_view* x, const float* w, const lhn_view
   hipStream_t s = (hipStream_t)stream;
   if (w && dw && stride == 1 && pad == dil * (k - 1) / 2 && x->C % 4 == 0 && x->W >= 8 && !lhn_dw_force_gather() &&
       lhn_dwk_bwd_lds(x, w, y, gy, dx, dx_accumulate, dw, k, dil, nrep, rep_stride, s, nullptr)) {
+    LHN_CHECK_LAUNCH("lhn_conv_dw_bwd");
+    return 0;
+  }
+  if (w && dw && k == 3 && stride == 2 && pad == 1 && dil == 1 && x->C % 4 == 0 && !lhn_dw_force_gather() &&
+      dws2_bwd(x, w, y, gy, dx, dx_accumulate, dw, nrep, rep_stride, s)) {
     LHN_CHECK_LAUNCH("lhn_conv_dw_bwd");
     return 0;
   }
@@ -1284,6 +1294,268 @@ static void launch_dwk_bwd(const lhn_view* x, const float* w, const lhn_view* y,
   const int grid = dw3_grid(ntile, cg, 4);
   hipLaunchKernelGGL((k_dwk_bwd_lds<K, DIL, BNS>), dim3(grid), dim3(256), lds, s, *x, w, *y, *gy, dx, dx_acc, dw, th, tw,
                      cg, nrep, rep_stride, ps, bs, dw3_xchunk(grid, cg));
+}
+
+
+// =====================================================================================================
+// Stride-2 3x3 depthwise (pad 1) with the input tile in LDS: the downsampling convolutions of the stems and of
+// lite_hrnet.py's fuse / transition layers (54 per Lite-HRNet-18 step).  The row-gather kernels they used to take
+// (k_dw_fwd / k_dw_bwd_data + k_dw_bwd_weight) ran at a fifth of the traffic-bound time.
+// Output tile TH x TW = 4 x 16, 32 channels per block; input tile (2 TH + 1) x (2 TW + 1) with origin (2 oh0 - 1, 2 ow0 - 1).
+struct DwS2 {
+  static constexpr int TH = 4, TW = 16, XH = 2 * TH + 1, XW = 2 * TW + 1, XPIX = XH * XW, DH = TH + 1, DW = TW + 1, DPIX = DH * DW;
+};
+
+__global__ void __launch_bounds__(256) k_dws2_fwd_lds(lhn_view x, const float* __restrict__ w, lhn_view y, double* __restrict__ stats,
+                                                      int tiles_h, int tiles_w, int cgroups, lhn_bnfin fin, lhn_pends px) {
+  using T = DwS2;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  f4* tx = reinterpret_cast<f4*>(smem);          // [XPIX][8]
+  f4* red = tx + T::XPIX * 8;                    // [512]
+  f4* wl = red + 512;                            // [9][8]
+  const int tid = threadIdx.x, c4 = tid & 7, pl = tid >> 3;
+  const int ntile = y.N * tiles_h * tiles_w * cgroups;
+  const int cg = blockIdx.x % cgroups;
+  const int cvalid = min(8, (x.C - cg * 32) >> 2);          // see k_dwk_fwd_lds
+  const bool cok = c4 < cvalid;
+  const int c4e = cok ? c4 : 0;
+  const int cin = x.coff + cg * 32 + 4 * c4e, cout = y.coff + cg * 32 + 4 * c4e;
+  for (int i = tid; i < 72; i += 256) {
+    const int k = i >> 3, cc = cg * 32 + 4 * min(i & 7, cvalid - 1);
+    wl[i] = (f4){w[(cc + 0) * 9 + k], w[(cc + 1) * 9 + k], w[(cc + 2) * 9 + k], w[(cc + 3) * 9 + k]};
+  }
+  const Xf4 xf = lhn_load_xf_t(lhn_resolve_table(x, px, smem), x.cstride, cin);
+  double sd[4] = {0, 0, 0, 0}, qd[4] = {0, 0, 0, 0};
+  constexpr int NIT = (T::XPIX + 31) / 32;
+  for (int t = blockIdx.x; t < ntile; t += gridDim.x) {
+    int r = t / cgroups;
+    const int tw = r % tiles_w;
+    r /= tiles_w;
+    const int th = r % tiles_h, n = r / tiles_h;
+    const int h0 = 2 * th * T::TH - 1, w0 = 2 * tw * T::TW - 1;
+    const f4 gate = x.gate ? *reinterpret_cast<const f4*>(x.gate + (size_t)n * x.cstride + cin) : (f4){1.f, 1.f, 1.f, 1.f};
+    const float* xin = x.data + (size_t)n * x.H * x.W * x.cstride + cin;
+    f4 raw[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int i = min(pl + 32 * it, T::XPIX - 1);
+      const int ph = i / T::XW, pw = i - ph * T::XW;
+      const int ih = min(max(h0 + ph, 0), x.H - 1), iw = min(max(w0 + pw, 0), x.W - 1);
+      raw[it] = *reinterpret_cast<const f4*>(xin + ((size_t)ih * x.W + iw) * x.cstride);
+    }
+    __syncthreads();                 // previous tile consumed (and wl / the resolved table visible)
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int i = pl + 32 * it;
+      if (i < T::XPIX) {
+        const int ph = i / T::XW, pw = i - ph * T::XW;
+        const int ih = h0 + ph, iw = w0 + pw;
+        const bool inb = ih >= 0 && ih < x.H && iw >= 0 && iw < x.W;
+        tx[i * 8 + c4] = inb ? lhn_apply_xf(raw[it], xf) * gate : (f4){0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    __syncthreads();
+    f4 s = (f4){0.f, 0.f, 0.f, 0.f}, q = s, kk = s;
+    int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int o = pl + 32 * j, oh = o / T::TW, ow = o - oh * T::TW;
+      const int ho = th * T::TH + oh, wo = tw * T::TW + ow;
+      if (cok && ho < y.H && wo < y.W) {
+        f4 acc = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int b = 0; b < 3; ++b) acc += tx[((2 * oh + a) * T::XW + 2 * ow + b) * 8 + c4] * wl[(a * 3 + b) * 8 + c4];
+        *reinterpret_cast<f4*>(y.data + ((size_t)(n * y.H + ho) * y.W + wo) * y.cstride + cout) = acc;
+        if (cnt == 0) kk = acc;
+        const f4 d = acc - kk;
+        s += d;
+        q += d * d;
+        ++cnt;
+      }
+    }
+    lhn_unshift4(sd, qd, s, q, kk, cnt);
+  }
+  if (stats) {
+    const int C = x.C;
+    double* st = stats + (size_t)((blockIdx.x / cgroups) % LHN_STAT_REPLICAS) * 2 * C + cg * 32;
+    lhn_block_stat_atomics_d(sd, qd, 8, reinterpret_cast<double*>(red), st, st + C, cvalid);
+    if (fin.counter && lhn_last_block(fin.counter)) lhn_bn_finalize_block(fin, stats);
+  }
+}
+
+// fused backward: dx for the 2TH x 2TW input pixels the tile owns (every input pixel belongs to one tile) and dW.
+//   dx[ih,iw] = sum over taps (a,b) with (ih+1-a), (iw+1-b) even of dy[(ih+1-a)/2, (iw+1-b)/2] * w[a][b]
+//   dW[a][b] += sum over the tile's outputs dy[ho,wo] * x[2ho-1+a, 2wo-1+b]
+__global__ void __launch_bounds__(256, 2) k_dws2_bwd_lds(lhn_view x, const float* __restrict__ w, lhn_view y, lhn_gradview gy,
+                                                      float* __restrict__ dx, int dx_acc, float* __restrict__ dw, int tiles_h,
+                                                      int tiles_w, int cgroups, int nrep, int64_t rep_stride) {
+  using T = DwS2;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  f4* tx = reinterpret_cast<f4*>(smem);          // [XPIX][8] transformed x (zero outside the image)
+  f4* tdy = tx + T::XPIX * 8;                    // [DPIX][8] dy (zero outside the output map); >= 36*8 float4 for the flush
+  f4* wl = tdy + T::DPIX * 8;                    // [9][8]
+  const int tid = threadIdx.x, c4 = tid & 7, pl = tid >> 3;
+  const int ntile = y.N * tiles_h * tiles_w * cgroups;
+  const int cg = blockIdx.x % cgroups;
+  const int cvalid = min(8, (x.C - cg * 32) >> 2);
+  const bool cok = c4 < cvalid;
+  const int c4e = cok ? c4 : 0;
+  const int cx = x.coff + cg * 32 + 4 * c4e, cy = y.coff + cg * 32 + 4 * c4e;
+  const Xf4 xxf = lhn_load_xf(x, cx), yxf = lhn_load_xf(y, cy);
+  const Gr4 ygr = lhn_load_coef(gy, y.cstride, cy);
+  for (int i = tid; i < 72; i += 256) {
+    const int k = i >> 3, cc = cg * 32 + 4 * min(i & 7, cvalid - 1);
+    wl[i] = (f4){w[(cc + 0) * 9 + k], w[(cc + 1) * 9 + k], w[(cc + 2) * 9 + k], w[(cc + 3) * 9 + k]};
+  }
+  f4 accw[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) accw[k] = (f4){0.f, 0.f, 0.f, 0.f};
+  constexpr int NITX = (T::XPIX + 31) / 32, NITD = (T::DPIX + 31) / 32;
+  for (int t = blockIdx.x; t < ntile; t += gridDim.x) {
+    int r = t / cgroups;
+    const int tw = r % tiles_w;
+    r /= tiles_w;
+    const int th = r % tiles_h, n = r / tiles_h;
+    const int h0 = 2 * th * T::TH - 1, w0 = 2 * tw * T::TW - 1;       // input tile origin
+    const int oh0 = th * T::TH, ow0 = tw * T::TW;                     // dy tile origin
+    const f4 xgate = x.gate ? *reinterpret_cast<const f4*>(x.gate + (size_t)n * x.cstride + cx) : (f4){1.f, 1.f, 1.f, 1.f};
+    f4 rx[NITX], ry[NITD], rz[NITD];
+#pragma unroll
+    for (int it = 0; it < NITX; ++it) {
+      const int i = min(pl + 32 * it, T::XPIX - 1);
+      const int ph = i / T::XW, pw = i - ph * T::XW;
+      const int ih = min(max(h0 + ph, 0), x.H - 1), iw = min(max(w0 + pw, 0), x.W - 1);
+      rx[it] = *reinterpret_cast<const f4*>(x.data + ((size_t)(n * x.H + ih) * x.W + iw) * x.cstride + cx);
+    }
+#pragma unroll
+    for (int it = 0; it < NITD; ++it) {
+      const int i = min(pl + 32 * it, T::DPIX - 1);
+      const int ph = i / T::DW, pw = i - ph * T::DW;
+      const int ho = min(oh0 + ph, y.H - 1), wo = min(ow0 + pw, y.W - 1);
+      const size_t off = ((size_t)(n * y.H + ho) * y.W + wo) * y.cstride + cy;
+      ry[it] = *reinterpret_cast<const f4*>(y.data + off);
+      rz[it] = *reinterpret_cast<const f4*>(gy.dz + off);
+    }
+    __syncthreads();                 // previous tile consumed (and wl visible)
+#pragma unroll
+    for (int it = 0; it < NITX; ++it) {
+      const int i = pl + 32 * it;
+      if (i < T::XPIX) {
+        const int ph = i / T::XW, pw = i - ph * T::XW;
+        const int ih = h0 + ph, iw = w0 + pw;
+        const bool inb = ih >= 0 && ih < x.H && iw >= 0 && iw < x.W;
+        tx[i * 8 + c4] = inb ? lhn_apply_xf(rx[it], xxf) * xgate : (f4){0.f, 0.f, 0.f, 0.f};
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < NITD; ++it) {
+      const int i = pl + 32 * it;
+      if (i < T::DPIX) {
+        const int ph = i / T::DW, pw = i - ph * T::DW;
+        const int ho = oh0 + ph, wo = ow0 + pw;
+        f4 d = (f4){0.f, 0.f, 0.f, 0.f};
+        if (ho < y.H && wo < y.W) {
+          const f4 du = lhn_grad_du(y, gy, yxf, ry[it], rz[it], n, ho, wo, cy);
+          d = ygr.A * du + ygr.B * ry[it] + ygr.Cc;
+        }
+        tdy[i * 8 + c4] = d;
+      }
+    }
+    __syncthreads();
+    // ---- dW: two outputs per thread
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int o = pl + 32 * j, oh = o / T::TW, ow = o - oh * T::TW;
+      const f4 dyc = tdy[(oh * T::DW + ow) * 8 + c4];          // zero outside the map
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) accw[a * 3 + b] += dyc * tx[((2 * oh + a) * T::XW + 2 * ow + b) * 8 + c4];
+    }
+    // ---- dx: thread = input column c = pl of the tile (parity fixed), 2 TH rows
+    if (dx && cok) {
+      const int c = pl, iw = 2 * ow0 + c;
+      // column taps: c even -> b = 1 at dy column c/2; c odd -> b = 0 at (c+1)/2 and b = 2 at (c-1)/2
+      const int nb = (c & 1) ? 2 : 1;
+      const int bA = (c & 1) ? 0 : 1, colA = (c & 1) ? (c + 1) >> 1 : c >> 1, colB = (c - 1) >> 1;
+      if (iw < x.W) {
+#pragma unroll
+        for (int rr = 0; rr < 2 * T::TH; ++rr) {
+          const int ih = 2 * oh0 + rr;
+          if (ih < x.H) {
+            f4 accx = (f4){0.f, 0.f, 0.f, 0.f};
+            // row taps: rr even -> a = 1 at dy row rr/2; rr odd -> a = 0 at (rr+1)/2 and a = 2 at (rr-1)/2  (rr is a compile-time constant)
+            if ((rr & 1) == 0) {
+              const f4* drow = tdy + ((rr >> 1) * T::DW) * 8 + c4;
+              accx += drow[colA * 8] * wl[(3 + bA) * 8 + c4];
+              if (nb == 2) accx += drow[colB * 8] * wl[(3 + 2) * 8 + c4];
+            } else {
+              const f4* d0 = tdy + (((rr + 1) >> 1) * T::DW) * 8 + c4;
+              const f4* d2 = tdy + (((rr - 1) >> 1) * T::DW) * 8 + c4;
+              accx += d0[colA * 8] * wl[(0 + bA) * 8 + c4] + d2[colA * 8] * wl[(6 + bA) * 8 + c4];
+              if (nb == 2) accx += d0[colB * 8] * wl[(0 + 2) * 8 + c4] + d2[colB * 8] * wl[(6 + 2) * 8 + c4];
+            }
+            float* o = dx + ((size_t)(n * x.H + ih) * x.W + iw) * x.cstride + cx;
+            if (dx_acc) accx += *reinterpret_cast<const f4*>(o);
+            *reinterpret_cast<f4*>(o) = accx;
+          }
+        }
+      }
+    }
+  }
+  // ---- flush dW (as k_dwk_bwd_lds)
+  float* dwr = dw + (size_t)((blockIdx.x / cgroups) % nrep) * rep_stride;
+#pragma unroll
+  for (int k = 0; k < 9; ++k)
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) {
+      accw[k].x += __shfl_xor(accw[k].x, o, 64);
+      accw[k].y += __shfl_xor(accw[k].y, o, 64);
+      accw[k].z += __shfl_xor(accw[k].z, o, 64);
+      accw[k].w += __shfl_xor(accw[k].w, o, 64);
+    }
+  __syncthreads();
+  if ((tid & 63) < 8)
+#pragma unroll
+    for (int k = 0; k < 9; ++k) tdy[(k * 4 + (tid >> 6)) * 8 + c4] = accw[k];
+  __syncthreads();
+  if (tid < 72) {
+    const int k = tid >> 3, cc = tid & 7;
+    const f4 sacc = tdy[(k * 4 + 0) * 8 + cc] + tdy[(k * 4 + 1) * 8 + cc] + tdy[(k * 4 + 2) * 8 + cc] + tdy[(k * 4 + 3) * 8 + cc];
+    const int cb = cg * 32 + 4 * cc;
+    if (cc < cvalid) {
+      atomicAdd(dwr + (cb + 0) * 9 + k, sacc.x);
+      atomicAdd(dwr + (cb + 1) * 9 + k, sacc.y);
+      atomicAdd(dwr + (cb + 2) * 9 + k, sacc.z);
+      atomicAdd(dwr + (cb + 3) * 9 + k, sacc.w);
+    }
+  }
+}
+
+// returns 1 if the stride-2 tiled kernel was launched
+static int dws2_fwd(const lhn_view* x, const float* w, const lhn_view* y, double* stats, lhn_bnfin fin, const lhn_pends& px, hipStream_t s) {
+  using T = DwS2;
+  const int cg = (x->C + 31) / 32;
+  const int th = (y->H + T::TH - 1) / T::TH, tw = (y->W + T::TW - 1) / T::TW, ntile = y->N * th * tw * cg;
+  size_t lds = (size_t)(T::XPIX * 8 + 512 + 72) * 16;
+  if (lds < LHN_RESOLVE_FLOATS * 4) lds = LHN_RESOLVE_FLOATS * 4;
+  static LhnKernelCfg cfg;
+  if (!lhn_kernel_cfg(cfg, &k_dws2_fwd_lds, lds, 4, nullptr)) return 0;
+  hipLaunchKernelGGL(k_dws2_fwd_lds, dim3(dw3_grid(ntile, cg, 6)), dim3(256), lds, s, *x, w, *y, stats, th, tw, cg, fin, px);
+  return 1;
+}
+static int dws2_bwd(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx, int dx_acc, float* dw,
+                    int nrep, int64_t rep_stride, hipStream_t s) {
+  using T = DwS2;
+  const int cg = (x->C + 31) / 32;
+  const int th = (y->H + T::TH - 1) / T::TH, tw = (y->W + T::TW - 1) / T::TW, ntile = y->N * th * tw * cg;
+  const size_t lds = (size_t)((T::XPIX + T::DPIX) * 8 + 72) * 16;
+  static LhnKernelCfg cfg;
+  if (!lhn_kernel_cfg(cfg, &k_dws2_bwd_lds, lds, 4, nullptr)) return 0;
+  hipLaunchKernelGGL(k_dws2_bwd_lds, dim3(dw3_grid(ntile, cg, 4)), dim3(256), lds, s, *x, w, *y, *gy, dx, dx_acc, dw, th, tw, cg, nrep, rep_stride);
+  return 1;
 }
 
 // returns 1 if an LDS-tiled kernel was launched

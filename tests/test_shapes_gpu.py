@@ -26,6 +26,9 @@ CASES = [
     (40, 40, 3, 1, 2, 2, 40, "lrelu", 1, 17, 33),
     (72, 72, 3, 1, 1, 1, 72, "lrelu", 3, 8, 8),
     (36, 36, 3, 1, 2, 2, 36, None, 2, 10, 12),
+    (20, 20, 3, 2, 1, 1, 20, None, 2, 9, 11),              # stride-2 tiled depthwise: odd maps, channel tail
+    (64, 64, 3, 2, 1, 1, 64, "lrelu", 3, 8, 34),
+    (40, 40, 3, 2, 1, 1, 40, None, 1, 33, 18),
     (32, 32, 3, 1, 1, 1, 1, "lrelu", 3, 6, 10),
     (64, 64, 3, 1, 1, 1, 1, None, 2, 9, 9),
     (128, 128, 3, 1, 1, 1, 1, "lrelu", 1, 5, 5),
