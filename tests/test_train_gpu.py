@@ -341,3 +341,41 @@ def test_bench_two_ranks_gloo_rehearsal(dev):
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 128 and d["config"]["parallelism"] == "dp2"
     assert d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["value"] > 0
     assert abs(d["value"] - 128 * 3 / (d["ms_per_step"] * 3e-3)) <= 1e-2 * d["value"]      # whole-job images / max-over-ranks time
+
+
+def test_run_to_run_spread(dev):
+    """No deterministic mode is built: BatchNorm statistics, weight-gradient replicas and the gate / pool
+    reductions are accumulated with double / float atomics, so the last bits depend on workgroup arrival order.  This bounds
+    the spread: the SAME training forward + backward (same weights, inputs, dropout masks) run three times gives outputs and
+    parameter gradients equal to 1e-5 relative (norm-wise), running statistics to 1e-6."""
+    from litehandnet_amd import get_loss, get_model
+    cfg = litehandnet_cfg("B")
+    cfg.MODEL["ca_dropout"] = 0.0
+    crit = get_loss(cfg)
+    x, meta, _ = _batch(41, 8, 128)
+    x = x.to(dev)
+    meta = {k: v.to(dev) for k, v in meta.items()}
+    sd0 = None
+    runs = []
+    for _ in range(3):
+        m = get_model(cfg)
+        if sd0 is None:
+            sd0 = {k: v.clone() for k, v in synth.synth_state_dict(m, 23).items()}
+        m.load_state_dict(sd0)
+        m.to(dev).train()
+        y = m(x)
+        loss, _ = crit(y, meta)
+        loss.backward()
+        runs.append((y.detach().double(), {k: p.grad.double() for k, p in m.named_parameters()},
+                     {k: b.double() for k, b in m.named_buffers() if "running" in k}, float(loss)))
+
+    def rel(a, b):
+        return float((a - b).norm() / (b.norm() + 1e-30))
+    y0, g0, b0, l0 = runs[0]
+    gn = max(float(v.norm()) for v in g0.values())
+    for y, g, b, l in runs[1:]:
+        assert rel(y, y0) < 1e-5 and abs(l - l0) <= 1e-6 * abs(l0)
+        for k in g0:
+            assert float((g[k] - g0[k]).norm()) <= 1e-5 * (float(g0[k].norm()) + 1e-3 * gn), k
+        for k in b0:
+            assert rel(b[k], b0[k]) < 1e-6, k
