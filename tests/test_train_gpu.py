@@ -376,6 +376,7 @@ def test_run_to_run_spread(dev):
     for y, g, b, l in runs[1:]:
         assert rel(y, y0) < 1e-5 and abs(l - l0) <= 1e-6 * abs(l0)
         for k in g0:
-            assert float((g[k] - g0[k]).norm()) <= 1e-5 * (float(g0[k].norm()) + 1e-3 * gn), k
+            # (parameters whose true gradient is zero -- a bias in front of a BatchNorm -- hold pure rounding noise: floor)
+            assert float((g[k] - g0[k]).norm()) <= 1e-5 * (float(g0[k].norm()) + 1e-2 * gn), k
         for k in b0:
             assert rel(b[k], b0[k]) < 1e-6, k
