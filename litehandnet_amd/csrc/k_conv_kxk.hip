@@ -12,27 +12,46 @@
 // dz := dy in place (dy = A*du + B*y + C with du from gate / pooled gradient / leaky derivative).  Used ahead of the
 // MFMA-heavy backward kernels: they then stream ONE plain tensor instead of (dz, raw y) + the formula per element,
 // which halves their prefetch registers (no spills) -- worth one extra elementwise pass when Cin*Cout is large.
-__global__ void __launch_bounds__(256) k_dy_inplace(lhn_view y, lhn_gradview g, float* __restrict__ dz) {
+__global__ void __launch_bounds__(256) k_dy_inplace(lhn_view y, lhn_gradview g, float* __restrict__ dz, float* __restrict__ dbias,
+                                                    int nrep, int64_t rep_stride) {
+  __shared__ f4 red[256];
   const int C4 = y.C >> 2, c4 = threadIdx.x % C4, pl = threadIdx.x / C4, PL = 256 / C4;
   const int ca = y.coff + 4 * c4;
   const Xf4 xf = lhn_load_xf(y, ca);
   const Gr4 gr = lhn_load_coef(g, y.cstride, ca);
   const int rows = y.N * y.H;
+  f4 bsum = (f4){0.f, 0.f, 0.f, 0.f};
   for (int row = blockIdx.x; row < rows; row += gridDim.x) {
     const int n = row / y.H, h = row - n * y.H;
     for (int w = LHN_LANE0(pl, PL); w < y.W; w += PL) {
       const size_t off = ((size_t)row * y.W + w) * y.cstride + ca;
       const f4 raw = *reinterpret_cast<const f4*>(y.data + off);
       const f4 du = lhn_grad_du(y, g, xf, raw, *reinterpret_cast<const f4*>(dz + off), n, h, w, ca);
-      *reinterpret_cast<f4*>(dz + off) = gr.A * du + gr.B * raw + gr.Cc;
+      const f4 dy = gr.A * du + gr.B * raw + gr.Cc;
+      *reinterpret_cast<f4*>(dz + off) = dy;
+      bsum += dy;
+    }
+  }
+  // d(bias) of a biased convolution = column sums of dy: this pass already touches every element.  One thread per CHANNEL
+  // adds its column (consecutive lanes -> consecutive addresses: the full-rate atomic form) into this block's gradient replica.
+  if (dbias) {
+    red[threadIdx.x] = bsum;                 // (lanes beyond PL * C4 never entered the loop: zero)
+    __syncthreads();
+    if ((int)threadIdx.x < y.C) {
+      const float* rf = reinterpret_cast<const float*>(red);
+      const int cc = threadIdx.x >> 2, jj = threadIdx.x & 3;
+      float v = 0.f;
+      for (int j = 0; j < PL; ++j) v += rf[(j * C4 + cc) * 4 + jj];
+      atomicAdd(dbias + (size_t)(blockIdx.x % nrep) * rep_stride + threadIdx.x, v);
     }
   }
 }
-static void launch_dy_inplace(const lhn_view* y, const lhn_gradview* gy, hipStream_t s) {
+static void launch_dy_inplace(const lhn_view* y, const lhn_gradview* gy, hipStream_t s, float* dbias = nullptr, int nrep = 1,
+                              int64_t rep_stride = 0) {
   int64_t g = (int64_t)y->N * y->H;
   const int64_t cap = (int64_t)lhn_num_cus() * 8;
   if (g > cap) g = cap;
-  hipLaunchKernelGGL(k_dy_inplace, dim3((int)g), dim3(256), 0, s, *y, *gy, const_cast<float*>(gy->dz));
+  hipLaunchKernelGGL(k_dy_inplace, dim3((int)g), dim3(256), 0, s, *y, *gy, const_cast<float*>(gy->dz), dbias, nrep < 1 ? 1 : nrep, rep_stride);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -579,7 +598,7 @@ extern "C" int lhn_conv_kxk_bwd(const lhn_view* x, const float* w, const lhn_vie
 // per input-channel slice with the output channels on gridDim.z.  Returns -1 when a shape has no instance (the caller then
 // takes the fused kernel).
 int lhn_pw_bwd_split(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx, int dx_accumulate,
-                     float* dw, int nrep, int64_t rep_stride, hipStream_t s) {
+                     float* dw, float* dbias, int nrep, int64_t rep_stride, hipStream_t s) {
   const int Cin = x->C, Cout = y->C;
   auto dgrad_ok = [&](int co, int nt) { return (co == 64 && (nt == 4 || nt == 2)) || (co == 128 && (nt == 4 || nt == 2 || nt == 1)) || (co == 32 && nt == 4); };
   auto wgrad_ok = [&](int ci, int nto) { return (ci == 64 && (nto == 4 || nto == 2)) || (ci == 128 && (nto == 4 || nto == 2 || nto == 1)) || (ci == 32 && nto == 4); };
@@ -592,7 +611,7 @@ int lhn_pw_bwd_split(const lhn_view* x, const float* w, const lhn_view* y, const
   if (Cout > 128 && Cout % 128 != 0) return -1;
   for (int k0 = 0; k0 < Cin; k0 += 128)
     if (!wgrad_ok(Cin - k0 < 128 ? Cin - k0 : 128, nto)) return -1;
-  launch_dy_inplace(y, gy, s);
+  launch_dy_inplace(y, gy, s, dbias, nrep, rep_stride);
   int rc = -1;
   if (dx) {
     for (int co0 = 0; co0 < Cout; co0 += 128) {

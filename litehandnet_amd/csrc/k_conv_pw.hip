@@ -850,7 +850,7 @@ static int launch_pw_bwd(const lhn_view* x, const float* w, const lhn_view* y, c
 }
 
 int lhn_pw_bwd_split(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx, int dx_accumulate,
-                     float* dw, int nrep, int64_t rep_stride, hipStream_t s);
+                     float* dw, float* dbias, int nrep, int64_t rep_stride, hipStream_t s);
 
 extern "C" int lhn_conv_pw_bwd2(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx,
                                 int dx_accumulate, float* dw, float* dbias, int stride, const float* dy_nchw, int nrep,
@@ -866,8 +866,8 @@ extern "C" int lhn_conv_pw_bwd2(const lhn_view* x, const float* w, const lhn_vie
                 wrows, wcols, Cin, Cout);
   const int64_t bstride = (opts && opts->nchw_batch_stride > 0) ? opts->nchw_batch_stride : (int64_t)Cout * HoWo;
   hipStream_t s = (hipStream_t)stream;
-  if (stride == 1 && !dy_nchw && !dbias && Cin * Cout >= 64 * 128 && Cout % 32 == 0 && Cin % 32 == 0 && wcols == Cin && wrows == Cout) {
-    const int rc = lhn_pw_bwd_split(x, w, y, gy, dx, dx_accumulate, dw, nrep, rep_stride, s);
+  if (stride == 1 && !dy_nchw && Cin * Cout >= 64 * 128 && Cout % 32 == 0 && Cin % 32 == 0 && Cout <= 256 && wcols == Cin && wrows == Cout) {
+    const int rc = lhn_pw_bwd_split(x, w, y, gy, dx, dx_accumulate, dw, dbias, nrep, rep_stride, s);
     if (rc == 0) {
       LHN_CHECK_LAUNCH("lhn_conv_pw_bwd");
       return 0;
