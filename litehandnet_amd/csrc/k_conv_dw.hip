@@ -284,6 +284,110 @@ __global__ void __launch_bounds__(256) k_stem3_fwd_mfma(const float* __restrict_
   }
 }
 
+
+// ------------------------------------------------------------------ stem forward, 7x7 -> 64 features (hourglassnet.py:96) on MFMA
+// K = 147 taps padded to 160.  64-pixel tiles (42 KB of LDS: 3 blocks per CU); wave = (32-pixel group, 32-feature tile), its
+// weights are 80 MFMA B registers.  thread = (pixel, one of 4 tap groups) loads 37 taps; the next tile's are prefetched.
+// The direct kernel took 1.9 ms for this layer at batch 64 (147 x 8 scalar FMAs and 2 LDS reads per tap and thread).
+__global__ void __launch_bounds__(256, 2) k_stem7_fwd_mfma(const float* __restrict__ img, const float* __restrict__ w, lhn_view y,
+                                                        double* __restrict__ stats, int Hi, int Wi, int stride, int pad, lhn_bnfin fin) {
+  constexpr int CO = 64, T = 147, TP = 160, NKS = TP / 2, LDV = TP + 4, BMP = 64, G = 4, NR = 6, NV = NR * 7;      // thread = (pixel, tap-row group): rows (c, kh) g, g+4, .. of 21, 7 kw each
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Vs = smem;                                   // [BMP][LDV], columns 147..159 stay zero
+  double* redd = reinterpret_cast<double*>(smem + BMP * LDV);      // [2 pixel groups][2 * CO]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int cot = wave & 1, pg = wave >> 1, co = cot * 32 + l31;
+  float wreg[NKS];                                    // step ks, lane (n = l31, k = lh): W[co][tap = NKS * lh + ks]
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    const int tap = NKS * lh + ks;
+    wreg[ks] = tap < T ? w[co * T + tap] : 0.f;
+  }
+  const int p = tid & (BMP - 1), g = tid >> 6;        // staging role: pixel of the tile, tap group
+  for (int t = T + g; t < TP; t += G) Vs[p * LDV + t] = 0.f;
+  const int64_t total = (int64_t)y.N * y.H * y.W;
+  const int64_t ntiles = (total + BMP - 1) / BMP;
+  float v[NV];
+  auto issue = [&](int64_t tile) __attribute__((always_inline)) {
+    const int64_t pix = tile * BMP + p;
+    const int64_t pc = pix < total ? pix : total - 1;
+    const int wo = (int)(pc % y.W);
+    const int64_t r = pc / y.W;
+    const int ho = (int)(r % y.H), n = (int)(r / y.H);
+    const float* base = img + (int64_t)n * 3 * Hi * Wi;
+    const int iw0 = wo * stride - pad;
+#pragma unroll
+    for (int jr = 0; jr < NR; ++jr) {
+      const int row = min(g + G * jr, 20), c = row / 7, kh = row - 7 * c;
+      const int ih = ho * stride - pad + kh, ihc = min(max(ih, 0), Hi - 1);
+      const float* rb = base + ((int64_t)c * Hi + ihc) * Wi;
+#pragma unroll
+      for (int kw = 0; kw < 7; ++kw) {
+        const int iw = iw0 + kw, iwc = min(max(iw, 0), Wi - 1);
+        const float q = rb[iwc];
+        v[jr * 7 + kw] = (ih == ihc && iw == iwc) ? q : 0.f;
+      }
+    }
+  };
+  float s = 0.f, q = 0.f, kk = 0.f;                   // this lane's feature: shifted sums (see TileStat)
+  int cnt = 0;
+  int64_t tile = blockIdx.x;
+  if (tile < ntiles) issue(tile);
+  for (; tile < ntiles; tile += gridDim.x) {
+    __syncthreads();
+#pragma unroll
+    for (int jr = 0; jr < NR; ++jr)
+      if (g + G * jr < 21)
+#pragma unroll
+        for (int kw = 0; kw < 7; ++kw) Vs[p * LDV + (g + G * jr) * 7 + kw] = v[jr * 7 + kw];
+    __syncthreads();
+    if (tile + gridDim.x < ntiles) issue(tile + gridDim.x);
+    const f4* ap = reinterpret_cast<const f4*>(Vs + (pg * 32 + l31) * LDV + NKS * lh);
+    f16v acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int c = 0; c < NKS / 4; ++c) {
+      if ((c & 3) == 0) asm volatile("" ::: "memory");      // at most 4 A fragments (16 registers) in flight: hoisted, all 20 spill
+      const f4 a = ap[c];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, wreg[4 * c + 0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, wreg[4 * c + 1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, wreg[4 * c + 2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, wreg[4 * c + 3], acc, 0, 0, 0);
+    }
+    const int64_t pbase = tile * BMP + pg * 32 + 4 * lh;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t pix = pbase + (r & 3) + 8 * (r >> 2);
+      if (pix < total) {
+        y.data[pix * y.cstride + y.coff + co] = acc[r];
+        if (cnt == 0) kk = acc[r];
+        const float d = acc[r] - kk;
+        s += d;
+        q += d * d;
+        ++cnt;
+      }
+    }
+  }
+  if (stats) {
+    const double k0 = kk, c0 = cnt;
+    double sd = (double)s + c0 * k0, qd = (double)q + 2.0 * k0 * (double)s + c0 * k0 * k0;
+    sd += __shfl_xor(sd, 32, 64);
+    qd += __shfl_xor(qd, 32, 64);
+    __syncthreads();
+    if (lh == 0) {
+      redd[pg * 2 * CO + co] = sd;
+      redd[pg * 2 * CO + CO + co] = qd;
+    }
+    __syncthreads();
+    if (tid < 2 * CO) {
+      double* st = stats + (size_t)(blockIdx.x % LHN_STAT_REPLICAS) * 2 * CO;
+      atomicAdd(st + tid, redd[tid] + redd[2 * CO + tid]);
+    }
+    if (fin.counter && lhn_last_block(fin.counter)) lhn_bn_finalize_block(fin, stats);
+  }
+}
+
 static inline int grid_for(int64_t items_per_block_total, int per_block, int cap_per_cu) {
   int64_t g = (items_per_block_total + per_block - 1) / per_block;
   const int64_t cap = (int64_t)lhn_num_cus() * cap_per_cu;
@@ -397,7 +501,19 @@ extern "C" int lhn_conv_stem_fwd(const float* img, const float* w, const lhn_vie
   LHN_CHECK_ARG(y->H == Ho && y->W == Wo, "lhn_conv_stem_fwd: output %dx%d, expected %dx%d", y->H, y->W, Ho, Wo);
   const int PL = 256 / (y->C / 8);
   const size_t lds = (size_t)(3 * k * k * y->C) * 4 + 256 * 16 * 4;
-  if (k == 3 && y->C == 32 && !lhn_dw_force_gather())
+  if (k == 7 && y->C == 64 && !lhn_dw_force_gather()) {
+    const size_t lds7 = (size_t)64 * 164 * 4 + 2 * 2 * 64 * 8;
+    static LhnKernelCfg cfg7;
+    int per_cu = 1;
+    if (!lhn_kernel_cfg(cfg7, &k_stem7_fwd_mfma, lds7, 3, &per_cu)) {
+      lhn_set_error("lhn_conv_stem_fwd: cannot reserve %zu B of LDS", lds7);
+      return 2;
+    }
+    const int64_t ntiles = ((int64_t)y->N * Ho * Wo + 63) / 64;
+    int grid = lhn_num_cus() * per_cu;
+    if (grid > ntiles) grid = (int)ntiles;
+    hipLaunchKernelGGL(k_stem7_fwd_mfma, dim3(grid), dim3(256), lds7, (hipStream_t)stream, img, w, *y, stats, Hi, Wi, stride, pad, fin);
+  } else if (k == 3 && y->C == 32 && !lhn_dw_force_gather())
     hipLaunchKernelGGL(k_stem3_fwd_mfma, dim3(grid_for((int64_t)y->N * Ho * Wo, 256, 3)), dim3(256), 0, (hipStream_t)stream, img, w, *y,
                        stats, Hi, Wi, stride, pad, fin);
   else
@@ -696,6 +812,110 @@ __global__ void __launch_bounds__(256) k_stem3_bwd_mfma(const float* __restrict_
   }
 }
 
+
+// ------------------------------------------------------------------ stem weight gradient, 7x7 -> 64 features, on MFMA:
+// dW (64 x 147) = dY^T (64 x P) * patch (P x 147): 2 feature tiles x 5 tap tiles of 32 x 32 over the four waves (3, 3, 2, 2),
+// K = the 64 pixels of a tile.  Staging as in k_stem7_fwd_mfma (row-wise taps) + k_stem3_bwd_mfma (dy formed at commit).
+__global__ void __launch_bounds__(256, 2) k_stem7_bwd_mfma(const float* __restrict__ img, lhn_view y, lhn_gradview gy, float* __restrict__ dw,
+                                                           int Hi, int Wi, int stride, int pad, int nrep, int64_t rep_stride) {
+  constexpr int CO = 64, T = 147, LDY = CO + 4, LDV = 161, BMP = 64, G = 4, NR = 6;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* dYs = smem;                     // [BMP][LDY]
+  float* Vs = smem + BMP * LDY;          // [BMP][LDV], columns 147..159 stay zero
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int c4 = tid & 15, prow = tid >> 4;
+  const int cy = y.coff + 4 * c4;
+  const Xf4 yxf = lhn_load_xf(y, cy);
+  const Gr4 ygr = lhn_load_coef(gy, y.cstride, cy);
+  const int p = tid & (BMP - 1), g = tid >> 6;
+  for (int t = T + g; t < 160; t += G) Vs[p * LDV + t] = 0.f;
+  f16v acc[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  const int64_t total = (int64_t)y.N * y.H * y.W;
+  const int64_t ntiles = (total + BMP - 1) / BMP;
+  f4 yraw[4], zraw[4];
+  float v[NR * 7];
+  auto issue = [&](int64_t tile) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int64_t pix = tile * BMP + prow + 16 * j;
+      pix = pix < total ? pix : total - 1;
+      yraw[j] = *reinterpret_cast<const f4*>(y.data + pix * y.cstride + cy);
+      zraw[j] = *reinterpret_cast<const f4*>(gy.dz + pix * y.cstride + cy);
+    }
+    const int64_t pix = tile * BMP + p;
+    const int64_t pc = pix < total ? pix : total - 1;
+    const int wo = (int)(pc % y.W);
+    const int64_t r = pc / y.W;
+    const int ho = (int)(r % y.H), n = (int)(r / y.H);
+    const float* base = img + (int64_t)n * 3 * Hi * Wi;
+    const int iw0 = wo * stride - pad;
+#pragma unroll
+    for (int jr = 0; jr < NR; ++jr) {
+      const int row = min(g + G * jr, 20), c = row / 7, kh = row - 7 * c;
+      const int ih = ho * stride - pad + kh, ihc = min(max(ih, 0), Hi - 1);
+      const float* rb = base + ((int64_t)c * Hi + ihc) * Wi;
+#pragma unroll
+      for (int kw = 0; kw < 7; ++kw) {
+        const int iw = iw0 + kw, iwc = min(max(iw, 0), Wi - 1);
+        const float q = rb[iwc];
+        v[jr * 7 + kw] = (ih == ihc && iw == iwc) ? q : 0.f;
+      }
+    }
+  };
+  int64_t tile = blockIdx.x;
+  if (tile < ntiles) issue(tile);
+  for (; tile < ntiles; tile += gridDim.x) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int pp = prow + 16 * j;
+      const int64_t pix = tile * BMP + pp;
+      f4 d = (f4){0.f, 0.f, 0.f, 0.f};
+      if (pix < total) {
+        const int wo = (int)(pix % y.W);
+        const int64_t r = pix / y.W;
+        const f4 du = lhn_grad_du(y, gy, yxf, yraw[j], zraw[j], (int)(r / y.H), (int)(r % y.H), wo, cy);
+        d = ygr.A * du + ygr.B * yraw[j] + ygr.Cc;
+      }
+      *reinterpret_cast<f4*>(dYs + pp * LDY + 4 * c4) = d;
+    }
+#pragma unroll
+    for (int jr = 0; jr < NR; ++jr)
+      if (g + G * jr < 21)
+#pragma unroll
+        for (int kw = 0; kw < 7; ++kw) Vs[p * LDV + (g + G * jr) * 7 + kw] = v[jr * 7 + kw];
+    __syncthreads();
+    if (tile + gridDim.x < ntiles) issue(tile + gridDim.x);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int job = wave + 4 * i;                  // 10 jobs: feature tile = job & 1, tap tile = job >> 1
+      if (job < 10) {
+        const float* ar = dYs + lh * LDY + (job & 1) * 32 + l31;
+        const float* br = Vs + lh * LDV + (job >> 1) * 32 + l31;
+#pragma unroll 8
+        for (int ks = 0; ks < 32; ++ks) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[2 * ks * LDY], br[2 * ks * LDV], acc[i], 0, 0, 0);
+      }
+    }
+  }
+  dw += (size_t)(blockIdx.x % nrep) * rep_stride;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int job = wave + 4 * i;
+    if (job < 10) {
+      const int t = (job >> 1) * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = (job & 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (t < T) atomicAdd(dw + co * T + t, acc[i][r]);
+      }
+    }
+  }
+}
+
 static int dw_bwd_fused(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx, float* dw, int k,
                         int dil, int nrep, int64_t rep_stride, double* bn_sums, const float* bn_save, int bn_C, int bn_coff, hipStream_t s);
 
@@ -784,7 +1004,19 @@ extern "C" int lhn_conv_stem_bwd(const float* img, const lhn_view* y, const lhn_
   LHN_CHECK_ARG(pow2(y->C / 4) && y->C <= 256 && (k == 1 || k == 3 || k == 7), "lhn_conv_stem_bwd: Cout=%d k=%d", y->C, k);
   const int PL = 256 / (y->C / 4);
   const int g = grid_for((int64_t)y->N * y->H * y->W, PL, 4);
-  if (k == 3 && y->C == 32 && !lhn_dw_force_gather()) {
+  if (k == 7 && y->C == 64 && !lhn_dw_force_gather()) {
+    const size_t lds = (size_t)64 * (68 + 161) * 4;
+    static LhnKernelCfg cfg7;
+    int per_cu = 1;
+    if (!lhn_kernel_cfg(cfg7, &k_stem7_bwd_mfma, lds, 2, &per_cu)) {
+      lhn_set_error("lhn_conv_stem_bwd: cannot reserve %zu B of LDS", lds);
+      return 2;
+    }
+    const int64_t ntiles = ((int64_t)y->N * y->H * y->W + 63) / 64;
+    int grid = lhn_num_cus() * per_cu;
+    if (grid > ntiles) grid = (int)ntiles;
+    hipLaunchKernelGGL(k_stem7_bwd_mfma, dim3(grid), dim3(256), lds, (hipStream_t)stream, img, *y, *gy, dw, Hi, Wi, stride, pad, nrep, rep_stride);
+  } else if (k == 3 && y->C == 32 && !lhn_dw_force_gather()) {
     const size_t lds = (size_t)256 * (36 + 33) * 4;
     static LhnKernelCfg cfg;
     int per_cu = 1;
