@@ -16,6 +16,9 @@ def per_forward(d, counter):
     rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
     cuts = [i for i, r in enumerate(rows) if "k_stem" in r["Kernel_Name"] and "fwd" in r["Kernel_Name"]]
+    nsteps = int(os.environ.get("PMC_STEPS", "4"))
+    if len(cuts) % nsteps == 0 and len(cuts) > nsteps:             # several stem convolutions per forward (variant A)
+        cuts = cuts[::len(cuts) // nsteps]
     if len(cuts) < 3:
         sys.exit(f"{d}: need >= 3 forwards, found {len(cuts)}")
     body, steps = rows[cuts[1]:cuts[-1]], len(cuts) - 2

@@ -1,6 +1,6 @@
 """Summarise rocprofv3 CSV output.  Usage:
   prof_summary.py stats <dir> <steps> <out.md> <title>        (--kernel-trace --stats: *_kernel_stats.csv)
-  prof_summary.py steady <dir> <out.md> <title>               (--kernel-trace: *_kernel_trace.csv; steady-state per-step table)
+  prof_summary.py steady <dir> <out.md> <title> [steps]       (--kernel-trace: *_kernel_trace.csv; steady-state per-step table)
   prof_summary.py pmc <dir> <passes> <counter>               (--pmc X --kernel-trace: *_counter_collection.csv) -> prints sum/pass
 """
 import csv, glob, os, sys
@@ -13,15 +13,17 @@ def find(d, suffix):
     return f[-1]
 
 
-def steady(d, out, title, marker="k_stem_fwd"):
+def steady(d, out, title, nsteps=0):
     """Per-step kernel table from the kernel TRACE, steady state only: the trace is cut at every launch of `marker` (one per
     forward); the first step (module upload = hundreds of __amd_rocclr_copyBuffer launches, kernel attribute setup, plan
     build) is dropped, the rest averaged.  Replaces `stats` for anything quoted per step."""
     rows = list(csv.DictReader(open(find(d, "kernel_trace.csv"))))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    cuts = [i for i, r in enumerate(rows) if marker in r["Kernel_Name"] or "k_stem3_fwd" in r["Kernel_Name"]]
+    cuts = [i for i, r in enumerate(rows) if "k_stem" in r["Kernel_Name"] and "fwd" in r["Kernel_Name"]]
+    if nsteps and len(cuts) % nsteps == 0 and len(cuts) > nsteps:      # several stem convolutions per forward (variant A)
+        cuts = cuts[::len(cuts) // nsteps]
     if len(cuts) < 3:
-        sys.exit(f"need >= 3 steps, found {len(cuts)} {marker} launches")
+        sys.exit(f"need >= 3 steps, found {len(cuts)} stem launches")
     # a step begins a few setup launches (memset / dropout masks) before its stem: attribute those to the step they precede
     body = rows[cuts[1]:cuts[-1]]
     steps = len(cuts) - 2
@@ -73,7 +75,7 @@ def pmc(d, passes, counter):
 
 if __name__ == "__main__":
     if sys.argv[1] == "steady":
-        steady(sys.argv[2], sys.argv[3], sys.argv[4])
+        steady(sys.argv[2], sys.argv[3], sys.argv[4], int(sys.argv[5]) if len(sys.argv) > 5 else 0)
     elif sys.argv[1] == "stats":
         stats(sys.argv[2], int(sys.argv[3]), sys.argv[4], sys.argv[5])
     else:
