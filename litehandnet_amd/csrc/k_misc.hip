@@ -741,15 +741,28 @@ __global__ void __launch_bounds__(256) k_bn_bwd_reduce(lhn_view y, lhn_gradview 
     const int n = row / y.H, h = row - n * y.H;
     const f4 gate = y.gate ? *reinterpret_cast<const f4*>(y.gate + (size_t)n * y.cstride + ca) : (f4){1.f, 1.f, 1.f, 1.f};
     const size_t rbase = (size_t)row * y.W * y.cstride + ca;
-    for (int w = LHN_LANE0(pl, PL); w < y.W; w += PL) {
-      const size_t off = rbase + (size_t)w * y.cstride;
-      const f4 raw = *reinterpret_cast<const f4*>(y.data + off);
-      f4 e = *reinterpret_cast<const f4*>(g.dz + off) * gate;
-      if (g.dpool) e += lhn_dpool_sum(g, y, n, h, w, ca);
-      const f4 u = raw * xf.sc + xf.sh;
-      const f4 du = e * (f4){u.x > 0.f ? 1.f : xf.sl.x, u.y > 0.f ? 1.f : xf.sl.y, u.z > 0.f ? 1.f : xf.sl.z, u.w > 0.f ? 1.f : xf.sl.w};
-      s += du;
-      q += du * ((raw - mean) * inv);
+    // four pixels per thread and pass: eight independent loads in flight (one pixel at a time the 64x64 maps ran at 2.7 TB/s)
+    for (int w0 = LHN_LANE0(pl, PL); w0 < y.W; w0 += 4 * PL) {
+      f4 raw4[4], dz4[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const size_t off = rbase + (size_t)min(w0 + j * PL, y.W - 1) * y.cstride;
+        raw4[j] = *reinterpret_cast<const f4*>(y.data + off);
+        dz4[j] = *reinterpret_cast<const f4*>(g.dz + off);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int w = w0 + j * PL;
+        if (w < y.W) {
+          const f4 raw = raw4[j];
+          f4 e = dz4[j] * gate;
+          if (g.dpool) e += lhn_dpool_sum(g, y, n, h, w, ca);
+          const f4 u = raw * xf.sc + xf.sh;
+          const f4 du = e * (f4){u.x > 0.f ? 1.f : xf.sl.x, u.y > 0.f ? 1.f : xf.sl.y, u.z > 0.f ? 1.f : xf.sl.z, u.w > 0.f ? 1.f : xf.sl.w};
+          s += du;
+          q += du * ((raw - mean) * inv);
+        }
+      }
     }
   }
   double* st = sums + (size_t)(blockIdx.x % LHN_STAT_REPLICAS) * 2 * y.C;
