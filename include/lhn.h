@@ -96,6 +96,10 @@ typedef struct lhn_bnbwdfin {
 } lhn_bnbwdfin;
 
 int         lhn_version(void);
+/* 1 when the library runs in its deterministic mode (environment LHN_DETERMINISTIC=1, read once): every cross-workgroup sum
+ * has one writer per replica and replicas are folded in a fixed order, so two runs on the same inputs agree bit for bit
+ * (forward, gradients, running statistics).  Grids shrink to at most 16 workgroups: expect a 20-40x slower step. */
+int         lhn_deterministic(void);
 const char* lhn_last_error(void);
 int         lhn_device_ok(void);              /* 0 if a gfx950 device is usable                       */
 

@@ -42,7 +42,7 @@ class Buf(C.Structure):
 
 # every exported symbol of include/lhn.h (tests check the .so exports all of them)
 SYMBOLS = [
-    "lhn_version", "lhn_last_error", "lhn_device_ok",
+    "lhn_version", "lhn_deterministic", "lhn_last_error", "lhn_device_ok",
     "lhn_heatmap_encode", "lhn_heatmap_argmax", "lhn_heatmap_refine", "lhn_transform_preds",
     "lhn_heatmap_decode", "lhn_heatmap_decode_dark", "lhn_heatmap_decode_dark_udp", "lhn_heatmap_nms", "lhn_heatmap_topk", "lhn_pck_accuracy",
     "lhn_loss_balanced_mse_fwd", "lhn_loss_balanced_mse_bwd", "lhn_affine_warp_normalize", "lhn_affine_warp_normalize2", "lhn_random_flip", "lhn_simdr_encode", "lhn_simdr_loss_fwd", "lhn_simdr_loss_bwd",

@@ -109,22 +109,26 @@ __global__ void __launch_bounds__(256) k_att_bwd2(const float* __restrict__ wl, 
                                                   const float* __restrict__ dgate, float* __restrict__ dad,
                                                   float* __restrict__ dwl, float* __restrict__ dbl, int N, int C) {
   __shared__ float sdz[256], sa[256];
-  const int n = blockIdx.x;
-  const float* ad = save + (int64_t)n * C;
-  const float* g = save + (int64_t)N * C + (int64_t)n * C;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    const float gg = g[c];
-    const float dz = dgate[(int64_t)n * C + c] * gg * (1.f - gg);
-    sdz[c] = dz;
-    sa[c] = ad[c];
-    atomicAdd(dbl + c, dz);
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < C * C; i += blockDim.x) atomicAdd(dwl + i, sdz[i / C] * sa[i % C]);
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    float d = 0.f;
-    for (int co = 0; co < C; ++co) d += wl[co * C + c] * sdz[co];
-    dad[(int64_t)n * C + c] = d;
+  // one workgroup per sample; the deterministic mode launches ONE workgroup that walks the samples in order (the parameter
+  // gradients are sums over samples into one destination: every address then has a single writer and a fixed order)
+  for (int n = blockIdx.x; n < N; n += gridDim.x) {
+    __syncthreads();
+    const float* ad = save + (int64_t)n * C;
+    const float* g = save + (int64_t)N * C + (int64_t)n * C;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      const float gg = g[c];
+      const float dz = dgate[(int64_t)n * C + c] * gg * (1.f - gg);
+      sdz[c] = dz;
+      sa[c] = ad[c];
+      atomicAdd(dbl + c, dz);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * C; i += blockDim.x) atomicAdd(dwl + i, sdz[i / C] * sa[i % C]);
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      float d = 0.f;
+      for (int co = 0; co < C; ++co) d += wl[co * C + c] * sdz[co];
+      dad[(int64_t)n * C + c] = d;
+    }
   }
 }
 
@@ -252,7 +256,7 @@ extern "C" int lhn_att_mlp_bwd(const float* pooled, const float* gamma, const fl
   hipStream_t s = (hipStream_t)stream;
   float* dad = save + (int64_t)N * C * 2 + 2 * C;
   LHN_CHECK_ARG(stage == 0 || (gsum && stage >= 1 && stage <= 2 && count_scale >= 1), "lhn_att_mlp_bwd: stage %d needs gsum", stage);
-  if (stage != 2) hipLaunchKernelGGL(k_att_bwd2, dim3(N), dim3(256), 0, s, wl, save, dgate, dad, dwl, dbl, N, C);
+  if (stage != 2) hipLaunchKernelGGL(k_att_bwd2, dim3(lhn_deterministic_mode() ? 1 : N), dim3(256), 0, s, wl, save, dgate, dad, dwl, dbl, N, C);
   hipLaunchKernelGGL(k_att_bwd1, dim3((C + 31) / 32), dim3(1024), 0, s, pooled, gamma, beta, w3, dropmask, save, dad, dpool, cstride,
                      coff, H, W, dgamma, dbeta, dw3, db3, N, C, 1, stage, gsum, stage ? count_scale : 1.0, stage ? pgrad_scale : 1.f);
   LHN_CHECK_LAUNCH("lhn_att_mlp_bwd");
@@ -299,7 +303,8 @@ __global__ void __launch_bounds__(256) k_se_bwd(const float* __restrict__ pooled
                                                 float* __restrict__ dw2, float* __restrict__ db2, int N, int C, int J, int mode) {
   // mode 1: sigmoid(relu(v)) has derivative g(1-g) where v > 0, i.e. where g > 1/2, and 0 elsewhere (both layers)
   __shared__ float sp[256], sh[64], sdz[256], sdh[64];
-  const int n = blockIdx.x;
+  for (int n = blockIdx.x; n < N; n += gridDim.x) {      // (deterministic mode: one workgroup, samples in order; see k_att_bwd2)
+  __syncthreads();
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     sp[c] = pooled[(int64_t)n * C + c];
     const float g = save[(int64_t)N * J + (int64_t)n * C + c];
@@ -326,6 +331,7 @@ __global__ void __launch_bounds__(256) k_se_bwd(const float* __restrict__ pooled
     for (int j = 0; j < J; ++j) d += w1[j * C + c] * sdh[j];
     d *= inv_hw;
     for (int s = 0; s < LHN_DPOOL_SLOTS; ++s) dpool[((int64_t)n * LHN_DPOOL_SLOTS + s) * cs + coff + c] = d;
+  }
   }
 }
 
@@ -358,7 +364,7 @@ extern "C" int lhn_se_mlp_bwd2(const float* pooled, const float* w1, const float
                                int N, int C, int J, int mode, void* stream) {
   LHN_CHECK_ARG(pooled && w1 && w2 && save && dgate && dpool && dw1 && db1 && dw2 && db2, "lhn_se_mlp_bwd: null pointer");
   LHN_CHECK_ARG(C > 0 && C <= 256 && J > 0 && J <= 64 && N > 0 && H > 0 && W > 0, "lhn_se_mlp_bwd: C=%d J=%d", C, J);
-  hipLaunchKernelGGL(k_se_bwd, dim3(N), dim3(256), 0, (hipStream_t)stream, pooled, w1, w2, save, dgate, dpool, cstride, coff,
+  hipLaunchKernelGGL(k_se_bwd, dim3(lhn_deterministic_mode() ? 1 : N), dim3(256), 0, (hipStream_t)stream, pooled, w1, w2, save, dgate, dpool, cstride, coff,
                      1.f / (float)(H * W), dw1, db1, dw2, db2, N, C, J, mode);
   LHN_CHECK_LAUNCH("lhn_se_mlp_bwd");
   return 0;

@@ -789,11 +789,21 @@ __global__ void __launch_bounds__(256, (CIN == 32 && NTO == 1 && !NCHW) ? 4 : (C
   if (dbias) {
     if (NCHW) {
       // head: few channels; recompute per-channel sums is cheap -- done by a separate tiny pass on the host side
-    } else if (ych_ok) {
-      if (4 * yc4 + 0 < geo.wrows) atomicAdd(dbias + 4 * yc4 + 0, bsum.x);
-      if (4 * yc4 + 1 < geo.wrows) atomicAdd(dbias + 4 * yc4 + 1, bsum.y);
-      if (4 * yc4 + 2 < geo.wrows) atomicAdd(dbias + 4 * yc4 + 2, bsum.z);
-      if (4 * yc4 + 3 < geo.wrows) atomicAdd(dbias + 4 * yc4 + 3, bsum.w);
+    } else {
+      // column sums of dy: the threads that share a channel group meet in LDS in a FIXED order (dYs is free by now), then
+      // one add per channel into this block's gradient replica -- a single writer per address, like dW
+      f4* bred = reinterpret_cast<f4*>(dYs);            // [YRP][YC4] float4 <= 64 * LDY floats
+      bred[yr0 * YC4 + yc4] = ych_ok ? bsum : (f4){0.f, 0.f, 0.f, 0.f};
+      __syncthreads();
+      if (tid < YC4 && 4 * tid < cout) {
+        f4 t = (f4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < YRP; ++j) t += bred[j * YC4 + tid];
+        float* db = dbias + (size_t)(blockIdx.x % nrep) * rep_stride + 4 * tid;
+        if (4 * tid + 0 < geo.wrows) atomicAdd(db + 0, t.x);
+        if (4 * tid + 1 < geo.wrows) atomicAdd(db + 1, t.y);
+        if (4 * tid + 2 < geo.wrows) atomicAdd(db + 2, t.z);
+        if (4 * tid + 3 < geo.wrows) atomicAdd(db + 3, t.w);
+      }
     }
   }
 }
@@ -836,7 +846,7 @@ static int launch_pw_bwd_t(const lhn_view* x, const float* w, const lhn_view* y,
   hipLaunchKernelGGL((k_pw_bwd<CIN, NTO, NCHW>), dim3(grid), dim3(256), lds, s, *x, w, *y, g, dx, dx_acc, dw, dbias, stride, dy_nchw,
                      cout, M, ntiles, nrep, rep_stride, geo);
   if (dbias && dy_nchw)
-    hipLaunchKernelGGL(k_bias_grad_nchw, dim3(geo.wrows, y->N < 16 ? y->N : 16), dim3(256), 0, s, dy_nchw, dbias, y->N, cout,
+    hipLaunchKernelGGL(k_bias_grad_nchw, dim3(geo.wrows, lhn_deterministic_mode() ? 1 : (y->N < 16 ? y->N : 16)), dim3(256), 0, s, dy_nchw, dbias, y->N, cout,
                        y->H * y->W, geo.nchw_bstride);
   return 0;
 }

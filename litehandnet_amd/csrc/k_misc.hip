@@ -602,7 +602,9 @@ __global__ void __launch_bounds__(256) k_ca_bwd2(const float* __restrict__ w1, c
                                                  float* __restrict__ db1, float* __restrict__ dw2, float* __restrict__ db2,
                                                  int N, int C) {
   __shared__ float sdv[256], sdh[128], sa[256], shh[128];
-  const int n = blockIdx.x, Ch = C / 2;
+  const int Ch = C / 2;
+  for (int n = blockIdx.x; n < N; n += gridDim.x) {      // (deterministic mode: gridDim.x == 1, samples in order; see k_att_bwd2)
+  __syncthreads();
   const float* ahat = save + (int64_t)N * C + (int64_t)n * C;
   const float* h = save + (int64_t)N * C * 2 + (int64_t)n * Ch;
   const float* g = save + (int64_t)N * C * 2 + (int64_t)N * Ch + (int64_t)n * C;
@@ -619,7 +621,7 @@ __global__ void __launch_bounds__(256) k_ca_bwd2(const float* __restrict__ w1, c
   __syncthreads();
   if (second) {
     for (int i = threadIdx.x; i < C * Ch; i += blockDim.x) atomicAdd(dw2 + i, sdv[i / Ch] * shh[i % Ch]);
-    return;
+    continue;
   }
   for (int j = threadIdx.x; j < Ch; j += blockDim.x) {
     float d = 0.f;
@@ -634,6 +636,7 @@ __global__ void __launch_bounds__(256) k_ca_bwd2(const float* __restrict__ w1, c
     float d = 0.f;
     for (int j = 0; j < Ch; ++j) d += w1[j * C + c] * sdh[j];
     dahat[(int64_t)n * C + c] = d;
+  }
   }
 }
 // grid = C/32 blocks; thread = (channel lane, sample lane) as in k_ca1
@@ -987,6 +990,7 @@ int lhn_gate_bwd_reduce(const lhn_view* y, const float* dz, float* dgate, void* 
   int split = (y->H * y->W + 127) / 128;
   if (split < 1) split = 1;
   if (split > 32) split = 32;
+  if (lhn_deterministic_mode()) split = 1;          // one workgroup per image: a single (ordered) writer per d(gate) element
   hipLaunchKernelGGL(k_gate_bwd_reduce, dim3(y->N, split), dim3(256), 0, s, *y, dz, dgate);
   LHN_CHECK_LAUNCH("lhn_gate_bwd_reduce");
   return 0;
@@ -1004,7 +1008,7 @@ int lhn_ca_mlp_bwd(const float* pooled, const float* w3, const float* gamma, con
   hipStream_t s = (hipStream_t)stream;
   float* dahat = const_cast<float*>(save) + (int64_t)N * C * 3 + (int64_t)N * (C / 2) + 2 * C;
   LHN_CHECK_ARG(stage == 0 || (gsum && stage >= 1 && stage <= 2 && count_scale >= 1), "lhn_ca_mlp_bwd: stage %d needs gsum", stage);
-  if (stage != 2) hipLaunchKernelGGL(k_ca_bwd2, dim3(N, 2), dim3(256), 0, s, w1, w2, save, dgate, dahat, dw1, db1, dw2, db2, N, C);
+  if (stage != 2) hipLaunchKernelGGL(k_ca_bwd2, dim3(lhn_deterministic_mode() ? 1 : N, 2), dim3(256), 0, s, w1, w2, save, dgate, dahat, dw1, db1, dw2, db2, N, C);
   hipLaunchKernelGGL(k_ca_bwd1, dim3((C + 31) / 32), dim3(1024), 0, s, pooled, w3, gamma, dropmask, save, dahat, dpool, cstride, coff, H, W, dw3, dgamma, dbeta, N, C, 1, stage, gsum, stage ? count_scale : 1.0, stage ? pgrad_scale : 1.f);
   LHN_CHECK_LAUNCH("lhn_ca_mlp_bwd");
   return 0;

@@ -11,7 +11,23 @@ void lhn_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+// LHN_DETERMINISTIC=1 (read once): bit-reproducible results at a fraction of the speed.  Every accumulation that is shared
+// between workgroups goes through REPLICAS indexed by blockIdx (32 for BatchNorm sums, 16 for weight gradients, 16 for the
+// loss partials) that are folded in a fixed order afterwards; with at most 16 workgroups per launch each replica has ONE
+// writer, so no sum depends on arrival order.  lhn_num_cus() is what every persistent grid is sized from: reporting 2 CUs
+// (x at most 8 workgroups per CU) is the whole switch for those kernels; the per-sample attention-MLP backward kernels and
+// the gate reduction, which add straight into one destination, run as a single ordered workgroup / one workgroup per image.
+bool lhn_deterministic_mode() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("LHN_DETERMINISTIC");
+    v = (e && e[0] == '1') ? 1 : 0;
+  }
+  return v == 1;
+}
+
 int lhn_num_cus() {
+  if (lhn_deterministic_mode()) return 2;
   static std::once_flag once[LHN_MAX_DEVICES];
   static int cus[LHN_MAX_DEVICES];
   const int slot = lhn_device_slot();
@@ -26,6 +42,7 @@ int lhn_num_cus() {
 
 extern "C" {
 int lhn_version(void) { return LHN_VERSION; }
+int lhn_deterministic(void) { return lhn_deterministic_mode() ? 1 : 0; }
 const char* lhn_last_error(void) { return g_err; }
 int lhn_device_ok(void) {
   int n = 0;

@@ -66,6 +66,7 @@ static inline int lhn_device_slot() {
   return d % LHN_MAX_DEVICES;
 }
 int lhn_num_cus();   // lhn_api.cpp: CUs of the current device; grid caps for persistent grid-stride kernels
+bool lhn_deterministic_mode();   // LHN_DETERMINISTIC=1, see lhn_api.cpp
 
 #ifdef __HIPCC__
 // Workgroups of `kernel` (256 threads, `dyn_lds` bytes of dynamic LDS) that are resident on one CU at the same time: the

@@ -380,3 +380,20 @@ def test_run_to_run_spread(dev):
             assert float((g[k] - g0[k]).norm()) <= 1e-5 * (float(g0[k].norm()) + 1e-2 * gn), k
         for k in b0:
             assert rel(b[k], b0[k]) < 1e-6, k
+
+
+
+
+def test_deterministic_mode_is_bit_reproducible(dev):
+    """LHN_DETERMINISTIC=1 (include/lhn.h: lhn_deterministic): two runs of the same two training steps -- outputs, loss,
+    every parameter gradient, every running statistic, dropout on -- agree BIT FOR BIT for variants B, A, mynet, Lite-HRNet
+    and the stacked hourglass (scripts/check_determinism.py; without the switch the same script reports a mismatch for every one).
+    The switch is read once per process, so the check runs in a child process (started before it touches the GPU)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LHN_DETERMINISTIC="1", LHN_REPO=root)
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "check_determinism.py")], env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    assert "DET" in r.stdout and "False" not in r.stdout.split("DET")[1]
