@@ -126,6 +126,7 @@ __global__ void __launch_bounds__(256) k_att_bwd2(const float* __restrict__ wl, 
     for (int i = threadIdx.x; i < C * C; i += blockDim.x) atomicAdd(dwl + i, sdz[i / C] * sa[i % C]);
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
       float d = 0.f;
+#pragma unroll 8
       for (int co = 0; co < C; ++co) d += wl[co * C + c] * sdz[co];
       dad[(int64_t)n * C + c] = d;
     }
@@ -318,6 +319,7 @@ __global__ void __launch_bounds__(256) k_se_bwd(const float* __restrict__ pooled
   for (int i = threadIdx.x; i < C * J; i += blockDim.x) atomicAdd(dw2 + i, sdz[i / J] * sh[i % J]);
   for (int j = threadIdx.x; j < J; j += blockDim.x) {
     float d = 0.f;
+#pragma unroll 8
     for (int c = 0; c < C; ++c) d += w2[c * J + j] * sdz[c];
     if (mode == 1) d = sh[j] > 0.5f ? d * sh[j] * (1.f - sh[j]) : 0.f;
     else d = sh[j] > 0.f ? d : 0.f;
@@ -328,6 +330,7 @@ __global__ void __launch_bounds__(256) k_se_bwd(const float* __restrict__ pooled
   for (int i = threadIdx.x; i < J * C; i += blockDim.x) atomicAdd(dw1 + i, sdh[i / C] * sp[i % C]);
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     float d = 0.f;
+#pragma unroll 8
     for (int j = 0; j < J; ++j) d += w1[j * C + c] * sdh[j];
     d *= inv_hw;
     for (int s = 0; s < LHN_DPOOL_SLOTS; ++s) dpool[((int64_t)n * LHN_DPOOL_SLOTS + s) * cs + coff + c] = d;

@@ -625,7 +625,8 @@ __global__ void __launch_bounds__(256) k_ca_bwd2(const float* __restrict__ w1, c
   }
   for (int j = threadIdx.x; j < Ch; j += blockDim.x) {
     float d = 0.f;
-    for (int c = 0; c < C; ++c) d += w2[c * Ch + j] * sdv[c];
+#pragma unroll 8
+    for (int c = 0; c < C; ++c) d += w2[c * Ch + j] * sdv[c];      // (unrolled: the loads of a mat-vec row in flight together)
     d *= shh[j] > 0.f ? 1.f : 0.01f;
     sdh[j] = d;
     atomicAdd(db1 + j, d);
@@ -634,6 +635,7 @@ __global__ void __launch_bounds__(256) k_ca_bwd2(const float* __restrict__ w1, c
   for (int i = threadIdx.x; i < Ch * C; i += blockDim.x) atomicAdd(dw1 + i, sdh[i / C] * sa[i % C]);
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     float d = 0.f;
+#pragma unroll 8
     for (int j = 0; j < Ch; ++j) d += w1[j * C + c] * sdh[j];
     dahat[(int64_t)n * C + c] = d;
   }
