@@ -277,6 +277,8 @@ def main():
     extras = world == 1 and not args.no_extras
     # variant A is the model the reference registers as `litehandnet` (models/__init__.py:11): timed in the same run
     a_el, a_fwd = measure_variant("A", args, dev, world, rank) if (extras and args.variant == "B") else (None, None)
+    # BASELINE config 5 (stacked hourglass, Lite-HRNet-18): same batch / steps, so that the driver's own run times them too
+    others = {v: measure_variant(v, args, dev, world, rank) for v in ("H", "L")} if (extras and args.variant == "B") else {}
     if rank != 0:
         return
     copy_gbs = copy_bandwidth(dev)
@@ -301,6 +303,10 @@ def main():
                             "ms_per_step": round(a_ms, 3), "images_per_s": round(B * args.steps / a_el, 1),
                             "forward_images_per_s": round(B / (a_fwd * 1e-3), 1)}
         out["roofline_A"] = forward_roofline("A", B, a_fwd, copy_gbs)
+    for v, (v_el, v_fwd) in others.items():
+        out[f"variant_{v}"] = {"workload": f"{VARIANT_NAME[v]}, same batch / steps", "ms_per_step": round(v_el / args.steps * 1e3, 3),
+                               "images_per_s": round(B * args.steps / v_el, 1), "forward_images_per_s": round(B / (v_fwd * 1e-3), 1)}
+        out[f"roofline_{v}"] = forward_roofline(v, B, v_fwd, copy_gbs)
     if extras:
         out["roofline_kernels"] = kernel_rooflines(B, dev)
     if not args.no_cpu_baseline and world == 1:
