@@ -71,7 +71,9 @@ def _check_block(ours, ref, x, dev, seed=0, fwd_tol=FWD_TOL, grad_tol=GRAD_TOL, 
         assert p.grad is not None, k
         den = rp[k].grad.double().norm() + floor
         e = float((p.grad.cpu().double() - rp[k].grad.double()).norm() / den)
-        assert e < max(grad_tol, 3 * e32s[k], 1.5 * worst32), (k, e, e32s[k], worst32)
+        # LHN_STRICT_BARS=1 (meant for LHN_DETERMINISTIC=1 runs, where nothing varies between runs) drops the worst-case escape
+        esc = 0.0 if os.environ.get("LHN_STRICT_BARS") == "1" else 1.5 * worst32
+        assert e < max(grad_tol, 3 * e32s[k], esc), (k, e, e32s[k], worst32)
     # running statistics (momentum 0.1, unbiased variance) after one training step
     for k, v in ours.state_dict().items():
         if k.endswith("running_mean") or k.endswith("running_var"):
