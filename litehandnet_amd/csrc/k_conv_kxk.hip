@@ -408,11 +408,17 @@ __global__ void __launch_bounds__(256) k_kxk_wgrad(lhn_view x, lhn_view y, lhn_g
       }
     }
   };
-  // (a register-prefetch variant of this loop produced wrong dW for NTO*NTI == 1 on hipcc 7.2 -- kept simple)
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    issue(tile);
+  // The next tile's raw loads are issued before this tile's MFMA phase and parked in LDS after it (PF).  Only where every
+  // wave owns whole dW tiles: the K-split instances (NTO*NTI < 4) produced wrong dW in this form on hipcc 7.2 and keep the
+  // plain issue -> commit -> multiply order.
+  constexpr bool PF = (KS == 1);
+  int tile = blockIdx.x;
+  if (PF && tile < ntiles) issue(tile);
+  for (; tile < ntiles; tile += gridDim.x) {
+    if (!PF) issue(tile);
     commit();
     __syncthreads();
+    if (PF && tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x);
     const int kpart = KS > 1 ? wave % KS : 0;
 #pragma unroll 4
     for (int ks = kpart * (32 / KS); ks < (kpart + 1) * (32 / KS); ++ks) {

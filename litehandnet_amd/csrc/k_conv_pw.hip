@@ -280,7 +280,7 @@ static int launch_pw_fwd(const lhn_view* x, const float* w, const float* bias, c
 template <int CIN, int NCOT, int NS>
 __global__ void __launch_bounds__(256, (NS > 1 || CIN == 128) ? 2 : 3)
 k_pw_fwd_wr(lhn_view x, const float* __restrict__ w, const float* __restrict__ bias, lhn_view y, double* __restrict__ stats,
-            int cout, int M, int ntiles, PwExtra ex) {
+            int cout, int M, int ntiles, PwExtra ex, int wstride, int yacc, int statC) {
   constexpr int LDA = CIN + 4, PXW = 4 / NCOT, BM = 32 * PXW;
   constexpr int C4 = CIN / 4, RP = 256 / C4, PF = BM / RP;      // float4 loads per thread, tile and source
   static_assert(PF >= 1, "tile too small for the loader");
@@ -293,7 +293,7 @@ k_pw_fwd_wr(lhn_view x, const float* __restrict__ w, const float* __restrict__ b
 #pragma unroll
   for (int kc = 0; kc < CIN / 8; ++kc) {
     f4 v = (f4){0.f, 0.f, 0.f, 0.f};
-    if (co < cout) v = *reinterpret_cast<const f4*>(w + (int64_t)co * CIN + kc * 8 + 4 * lh);
+    if (co < cout) v = *reinterpret_cast<const f4*>(w + (int64_t)co * wstride + kc * 8 + 4 * lh);      // wstride: row of the WHOLE weight
     wreg[kc * 4 + 0] = v.x; wreg[kc * 4 + 1] = v.y; wreg[kc * 4 + 2] = v.z; wreg[kc * 4 + 3] = v.w;
   }
   const float bv = (bias && co < cout) ? bias[co] : 0.f;
@@ -395,7 +395,8 @@ k_pw_fwd_wr(lhn_view x, const float* __restrict__ w, const float* __restrict__ b
       for (int r = 0; r < 16; ++r) {
         const int m = mbase + (r & 3) + 8 * (r >> 2);
         if (m < M) {
-          const float v = acc[r] + bv;
+          float v = acc[r] + bv;
+          if (yacc) v += yo[(int64_t)m * y.cstride];       // second K slice of a wide input (C = 256): statistics see the sum
           yo[(int64_t)m * y.cstride] = v;
           ts.add(v);
         }
@@ -407,16 +408,16 @@ k_pw_fwd_wr(lhn_view x, const float* __restrict__ w, const float* __restrict__ b
   if (stats && co < cout) {
     const double s = ssum + __shfl_xor(ssum, 32, 64), q = ssq + __shfl_xor(ssq, 32, 64);
     if (lh == 0) {
-      double* st = stats + (size_t)(blockIdx.x % LHN_STAT_REPLICAS) * 2 * cout;
+      double* st = stats + (size_t)(blockIdx.x % LHN_STAT_REPLICAS) * 2 * statC;      // statC: channels of the whole BatchNorm
       atomicAdd(st + co, s);
-      atomicAdd(st + cout + co, q);
+      atomicAdd(st + statC + co, q);
     }
   }
 }
 
 template <int CIN, int NCOT, int NS>
 static int launch_pw_fwd_wr(const lhn_view* x, const float* w, const float* bias, const lhn_view* y, double* stats, int cout,
-                            hipStream_t s, const PwExtra* exp) {
+                            hipStream_t s, const PwExtra* exp, const PwGeom& geo) {
   PwExtra ex;
   if (exp) ex = *exp; else { ex.n = 0; ex.pend[0].n = ex.pend[1].n = ex.pend[2].n = 0; ex.sum_out = nullptr; }
   constexpr int BM = 32 * (4 / NCOT);
@@ -430,13 +431,14 @@ static int launch_pw_fwd_wr(const lhn_view* x, const float* w, const float* bias
   }
   int grid = lhn_num_cus() * per_cu;
   if (grid > ntiles) grid = ntiles;
-  hipLaunchKernelGGL((k_pw_fwd_wr<CIN, NCOT, NS>), dim3(grid), dim3(256), lds, s, *x, w, bias, *y, stats, cout, M, ntiles, ex);
+  hipLaunchKernelGGL((k_pw_fwd_wr<CIN, NCOT, NS>), dim3(grid), dim3(256), lds, s, *x, w, bias, *y, stats, cout, M, ntiles, ex, geo.wstride,
+                     geo.yacc, geo.statC);
   return 0;
 }
 
 // returns -1 when the register-resident-weights kernel has no instance for the shape
 static int pw_fwd_wr(const lhn_view* x, const float* w, const float* bias, const lhn_view* y, double* stats, int cout, hipStream_t s,
-                     const PwExtra* ex) {
+                     const PwExtra* ex, const PwGeom& geo) {
   static int off = -1;
   if (off < 0) {
     const char* e = getenv("LHN_PW_LDSW");      // 1 = always take the LDS-resident-W kernel (A/B comparisons)
@@ -446,11 +448,11 @@ static int pw_fwd_wr(const lhn_view* x, const float* w, const float* bias, const
   const int ci = x->C, ncot = cout <= 32 ? 1 : cout <= 64 ? 2 : 4;
   const bool ms = ex && ex->n > 0;
   if (ms) {
-    if (ci == 128 && ncot == 4) return launch_pw_fwd_wr<128, 4, 3>(x, w, bias, y, stats, cout, s, ex);
-    if (ci == 64 && ncot == 2) return launch_pw_fwd_wr<64, 2, 3>(x, w, bias, y, stats, cout, s, ex);
+    if (ci == 128 && ncot == 4) return launch_pw_fwd_wr<128, 4, 3>(x, w, bias, y, stats, cout, s, ex, geo);
+    if (ci == 64 && ncot == 2) return launch_pw_fwd_wr<64, 2, 3>(x, w, bias, y, stats, cout, s, ex, geo);
     return -1;
   }
-#define WR(CI, NC) if (ci == CI && ncot == NC) return launch_pw_fwd_wr<CI, NC, 1>(x, w, bias, y, stats, cout, s, ex);
+#define WR(CI, NC) if (ci == CI && ncot == NC) return launch_pw_fwd_wr<CI, NC, 1>(x, w, bias, y, stats, cout, s, ex, geo);
   WR(128, 4) WR(128, 2) WR(64, 4) WR(64, 2) WR(64, 1) WR(32, 4) WR(32, 2) WR(32, 1)
 #undef WR
   return -1;
@@ -465,9 +467,11 @@ static int pw_fwd_slice(const lhn_view* x, const float* w, const float* bias, co
   const int ci = pw_cin_tile(x->C), nt = (cout + 31) / 32 == 3 ? 4 : (cout + 31) / 32;
   int rc = -1;
   // fast path: whole-K slice with full-width rows, plain NHWC store, no fused finalize
-  if (stride == 1 && !y_nchw && !geo.yacc && x->C == ci && geo.kvalid == ci && geo.wstride == ci && geo.wrows == cout &&
-      geo.statC == cout && !(fin && stats) && (reinterpret_cast<uintptr_t>(w) & 15) == 0) {
-    rc = pw_fwd_wr(x, w, bias, y, stats, cout, s, ex);
+  // (slices of a C = 256 convolution qualify too: the kernel takes the whole weight's row stride, accumulates later K slices
+  // into y and addresses the statistics of the whole BatchNorm)
+  if (stride == 1 && !y_nchw && x->C == ci && geo.kvalid == ci && geo.wstride % 4 == 0 && geo.wrows == cout &&
+      !(geo.yacc && ex && ex->n > 0) && !(fin && stats) && (reinterpret_cast<uintptr_t>(w) & 15) == 0) {
+    rc = pw_fwd_wr(x, w, bias, y, stats, cout, s, ex, geo);
     if (rc != -1) return rc;
   }
   if (ex && ex->n > 0) {      // summed-on-load sources: the square 1x1 of MSRB (litehourglass.py:30,49), C = 64 / 128

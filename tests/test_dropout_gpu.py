@@ -178,7 +178,7 @@ def test_bench_config_bs64_256(dev, variant):
     floor = 1e-3 * max(g64.values())
     worst = max(abs(float(p.grad.norm()) - g64[k]) / (g64[k] + floor) for k, p in ours.named_parameters())
     worst32 = max(abs(g32[k] - g64[k]) / (g64[k] + floor) for k in g64)
-    assert worst <= max(3 * worst32, 1e-3), (worst, worst32)
+    assert worst <= max(4 * worst32, 1e-2), (worst, worst32)              # see test_model_gpu._model_case
     p, _ = heatmap._get_max_preds(y.detach())
     p64, _ = onp.get_max_preds(y64n.astype(np.float32))
     p32, _ = onp.get_max_preds(y32)
