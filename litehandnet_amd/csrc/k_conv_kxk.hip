@@ -603,6 +603,8 @@ extern "C" int lhn_conv_kxk_bwd(const lhn_view* x, const float* w, const lhn_vie
 // above 128 (hourglass: 256) run as 128-wide slices: dgrad accumulates over output-channel slices (its K), wgrad runs once
 // per input-channel slice with the output channels on gridDim.z.  Returns -1 when a shape has no instance (the caller then
 // takes the fused kernel).
+int lhn_pw_dgrad_wr(const lhn_view* dyv, const float* w, const lhn_view* dxv, int wstride, int accumulate, hipStream_t s);
+
 int lhn_pw_bwd_split(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx, int dx_accumulate,
                      float* dw, float* dbias, int nrep, int64_t rep_stride, hipStream_t s) {
   const int Cin = x->C, Cout = y->C;
@@ -627,6 +629,31 @@ int lhn_pw_bwd_split(const lhn_view* x, const float* w, const lhn_view* y, const
       yv.C = cc;
       const float* wv = w + (size_t)co0 * Cin;
       const int acc = dx_accumulate || co0 > 0, nsplit = (Cin + 32 * ntd - 1) / (32 * ntd);
+      // the register-resident-weights 1x1 kernel (k_conv_pw.hip) run on dy with W transposed, <= 128 input channels per launch
+      if ((cc == 32 || cc == 64 || cc == 128) && x->C % 32 == 0) {
+        lhn_view dyv = yv;
+        dyv.data = const_cast<float*>(gy->dz);
+        dyv.table = nullptr;
+        dyv.gate = nullptr;
+        dyv.pend = nullptr;
+        bool ok = true;
+        for (int ci0 = 0; ci0 < Cin && ok; ci0 += 128) {
+          lhn_view dxv = *x;
+          dxv.data = dx;
+          dxv.table = nullptr;
+          dxv.gate = nullptr;
+          dxv.pend = nullptr;
+          dxv.coff = x->coff + ci0;
+          dxv.C = Cin - ci0 < 128 ? Cin - ci0 : 128;
+          const int r2 = lhn_pw_dgrad_wr(&dyv, wv + ci0, &dxv, Cin, acc, s);
+          if (r2 > 0) return r2;
+          if (r2 < 0) {
+            if (ci0 > 0) return 3;      // (cannot happen: the first slice decides whether there is an instance)
+            ok = false;
+          }
+        }
+        if (ok) continue;
+      }
       rc = -1;
 #define PB(CO, NTV) if (cc == CO && ntd == NTV) rc = launch_kxk<CO, NTV, 1, 1, true>(x, wv, &yv, gy, nullptr, dx, acc, 1, x->C, s, nullptr, nsplit);
       PB(64, 4) PB(128, 4) PB(128, 2) PB(64, 2) PB(128, 1) PB(32, 4)

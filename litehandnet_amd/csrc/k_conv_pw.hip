@@ -280,7 +280,7 @@ static int launch_pw_fwd(const lhn_view* x, const float* w, const float* bias, c
 template <int CIN, int NCOT, int NS>
 __global__ void __launch_bounds__(256, (NS > 1 || CIN == 128) ? 2 : 3)
 k_pw_fwd_wr(lhn_view x, const float* __restrict__ w, const float* __restrict__ bias, lhn_view y, double* __restrict__ stats,
-            int cout, int M, int ntiles, PwExtra ex, int wstride, int yacc, int statC) {
+            int cout, int M, int ntiles, PwExtra ex, int wstride, int yacc, int statC, int wt) {
   constexpr int LDA = CIN + 4, PXW = 4 / NCOT, BM = 32 * PXW;
   constexpr int C4 = CIN / 4, RP = 256 / C4, PF = BM / RP;      // float4 loads per thread, tile and source
   static_assert(PF >= 1, "tile too small for the loader");
@@ -293,7 +293,13 @@ k_pw_fwd_wr(lhn_view x, const float* __restrict__ w, const float* __restrict__ b
 #pragma unroll
   for (int kc = 0; kc < CIN / 8; ++kc) {
     f4 v = (f4){0.f, 0.f, 0.f, 0.f};
-    if (co < cout) v = *reinterpret_cast<const f4*>(w + (int64_t)co * wstride + kc * 8 + 4 * lh);      // wstride: row of the WHOLE weight
+    if (co < cout) {
+      if (!wt) v = *reinterpret_cast<const f4*>(w + (int64_t)co * wstride + kc * 8 + 4 * lh);      // wstride: row of the WHOLE weight
+      else {      // transposed use (data gradient: out[ci] = sum_co dy[co] * W[co][ci]): feature `co` of this launch is a COLUMN of W
+        const float* wc = w + (int64_t)(kc * 8 + 4 * lh) * wstride + co;
+        v = (f4){wc[0], wc[wstride], wc[2 * (int64_t)wstride], wc[3 * (int64_t)wstride]};
+      }
+    }
     wreg[kc * 4 + 0] = v.x; wreg[kc * 4 + 1] = v.y; wreg[kc * 4 + 2] = v.z; wreg[kc * 4 + 3] = v.w;
   }
   const float bv = (bias && co < cout) ? bias[co] : 0.f;
@@ -417,7 +423,7 @@ k_pw_fwd_wr(lhn_view x, const float* __restrict__ w, const float* __restrict__ b
 
 template <int CIN, int NCOT, int NS>
 static int launch_pw_fwd_wr(const lhn_view* x, const float* w, const float* bias, const lhn_view* y, double* stats, int cout,
-                            hipStream_t s, const PwExtra* exp, const PwGeom& geo) {
+                            hipStream_t s, const PwExtra* exp, const PwGeom& geo, int wt = 0) {
   PwExtra ex;
   if (exp) ex = *exp; else { ex.n = 0; ex.pend[0].n = ex.pend[1].n = ex.pend[2].n = 0; ex.sum_out = nullptr; }
   constexpr int BM = 32 * (4 / NCOT);
@@ -432,13 +438,13 @@ static int launch_pw_fwd_wr(const lhn_view* x, const float* w, const float* bias
   int grid = lhn_num_cus() * per_cu;
   if (grid > ntiles) grid = ntiles;
   hipLaunchKernelGGL((k_pw_fwd_wr<CIN, NCOT, NS>), dim3(grid), dim3(256), lds, s, *x, w, bias, *y, stats, cout, M, ntiles, ex, geo.wstride,
-                     geo.yacc, geo.statC);
+                     geo.yacc, geo.statC, wt);
   return 0;
 }
 
 // returns -1 when the register-resident-weights kernel has no instance for the shape
 static int pw_fwd_wr(const lhn_view* x, const float* w, const float* bias, const lhn_view* y, double* stats, int cout, hipStream_t s,
-                     const PwExtra* ex, const PwGeom& geo) {
+                     const PwExtra* ex, const PwGeom& geo, int wt = 0) {
   static int off = -1;
   if (off < 0) {
     const char* e = getenv("LHN_PW_LDSW");      // 1 = always take the LDS-resident-W kernel (A/B comparisons)
@@ -452,10 +458,30 @@ static int pw_fwd_wr(const lhn_view* x, const float* w, const float* bias, const
     if (ci == 64 && ncot == 2) return launch_pw_fwd_wr<64, 2, 3>(x, w, bias, y, stats, cout, s, ex, geo);
     return -1;
   }
-#define WR(CI, NC) if (ci == CI && ncot == NC) return launch_pw_fwd_wr<CI, NC, 1>(x, w, bias, y, stats, cout, s, ex, geo);
+#define WR(CI, NC) if (ci == CI && ncot == NC) return launch_pw_fwd_wr<CI, NC, 1>(x, w, bias, y, stats, cout, s, ex, geo, wt);
   WR(128, 4) WR(128, 2) WR(64, 4) WR(64, 2) WR(64, 1) WR(32, 4) WR(32, 2) WR(32, 1)
 #undef WR
   return -1;
+}
+
+// Data gradient of a 1x1 on the same kernel: dx[.., ci0 + n] (+)= sum_k dy[.., k] * W[co0 + k][ci0 + n].  dyv: the plain dy
+// (k_dy_inplace ran) as a view of C = 32/64/128 output features, dxv: <= 128 input channels of the gradient buffer,
+// w = &W[co0][ci0], wstride = Cin of the whole weight.  Returns -1 when there is no instance for the shape.
+int lhn_pw_dgrad_wr(const lhn_view* dyv, const float* w, const lhn_view* dxv, int wstride, int accumulate, hipStream_t s) {
+  static int off = -1;
+  if (off < 0) {
+    const char* e = getenv("LHN_PW_LDSW");
+    off = (e && e[0] == '1') ? 1 : 0;
+  }
+  if (off) return -1;
+  PwGeom g;
+  g.wstride = wstride;
+  g.kvalid = dyv->C;
+  g.wrows = dxv->C;
+  g.yacc = accumulate;
+  g.statC = dxv->C;
+  g.nchw_bstride = 0;
+  return pw_fwd_wr(dyv, w, nullptr, dxv, nullptr, dxv->C, s, nullptr, g, 1);
 }
 
 // smallest tile width (16/32/64/128) that holds `c` input channels; 0 = none
