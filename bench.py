@@ -3,6 +3,7 @@
 litehandnet (MSRB hourglass = variant B by default), synthetic inputs resident in HBM, random-init weights.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N ...            (no WORLD_SIZE in the environment: starts its own N ranks, see spawn_ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (HBM, measured live with
@@ -253,6 +254,29 @@ def forward_roofline(variant, B, fwd_ms, copy_gbs):
     return r
 
 
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` run on its own (no WORLD_SIZE: nobody wrapped it in torch.distributed.run) starts its N
+    ranks itself -- the counterpart of the reference's `mp.spawn(main, nprocs=ngpus)` (dist_train.py:264-276).  The ranks
+    are fresh child processes (`python -m torch.distributed.run --standalone`-style rendezvous on 127.0.0.1) started BEFORE
+    this parent makes any GPU call; the parent relays rank 0's JSON line and the children's exit code and never touches
+    the GPU itself (no exec after HIP initialisation).  With fewer than N GPUs visible the ranks cannot run over RCCL (one
+    GPU per rank): that is an error unless LHN_DIST_BACKEND=gloo asks for the rehearsal backend (ranks share the GPUs)."""
+    import socket
+    import subprocess
+    ndev = torch.cuda.device_count()          # counts devices without initialising HIP
+    if ndev < n and os.environ.get("LHN_DIST_BACKEND") != "gloo":
+        raise SystemExit(f"bench.py --gpus {n}: only {ndev} GPU(s) visible (RCCL needs one per rank; LHN_DIST_BACKEND=gloo "
+                         "rehearses with shared GPUs)")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -265,10 +289,16 @@ def main():
     ap.add_argument("--sync-bn", action="store_true", help="cfg.TRAIN.syncBN: SyncBatchNorm over the process group (N > 1)")
     ap.add_argument("--dropout", type=float, default=0.3, help="Dropout2d p inside channel attention (reference: 0.3)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     from litehandnet_amd.train import init_distributed
 
     rank, local, world = init_distributed()
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} was started with WORLD_SIZE={world}: the two must agree")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     dev = torch.device("cuda", torch.cuda.current_device())

@@ -97,3 +97,15 @@ def test_gradient_handoff_follows_the_process_group():
     finally:
         dist.destroy_process_group()
     assert eng._via_autograd() is False
+
+
+def test_bench_gpus_must_match_world_size():
+    """`bench.py --gpus N` never reports a line for another rank count: a WORLD_SIZE that disagrees with --gpus is an error
+    (and with no WORLD_SIZE at all bench.py starts its own N ranks: tests/test_train_gpu.py)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         env=env, capture_output=True, text=True, timeout=300, cwd=root)
+    assert out.returncode != 0 and "WORLD_SIZE=1" in out.stderr

@@ -316,23 +316,17 @@ def test_synthetic_training_learns(dev):
 
 
 def test_bench_two_ranks_gloo_rehearsal(dev):
-    """bench.py --gpus 2 through torch.distributed.run with the gloo rehearsal backend (both ranks on cuda:0; RCCL needs one
-    GPU per rank): the launch path the driver uses for N > 1 -- rendezvous, parameter broadcast, side-stream gradient
-    exchange, barrier + max-over-ranks timing, ONE JSON line from rank 0 with n_gpus 2 and global batch 128.
-    Started as a child process before this test touches the GPU itself in it (the child owns its own HIP contexts)."""
+    """PLAIN `python bench.py --gpus 2` (the form of the driver's N = 1 command; no torch.distributed.run around it): bench.py
+    starts its two ranks itself before touching the GPU (dist_train.py:264-276 `mp.spawn`), here with the gloo rehearsal
+    backend (both ranks on cuda:0; RCCL needs one GPU per rank) -- rendezvous, parameter broadcast, side-stream gradient
+    exchange, barrier + max-over-ranks timing, ONE JSON line from rank 0 with n_gpus 2 and global batch 128."""
     import json
-    import socket
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    env = dict(os.environ, LHN_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(LHN_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -341,6 +335,11 @@ def test_bench_two_ranks_gloo_rehearsal(dev):
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 128 and d["config"]["parallelism"] == "dp2"
     assert d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["value"] > 0
     assert abs(d["value"] - 128 * 3 / (d["ms_per_step"] * 3e-3)) <= 1e-2 * d["value"]      # whole-job images / max-over-ranks time
+    # without the rehearsal switch two ranks on a one-GPU box must fail loudly, not measure one GPU
+    if torch.cuda.device_count() < 2:
+        env.pop("LHN_DIST_BACKEND")
+        bad = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=120, cwd=root)
+        assert bad.returncode != 0 and "GPU" in bad.stderr
 
 
 def test_run_to_run_spread(dev):
