@@ -418,10 +418,15 @@ typedef struct lhn_buf {
 void* lhn_plan_create(const lhn_buf* bufs, int nbufs, const lhn_op* fwd, int nfwd, const lhn_op* bwd, int nbwd);
 void  lhn_plan_destroy(void* plan);
 /* io: phase 0 {image NCHW, heatmap NCHW out}; phase 1 {image NCHW, d(heatmap) NCHW}.
- * training: bit 0 = train-mode BatchNorm (batch statistics, running statistics updated); bit 1 (LHN_RUN_TABLES_CURRENT,
+ * training: a bit set -- bit 0 = train-mode BatchNorm (batch statistics, running statistics updated); bit 1 (LHN_RUN_TABLES_CURRENT,
  * eval only) = the workspace's per-buffer BatchNorm tables were built by an earlier eval run of THIS plan and no parameter
  * or running statistic changed since: the launches that only rebuild them are skipped. */
 #define LHN_RUN_TABLES_CURRENT 2
+/* bit 2: the launch sequence of this (phase, pointer set) may be captured into a hipGraph on its second sighting and replayed
+ * afterwards (one graph launch instead of hundreds of kernel launches: Lite-HRNet runs 2,600 small launches per step and is
+ * launch-bound).  Needs a real stream (the legacy default stream cannot be captured); a plan whose pointers never repeat
+ * falls back to plain launches.  LHN_GRAPH=1 in the environment sets it for every call. */
+#define LHN_RUN_GRAPH 4
 int   lhn_plan_run(void* plan, int phase, void* workspace, void* const* params, void* const* grads,
                    void* const* io, int training, int grad_replicas, int64_t grad_rep_stride, void* stream);
 

@@ -13,21 +13,44 @@ static inline bool pow2i(int v) { return v > 0 && (v & (v - 1)) == 0; }
 // ------------------------------------------------------------------ BatchNorm finalize
 // torch.nn.BatchNorm2d: normalise with the biased batch variance, update running_var with the
 // unbiased one, eps inside the sqrt, momentum = exponential average factor.
-__global__ void k_bn_finalize(const double* __restrict__ stats, const float* __restrict__ gamma,
+// One workgroup of up to 1024 threads: thread (c, g) folds replicas g, g + G, ... of channel c (all of its loads in flight
+// together), the G partial sums of a channel meet in LDS in a fixed order (run-to-run reproducible), one thread per channel
+// does the arithmetic.  (The first version walked one thread per channel through 64 dependent double loads: 6 us per launch,
+// 52 launches per forward of the MSRB hourglass.)
+#define LHN_FIN_THREADS 1024
+__global__ void __launch_bounds__(LHN_FIN_THREADS) k_bn_finalize(const double* __restrict__ stats, const float* __restrict__ gamma,
                               const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
                               int64_t* __restrict__ nbt, float* __restrict__ table, int cs, int coff, int C,
                               float* __restrict__ save, double count, float eps, float momentum, float slope, int training,
                               const float* __restrict__ cbias, int SC) {
   // SC = channels of the statistics / save layout (>= C: a convolution whose output view is padded to a multiple of 4
   // accumulates SC columns, the BatchNorm owns the first C)
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+  __shared__ double part[2 * LHN_FIN_THREADS];
+  const int nt = blockDim.x;
+  int G = nt / C;
+  G = G < 1 ? 1 : (G > LHN_STAT_REPLICAS ? LHN_STAT_REPLICAS : G);
+  for (int c0 = 0; c0 < C; c0 += nt) {           // (one round unless C > 1024)
+    const int g = threadIdx.x / C, c = c0 + (G > 1 ? threadIdx.x - g * C : threadIdx.x);
+    if (c0) __syncthreads();
+    if (training && g < G && c < C) {
+      double s1 = 0, s2 = 0;
+#pragma unroll 4
+      for (int r = g; r < LHN_STAT_REPLICAS; r += G) {
+        s1 += stats[(size_t)r * 2 * SC + c];
+        s2 += stats[(size_t)r * 2 * SC + SC + c];
+      }
+      part[2 * threadIdx.x] = s1;
+      part[2 * threadIdx.x + 1] = s2;
+    }
+    __syncthreads();
+    if (g != 0 || c >= C) continue;
     double mean, var;
     const double cb = cbias ? (double)cbias[c] : 0.0;   // bias of the conv in front: stored output excludes it
     if (training) {
       double s1 = 0, s2 = 0;
-      for (int r = 0; r < LHN_STAT_REPLICAS; ++r) {
-        s1 += stats[(size_t)r * 2 * SC + c];
-        s2 += stats[(size_t)r * 2 * SC + SC + c];
+      for (int k = 0; k < G; ++k) {
+        s1 += part[2 * (k * C + threadIdx.x)];
+        s2 += part[2 * (k * C + threadIdx.x) + 1];
       }
       mean = s1 / count;
       var = s2 / count - mean * mean;
@@ -42,8 +65,8 @@ __global__ void k_bn_finalize(const double* __restrict__ stats, const float* __r
       var = rvar[c];
     }
     const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
-    const float sc = g * invstd;
+    const float gm = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const float sc = gm * invstd;
     table[coff + c] = sc;
     table[cs + coff + c] = b - (float)mean * sc;
     table[2 * cs + coff + c] = slope;
@@ -794,14 +817,33 @@ __global__ void __launch_bounds__(256) k_bn_bwd_reduce(lhn_view y, lhn_gradview 
   if (fin.counter && lhn_last_block(fin.counter)) lhn_bn_bwd_finalize_block(fin, sums, save);
 }
 // dy = A*du + B*y + C with  A = s, B = -s*invstd*dgamma/n, C = -s*dbeta/n + s*invstd*mean*dgamma/n, s = gamma*invstd
-__global__ void k_bn_bwd_finalize(const double* __restrict__ sums, const float* __restrict__ gamma,
+__global__ void __launch_bounds__(LHN_FIN_THREADS) k_bn_bwd_finalize(const double* __restrict__ sums, const float* __restrict__ gamma,
                                   const float* __restrict__ save, float* __restrict__ coef, int cs, int coff, int C,
                                   double count, float* __restrict__ dgamma, float* __restrict__ dbeta, float pgrad_scale, int SC) {
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+  // replica fold as in k_bn_finalize
+  __shared__ double part[2 * LHN_FIN_THREADS];
+  const int nt = blockDim.x;
+  int G = nt / C;
+  G = G < 1 ? 1 : (G > LHN_STAT_REPLICAS ? LHN_STAT_REPLICAS : G);
+  for (int c0 = 0; c0 < C; c0 += nt) {
+    const int g = threadIdx.x / C, c = c0 + (G > 1 ? threadIdx.x - g * C : threadIdx.x);
+    if (c0) __syncthreads();
+    if (g < G && c < C) {
+      double s1 = 0, s2 = 0;
+#pragma unroll 4
+      for (int r = g; r < LHN_STAT_REPLICAS; r += G) {
+        s1 += sums[(size_t)r * 2 * SC + c];
+        s2 += sums[(size_t)r * 2 * SC + SC + c];
+      }
+      part[2 * threadIdx.x] = s1;
+      part[2 * threadIdx.x + 1] = s2;
+    }
+    __syncthreads();
+    if (g != 0 || c >= C) continue;
     double db = 0, dg = 0;
-    for (int r = 0; r < LHN_STAT_REPLICAS; ++r) {
-      db += sums[(size_t)r * 2 * SC + c];
-      dg += sums[(size_t)r * 2 * SC + SC + c];
+    for (int k = 0; k < G; ++k) {
+      db += part[2 * (k * C + threadIdx.x)];
+      dg += part[2 * (k * C + threadIdx.x) + 1];
     }
     const double mean = save[c], inv = save[SC + c], s = (double)(gamma ? gamma[c] : 1.f) * inv;
     coef[coff + c] = (float)s;
@@ -844,7 +886,11 @@ int lhn_bn_finalize2(const double* stats, const float* gamma, const float* beta,
   LHN_CHECK_ARG(table && C > 0 && coff >= 0 && coff + C <= cstride && stat_channels >= C, "lhn_bn_finalize: bad table slice");
   LHN_CHECK_ARG(training ? (stats != nullptr) : (running_mean && running_var), "lhn_bn_finalize: missing statistics");
   LHN_CHECK_ARG(!training || count >= 1, "lhn_bn_finalize: count");
-  hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(C <= 64 ? 64 : (C <= 128 ? 128 : 256)), 0, (hipStream_t)stream, stats,
+  // training: (channel, replica group) threads, a whole number of channel rows; eval: one thread per channel
+  int nt = training ? (C >= LHN_FIN_THREADS ? LHN_FIN_THREADS : (LHN_FIN_THREADS / C > LHN_STAT_REPLICAS ? LHN_STAT_REPLICAS : LHN_FIN_THREADS / C) * C)
+                    : (C <= 64 ? 64 : (C <= 128 ? 128 : 256));
+  nt = (nt + 63) / 64 * 64;
+  hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(nt), 0, (hipStream_t)stream, stats,
                      gamma, beta, running_mean, running_var, nbt, table, cstride, coff, C, save, count, eps, momentum,
                      slope, training, conv_bias, stat_channels);
   LHN_CHECK_LAUNCH("lhn_bn_finalize");
@@ -1032,7 +1078,9 @@ int lhn_bn_bwd_finalize(const double* sums, const float* gamma, const float* sav
 int lhn_bn_bwd_finalize2(const double* sums, const float* gamma, const float* save, float* coef, int cstride, int coff, int C,
                          int stat_channels, double count, float* dgamma, float* dbeta, float pgrad_scale, void* stream) {
   LHN_CHECK_ARG(sums && save && coef && C > 0 && coff + C <= cstride && stat_channels >= C, "lhn_bn_bwd_finalize: bad args");
-  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(1), dim3(C <= 64 ? 64 : (C <= 128 ? 128 : 256)), 0, (hipStream_t)stream, sums, gamma, save, coef, cstride, coff, C, count, dgamma, dbeta, pgrad_scale, stat_channels);
+  int nt = C >= LHN_FIN_THREADS ? LHN_FIN_THREADS : (LHN_FIN_THREADS / C > LHN_STAT_REPLICAS ? LHN_STAT_REPLICAS : LHN_FIN_THREADS / C) * C;
+  nt = (nt + 63) / 64 * 64;
+  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(1), dim3(nt), 0, (hipStream_t)stream, sums, gamma, save, coef, cstride, coff, C, count, dgamma, dbeta, pgrad_scale, stat_channels);
   LHN_CHECK_LAUNCH("lhn_bn_bwd_finalize");
   return 0;
 }

@@ -620,7 +620,7 @@ static uint64_t hash_ptrs(void* const* a, const std::vector<lhn_op>& ops, bool g
   return h;
 }
 
-// Runs one phase.  With LHN_GRAPH=1 the launch sequence of a (phase, pointer set) is captured into a hipGraph the second
+// Runs one phase.  With LHN_RUN_GRAPH in `training` (or LHN_GRAPH=1 in the environment) the launch sequence of a (phase, pointer set) is captured into a hipGraph the second
 // time it is seen and replayed afterwards (one graph launch instead of 150-400 kernel launches: the small-batch /
 // low-resolution end of the network is launch-bound).  The plan is static, so a graph is valid for as long as the
 // workspace, parameter, gradient and io pointers repeat; a different pointer set simply gets its own graph (LRU of 8),
@@ -633,7 +633,9 @@ int lhn_plan_run(void* plan, int phase, void* ws, void* const* params, void* con
   LHN_CHECK_ARG(phase == 0 || (phase == 1 && grads), "lhn_plan_run: phase %d", phase);
   Plan* P = static_cast<Plan*>(plan);
   // (the legacy default stream cannot be captured: graphs need the caller to run on a real stream)
-  if (!graphs_enabled() || stream == nullptr || P->graph_misses > 64) return run_ops(P, phase, ws, params, grads, io, training, nrep, rstr, stream);
+  const bool want_graph = graphs_enabled() || (training & LHN_RUN_GRAPH) != 0;
+  training &= ~LHN_RUN_GRAPH;
+  if (!want_graph || stream == nullptr || P->graph_misses > 64) return run_ops(P, phase, ws, params, grads, io, training, nrep, rstr, stream);
   const std::vector<lhn_op>& ops = phase == 0 ? P->fwd : P->bwd;
   const uint64_t ph = hash_ptrs(params, ops, false), gh = phase == 1 ? hash_ptrs(grads, ops, true) : 0;
   hipStream_t s = static_cast<hipStream_t>(stream);

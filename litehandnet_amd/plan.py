@@ -390,6 +390,7 @@ class PlanBuilder:
         save = self._ws("misc", (5 * self.N * Cc + self.N * (Cc // 2) + 2 * Cc) * 4)
         mask = self._ws("mask", self.N * Cc * 4) if self.p_drop > 0 else None
         rec = dict(op=CA_MLP, y=y, ca=ca, pooled=pooled, save=save, mask=mask, gsum=self._ws("misc", 2 * Cc * 8))
+
         if self.with_backward:
             rec["gsum_b"] = self._ws("misc", 2 * Cc * 8)
             rec["dgate"] = self._ws("misc", self.N * Cc * 4)
@@ -975,6 +976,26 @@ class PlanBuilder:
     _no_grad_buf = -1   # the image never needs a gradient
 
 
+_SIDE_STREAMS = {}
+
+
+def _graph_default(n_ops):
+    """hipGraph replay of a plan's launch sequence (LHN_RUN_GRAPH): only with LHN_GRAPH=1.  Measured on MI355X (round 3, same
+    box, Lite-HRNet-18 at batch 64, 663 forward ops / 2,600 launches per step): replay 38.83 ms per step and 13.22 ms per
+    forward against 37.16 / 12.43 ms with plain launches -- outside the profiler the host keeps up with the queue, and a
+    graph launch adds its fixed cost per phase.  So replay is NOT a default for any plan size."""
+    return os.environ.get("LHN_GRAPH", "") == "1"
+
+
+def _side_stream(device):
+    """One non-default stream per device: the legacy default stream cannot be captured into a hipGraph."""
+    key = torch.device(device).index
+    s = _SIDE_STREAMS.get(key)
+    if s is None:
+        s = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return s
+
+
 _TRAIN_RUNS = 0      # bumped by every train-mode forward of any plan in this process (see CompiledPlan.run)
 _TABLE_EPOCH = 0     # bumped by invalidate_tables(): state changed where neither torch's version counters nor data pointers see it
 
@@ -999,6 +1020,7 @@ class CompiledPlan:
         if not self.handle:
             raise _lib.LhnError("lhn_plan_create: " + L.lhn_last_error().decode())
         self.n_fwd, self.n_bwd = nf, nb
+        self.use_graph = _graph_default(nf)
         self.ws = torch.empty(pb.total_bytes, dtype=torch.uint8, device=device)
         # tables start as the identity transform (scale 1, shift 0, slope 1); FINALIZE overwrites BN slices
         for b in pb.bufs:
@@ -1090,6 +1112,20 @@ class CompiledPlan:
             # running statistics behind torch's back, so any training run anywhere invalidates every plan's tables)
             if not training and self._tables_current():
                 mode |= 2              # LHN_RUN_TABLES_CURRENT
+        if self.use_graph:
+            # replayed as a hipGraph (LHN_RUN_GRAPH).  On torch's default stream -- which cannot be captured -- the phase runs
+            # on a side stream ordered after everything queued so far, and the default stream waits for it: the caller sees
+            # the usual stream semantics (no exec, no capture of the default stream).
+            cur = torch.cuda.current_stream(self.ws.device)
+            if cur.cuda_stream == 0:
+                side = _side_stream(self.ws.device)
+                side.wait_stream(cur)
+                rc = L.lhn_plan_run(C.c_void_p(self.handle), phase, _lib.ptr(self.ws), self._params, self._grads, self._io,
+                                    mode | 4, int(grad_replicas), C.c_int64(int(grad_rep_stride)), C.c_void_p(side.cuda_stream))
+                cur.wait_stream(side)
+                _lib.check(rc, "lhn_plan_run")
+                return
+            mode |= 4
         rc = L.lhn_plan_run(C.c_void_p(self.handle), phase, _lib.ptr(self.ws), self._params, self._grads, self._io,
                             mode, int(grad_replicas), C.c_int64(int(grad_rep_stride)), _lib.stream())
         _lib.check(rc, "lhn_plan_run")

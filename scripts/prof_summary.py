@@ -1,6 +1,7 @@
 """Summarise rocprofv3 CSV output.  Usage:
   prof_summary.py stats <dir> <steps> <out.md> <title>        (--kernel-trace --stats: *_kernel_stats.csv)
   prof_summary.py steady <dir> <out.md> <title> [steps]       (--kernel-trace: *_kernel_trace.csv; steady-state per-step table)
+  prof_summary.py levels <dir> <levels.json> <out.md> <title>  (forward trace + prof_step.py --dump-levels: per resolution level)
   prof_summary.py pmc <dir> <passes> <counter>               (--pmc X --kernel-trace: *_counter_collection.csv) -> prints sum/pass
 """
 import csv, glob, os, sys
@@ -47,6 +48,48 @@ def steady(d, out, title, nsteps=0):
     print(open(out).read()[:3500])
 
 
+def levels(d, levels_json, out, title):
+    """Forward time and launch count PER RESOLUTION LEVEL (the map size an op works on: 128, 64, 32, 16, 8): the kernel trace of
+    `prof_step.py --fwd-only --dump-levels L.json` is walked in launch order against the plan's op list (every library launch
+    must belong to the kernel families of the current or the next op, anything else aborts); torch's own kernels (dropout
+    masks) and memsets are listed under `other`.  Steady state: first forward dropped."""
+    import json
+    ops = json.load(open(levels_json))
+    rows = list(csv.DictReader(open(find(d, "kernel_trace.csv"))))
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    cuts = [i for i, r in enumerate(rows) if "k_stem" in r["Kernel_Name"] and "fwd" in r["Kernel_Name"]]
+    nstem = sum(1 for o in ops if "k_stem" in o["families"])
+    cuts = cuts[::max(1, nstem)]
+    if len(cuts) < 3:
+        sys.exit("need >= 3 forwards")
+    agg, steps = {}, 0
+    for a, b in zip(cuts[1:-1], cuts[2:]):
+        steps += 1
+        j = 0
+        for r in rows[a:b]:
+            name = r["Kernel_Name"]
+            t = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+            lib = name.startswith("k_") or name.startswith("void k_")
+            key = "other"
+            if lib:
+                base = name.replace("void ", "")
+                if j == len(ops) or not any(base.startswith(f) for f in ops[j]["families"]):
+                    sys.exit(f"launch {j} of a forward is {name[:50]}, the plan expects {ops[j]['families'] if j < len(ops) else 'nothing'}")
+                key = ops[j]["size"]
+                j += 1
+            e = agg.setdefault(key, [0, 0])
+            e[0] += 1
+            e[1] += t
+    tot = sum(v[1] for v in agg.values())
+    with open(out, "w") as f:
+        f.write(f"# {title}\n\nper resolution level, steady state ({steps} forwards): {tot / steps / 1e6:.3f} ms kernel time, "
+                f"{sum(v[0] for v in agg.values()) / steps:.0f} launches per forward\n\n| map size | launches | ms | avg us | % |\n|---|---|---|---|---|\n")
+        for k in sorted(agg, key=lambda k: -(k if isinstance(k, int) else 0)):
+            n, t = agg[k]
+            f.write(f"| {k} | {n / steps:g} | {t / steps / 1e6:.3f} | {t / n / 1e3:.1f} | {100 * t / tot:.1f} |\n")
+    print(open(out).read())
+
+
 def stats(d, steps, out, title):
     rows = list(csv.DictReader(open(find(d, "kernel_stats.csv"))))
     tot = sum(float(r["TotalDurationNs"]) for r in rows)
@@ -76,6 +119,8 @@ def pmc(d, passes, counter):
 if __name__ == "__main__":
     if sys.argv[1] == "steady":
         steady(sys.argv[2], sys.argv[3], sys.argv[4], int(sys.argv[5]) if len(sys.argv) > 5 else 0)
+    elif sys.argv[1] == "levels":
+        levels(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5])
     elif sys.argv[1] == "stats":
         stats(sys.argv[2], int(sys.argv[3]), sys.argv[4], sys.argv[5])
     else:

@@ -86,6 +86,16 @@ def test_model_H2_256_golden(dev, golden_dir):
     _model_case(dev, golden_dir, "H2_256", variant="H", num_stack=2)
 
 
+def test_hourglass_whole_model_gradients_elementwise(dev):
+    """Every parameter gradient of the whole 2-stack network ELEMENT BY ELEMENT against the float64 oracle (the golden cases above
+    compare gradient norms only): stack wiring, the padded 24-channel prediction copy feeding merge_preds, the two head
+    convolutions, the stacked [N, S, K, H, W] output gradient (hourglassnet.py:124-136)."""
+    from litehandnet_amd import get_model
+    cfg = litehandnet_cfg("H", num_stack=2)
+    ours, ref = get_model(cfg), torch_ref.get_model(cfg)
+    _check_block(ours, ref, synth.synth_images(2, 128, 61), dev, seed=62, no_dx=True, grad_tol=2e-2)
+
+
 def test_hourglass_eval_and_output_shape(dev):
     """eval mode (running statistics) against the float64 oracle; output is [N, num_stack, K, H/4, W/4] even for one stack."""
     from litehandnet_amd import get_model

@@ -125,6 +125,16 @@ def test_model_L18_256_golden(dev, golden_dir):
     _model_case(dev, golden_dir, "L18_256", variant="L", depth=18)
 
 
+def test_litehrnet_whole_model_gradients_elementwise(dev):
+    """Every parameter gradient of the whole Lite-HRNet-18 element by element against the float64 oracle (the golden cases compare
+    gradient norms): cross-branch routing, the twice-evaluated fuse layers, the iterative head (lite_hrnet.py:145-282)."""
+    from litehandnet_amd import get_model
+    cfg = litehandnet_cfg("L", depth=18)
+    cfg.MODEL["ca_dropout"] = 0.0
+    ours, ref = get_model(cfg), torch_ref.get_model(cfg)
+    _check_block(ours, ref, synth.synth_images(4, 128, 63), dev, seed=64, no_dx=True, grad_tol=2e-2)
+
+
 def test_litehrnet_eval(dev):
     from litehandnet_amd import get_model
     cfg = litehandnet_cfg("L", depth=18)

@@ -10,8 +10,15 @@ import torch
 from litehandnet_amd.config import litehandnet_cfg
 from oracle import heatmap_np as onp
 from oracle import synth, torch_ref
+from conftest import parity_record
 
 pytestmark = pytest.mark.gpu
+STRICT = os.environ.get("LHN_STRICT_BARS") == "1"
+# whole-network gradient NORMS: floor 1e-3 of the largest norm; factor 3 x the reference's own fp32 error in the strict
+# (deterministic) run, 4 x in the default mode where the arrival order of the atomics moves the worst parameter run to run
+MODEL_GRAD_FACTOR = 3.0 if STRICT else float(os.environ.get("LHN_MODEL_GRAD_FACTOR", "3.0"))
+MODEL_GRAD_FLOOR = 1e-3
+WHOLE_MODEL_GRAD_TOL = 2e-2      # elementwise gradients of whole small networks (chaotic ReLU flips, see test_width_256)
 
 FWD_TOL = 1e-4     # fp32 vs the float64 oracle: max-abs error relative to the tensor's max-abs
 GRAD_TOL = 1e-3    # gradients vs the float64 oracle, relative to the gradient's norm (floored, see _check_block)
@@ -67,13 +74,20 @@ def _check_block(ours, ref, x, dev, seed=0, fwd_tol=FWD_TOL, grad_tol=GRAD_TOL, 
     # block (weight-gradient atomics make our low bits vary run to run; a parameter sitting exactly at 3x must not flake)
     e32s = {k: float((rp32[k].grad.double() - rp[k].grad.double()).norm() / (rp[k].grad.double().norm() + floor)) for k in rp}
     worst32 = max(e32s.values())
+    worst_e, worst_ratio, worst_k = 0.0, 0.0, ""
     for k, p in ours.named_parameters():
         assert p.grad is not None, k
         den = rp[k].grad.double().norm() + floor
         e = float((p.grad.cpu().double() - rp[k].grad.double()).norm() / den)
         # LHN_STRICT_BARS=1 (meant for LHN_DETERMINISTIC=1 runs, where nothing varies between runs) drops the worst-case escape
-        esc = 0.0 if os.environ.get("LHN_STRICT_BARS") == "1" else 1.5 * worst32
+        esc = 0.0 if STRICT else 1.5 * worst32
+        if e / max(grad_tol, 3 * e32s[k]) > worst_ratio:
+            worst_e, worst_ratio, worst_k = e, e / max(grad_tol, 3 * e32s[k]), k
         assert e < max(grad_tol, 3 * e32s[k], esc), (k, e, e32s[k], worst32)
+    test = os.environ.get("PYTEST_CURRENT_TEST", "block").split("::")[-1].split(" ")[0]
+    parity_record(f"{test}/{type(ref).__name__}/seed{seed}", fwd_err=_rel(yg, yr), fwd_err_ref_fp32=_rel(y32, yr), fwd_bar=max(fwd_tol, 3 * _rel(y32, yr)),
+                  grad_worst_err=worst_e, grad_worst_over_bar=worst_ratio, grad_worst_param=worst_k, grad_ref_fp32_worst=worst32,
+                  grad_tol=grad_tol)
     # running statistics (momentum 0.1, unbiased variance) after one training step
     for k, v in ours.state_dict().items():
         if k.endswith("running_mean") or k.endswith("running_var"):
@@ -109,7 +123,7 @@ def test_silu_activation(dev):
     cfg = litehandnet_cfg("A", activation="silu")
     cfg.MODEL["ca_dropout"] = 0.0
     ours, ref = get_model(cfg), torch_ref.get_model(cfg, p_drop=0.0)
-    _check_block(ours, ref, synth.synth_images(8, 64, 13), dev, seed=14, no_dx=True, grad_tol=3e-2)      # whole model: see _model_case
+    _check_block(ours, ref, synth.synth_images(8, 64, 13), dev, seed=14, no_dx=True, grad_tol=WHOLE_MODEL_GRAD_TOL)      # whole model: see _model_case
 
 
 @pytest.mark.parametrize("c,dil,stride", [(32, 1, 1), (64, 2, 1), (32, 1, 2)])
@@ -195,7 +209,7 @@ def _model_case(dev, golden_dir, tag, variant="B", **kw):
     # whole-network gradient norms are chaotic at this level (one ReLU derivative flipping moves every upstream norm by ~0.4 %,
     # DESIGN.md section 2): any change of summation order -- another kernel for one layer, another atomic arrival order -- moves
     # the worst parameter between 2x and 4x the reference's own fp32 error.  The tight evidence is block-level (_check_block)
-    assert worst <= max(4 * worst32, 1e-2), (worst, worst32)
+    assert worst <= max(MODEL_GRAD_FACTOR * worst32, MODEL_GRAD_FLOOR), (worst, worst32)
     bk = str(g["bn_key"])
     rm64 = ref.state_dict()[bk].numpy()
     rm_tol = max(1e-5, 3 * np.abs(g["bn_running_mean"] - rm64).max())
@@ -206,6 +220,12 @@ def _model_case(dev, golden_dir, tag, variant="B", **kw):
     p32, _ = onp.get_max_preds(np.ascontiguousarray(last(g["heatmap"])))
     same32 = (p32 == p64).all(-1)
     assert (p.cpu().numpy() == p64).all(-1)[same32].all()
+    pn_ = p.cpu().numpy()
+    parity_record(f"model_{tag}_golden", heatmap_err=err, heatmap_err_ref_fp32=ref32_err, heatmap_bar=max(3 * ref32_err, 1e-4),
+                  loss_err=abs(float(loss.detach()) - float(l64)) / abs(float(l64)), loss_err_ref_fp32=abs(float(g["loss"]) - float(l64)) / abs(float(l64)),
+                  grad_norm_worst=worst, grad_norm_ref_fp32_worst=worst32, grad_norm_bar=max(MODEL_GRAD_FACTOR * worst32, MODEL_GRAD_FLOOR),
+                  argmax_disagree_vs_f64=int((~(pn_ == p64).all(-1)).sum()), argmax_disagree_vs_ref_fp32=int((~(pn_ == p32).all(-1)).sum()),
+                  argmax_ref_fp32_disagree_vs_f64=int((~same32).sum()), keypoints=int(p64.shape[0] * p64.shape[1]))
     print(f"[{tag}] heatmap err vs f64: hip {err:.2e} / reference-fp32 {ref32_err:.2e}; grad-norm err: hip {worst:.2e} / "
           f"reference-fp32 {worst32:.2e}; argmax agree {float((p.cpu().numpy() == p64).all(-1).mean()):.4f}")
 
