@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define LHN_VERSION 2
+#define LHN_VERSION 3
 /* cross-block accumulators (BN statistics, BN-backward sums) are replicated to spread atomic traffic:
  * layout double[LHN_STAT_REPLICAS][2][C]; a block adds into replica (blockIdx % LHN_STAT_REPLICAS). */
 #define LHN_STAT_REPLICAS 32
@@ -141,6 +141,10 @@ int lhn_affine_warp_normalize(const unsigned char* img, int N, int Hs, int Ws, c
  * exchanges the joints / visibility of every (left, right) pair, mirrors x (W - 1 - x), multiplies by the visibility and
  * mirrors center_x; lhn_affine_warp_normalize2 then reads the source image of those samples mirrored (img[:, ::-1]) --
  * the flipped image is never written.  pairs: int32 [npairs][2] on the device. */
+/* HSVRandomAug (datasets/data_pipeline/random_hsv.py:20-34) in place on uint8 BGR images [N,H,W,3]: gains = int16 [N][3] (hue,
+ * saturation, value), drawn by the caller exactly as the reference draws them (litehandnet_amd.pipeline.hsv_gains).  The integer
+ * jitter is the reference's; the 8-bit colour conversions follow OpenCV's algorithm (cv2 absent here: parity unpinned). */
+int lhn_hsv_jitter(unsigned char* img, const int16_t* gains, int N, int H, int W, void* stream);
 int lhn_random_flip(float* joints /*[N,K,3]*/, float* visible /*[N,K,vis_stride]*/, int vis_stride, float* center /*[N,2]*/,
                     const unsigned char* flipped /*[N]*/, const int32_t* pairs, int npairs, int N, int K, int img_width,
                     void* stream);
@@ -378,6 +382,9 @@ int lhn_conv_kxk_bwd(const lhn_view* x, const float* w, const lhn_view* y, const
 int lhn_plan_run_range(void* plan, int phase, int64_t step_begin, int64_t step_end, void* workspace,
                        void* const* params, void* const* grads, void* const* io, int training, int grad_replicas,
                        int64_t grad_rep_stride, double count_scale, float pgrad_scale, void* stream);
+/* SyncBatchNorm: stats[nrep][n] -> replica 0 holds the sum over the replicas, the others are zeroed; the caller then all-reduces
+ * only the first n doubles (32x fewer bytes per BatchNorm than the replicated layout) and the finalize launches run unchanged. */
+int lhn_fold_stat_replicas(double* stats, int64_t n, int nrep, void* stream);
 int lhn_reduce_replicas(float* out, const float* part, int64_t n, int nrep, int64_t rep_stride, void* stream);
 int lhn_ew_bwd(const lhn_view* srcs, int nsrc, const lhn_view* dst, const float* ddst, float out_slope,
                float* const* dsrcs, const int* accumulate, void* stream);
@@ -389,6 +396,34 @@ int lhn_maxpool2_bwd(const lhn_view* x, const lhn_view* y, const float* dy, floa
 int lhn_avgpool_bwd(const lhn_view* x, const float* dout /*[N,OH,OW,C]*/, int OH, int OW, float* dx,
                     int dx_accumulate, void* stream);
 int lhn_gate_bwd_reduce(const lhn_view* y, const float* dz, float* dgate /*[N][C] dense*/, void* stream);
+/* BatchNorm-backward sums of a GATED buffer without a pass of their own (the gate gradient needs one pass over (y, dz), the
+ * pooled gradient of the attention exists only after it, and lhn_bn_bwd_reduce would be a second pass over both).  With
+ *   du = (g[n,c] * dz + sum over the bins containing the pixel of e[n,bin,c]) * act'(u),   e = d loss / d pooled / |bin|
+ * the sums split per sample:  sum du = sum_n (g * T0 + sum_bins e * M0),  sum du * xhat = sum_n (g * T1 + sum_bins e * M1)  with
+ *   T0 = sum_px dz * act'(u), T1 = sum_px dz * act'(u) * xhat     per (n, c):      lhn_gate_bwd_reduce2 (tsum[N][2][C], = dgate + N*C)
+ *   M0 = sum_{px in bin} act'(u), M1 = sum_{px in bin} act'(u) * xhat  per (n, bin, c): lhn_avgpool_fwd3 (pstat[N*9][2][C], forward)
+ * and lhn_ca_mlp_bwd2 assembles them right where e is formed and stores them into replica 0 of the producers' sums.
+ * slices: the (up to two) convolution + BatchNorm outputs that make up the buffer (common.py:40-66 gates cat(left, right)). */
+typedef struct lhn_bn_slices {
+  const float* save[2];   /* [2][C[k]] mean | invstd saved by lhn_bn_finalize                      */
+  double*      sums[2];   /* [LHN_STAT_REPLICAS][2][C[k]] (zeroed by the caller) or NULL; lhn_ca_mlp_bwd2 only */
+  int32_t      lo[2], C[2];
+  int32_t      n;         /* 0..2 */
+} lhn_bn_slices;
+int lhn_gate_bwd_reduce2(const lhn_view* y, const float* dz, float* dgate /*[3][N][C]: dgate | tsum*/, float* tsum,
+                         const lhn_bn_slices* slices, void* stream);
+int lhn_avgpool_fwd3(const lhn_view* x, float* out /*[N,OH,OW,C]*/, int OH, int OW, float* pstat /*[N*OH*OW][2][C] or NULL*/,
+                     const lhn_bn_slices* slices, void* stream);
+int lhn_ca_mlp_bwd2(const float* pooled, const float* w3, const float* gamma, const float* w1, const float* w2,
+                    const float* dropmask, const float* save, const float* dgate, float* dpool, int cstride, int coff, int H,
+                    int W, float* dw3, float* dgamma, float* dbeta, float* dw1, float* db1, float* dw2, float* db2, int N, int C,
+                    int stage, double* gsum, double count_scale, float pgrad_scale, const float* tsum, const float* pstat,
+                    const lhn_bn_slices* slices, void* stream);
+/* ... and copy_src (or NULL): channels [0, copy_src->C) of the pooled buffer x have not been written yet -- they are the
+ * pass-through half of a gated RepBasicUnit (litehourglass.py:74-77: ca(cat(left, conv(right)))).  The kernel takes their consumed
+ * values from copy_src, pools them and stores them into x: no separate copy pass.  pstat may be NULL here. */
+int lhn_avgpool_fwd4(const lhn_view* x, float* out, int OH, int OW, float* pstat, const lhn_bn_slices* slices,
+                     const lhn_view* copy_src, void* stream);
 int lhn_ca_mlp_bwd(const float* pooled, const float* w3, const float* gamma, const float* w1, const float* w2,
                    const float* dropmask, const float* save, const float* dgate, float* dpool /*[N,9,cs]*/,
                    int cstride, int coff, int H, int W, float* dw3, float* dgamma, float* dbeta, float* dw1,
@@ -405,7 +440,7 @@ typedef struct lhn_op {
   int32_t pend[3][2];  /* forward ops: per input, indices of the producer ops whose BatchNorm this op finalizes, -1 = none */
   int32_t out_buf, out_coff, out_C;
   int32_t p[12];       /* parameter / state indices into the params array, -1 = none              */
-  int64_t ws[6];       /* byte offsets into the workspace, -1 = none                               */
+  int64_t ws[12];      /* byte offsets into the workspace, -1 = none                               */
   int32_t i[8];
   float   f[8];        /* [0..3] op scalars (eps, momentum, slope, ..); [4..6] coefficients of summed input sources */
 } lhn_op;

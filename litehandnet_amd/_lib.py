@@ -31,7 +31,7 @@ class Op(C.Structure):
     _fields_ = [("kind", C.c_int32),
                 ("in_buf", C.c_int32 * 3), ("in_coff", C.c_int32 * 3), ("in_C", C.c_int32 * 3), ("pend", (C.c_int32 * 2) * 3),
                 ("out_buf", C.c_int32), ("out_coff", C.c_int32), ("out_C", C.c_int32),
-                ("p", C.c_int32 * 12), ("ws", C.c_int64 * 6), ("i", C.c_int32 * 8), ("f", C.c_float * 8)]
+                ("p", C.c_int32 * 12), ("ws", C.c_int64 * 12), ("i", C.c_int32 * 8), ("f", C.c_float * 8)]
 
 
 class Buf(C.Structure):
@@ -45,12 +45,12 @@ SYMBOLS = [
     "lhn_version", "lhn_deterministic", "lhn_last_error", "lhn_device_ok",
     "lhn_heatmap_encode", "lhn_heatmap_argmax", "lhn_heatmap_refine", "lhn_transform_preds",
     "lhn_heatmap_decode", "lhn_heatmap_decode_dark", "lhn_heatmap_decode_dark_udp", "lhn_heatmap_nms", "lhn_heatmap_topk", "lhn_pck_accuracy",
-    "lhn_loss_balanced_mse_fwd", "lhn_loss_balanced_mse_bwd", "lhn_affine_warp_normalize", "lhn_affine_warp_normalize2", "lhn_random_flip", "lhn_simdr_encode", "lhn_simdr_loss_fwd", "lhn_simdr_loss_bwd",
+    "lhn_loss_balanced_mse_fwd", "lhn_loss_balanced_mse_bwd", "lhn_affine_warp_normalize", "lhn_affine_warp_normalize2", "lhn_random_flip", "lhn_hsv_jitter", "lhn_simdr_encode", "lhn_simdr_loss_fwd", "lhn_simdr_loss_bwd",
     "lhn_conv_pw_fwd", "lhn_conv_pw_fwd2", "lhn_conv_pw_bwd2", "lhn_conv_dw_fwd", "lhn_conv_dw_fwd2", "lhn_conv_dw_fwd3", "lhn_conv_stem_fwd", "lhn_conv_kxk_fwd",
     "lhn_bn_finalize", "lhn_table_fill", "lhn_table_bias", "lhn_fold_bn", "lhn_ew_fwd", "lhn_ew_fwd2", "lhn_ew_fwd3", "lhn_ew_mul_bwd", "lhn_bilinear_bwd", "lhn_shuffle2_fwd", "lhn_shuffle2_bwd", "lhn_bn_finalize2", "lhn_bn_bwd_finalize2", "lhn_maxpool2_fwd", "lhn_avgpool_fwd", "lhn_avgpool_fwd2", "lhn_avgpool_bwd2", "lhn_se_mlp_fwd2", "lhn_se_mlp_bwd2", "lhn_ca_mlp_fwd", "lhn_att_mlp_fwd", "lhn_att_mlp_bwd", "lhn_se_mlp_fwd", "lhn_se_mlp_bwd",
     "lhn_bn_bwd_reduce", "lhn_bn_bwd_finalize", "lhn_conv_pw_bwd", "lhn_conv_dw_bwd", "lhn_conv_dw_bwd2", "lhn_conv_dw_bwd3", "lhn_conv_stem_bwd",
-    "lhn_conv_kxk_bwd", "lhn_ew_bwd", "lhn_ew_bwd2", "lhn_maxpool2_bwd", "lhn_avgpool_bwd", "lhn_gate_bwd_reduce",
-    "lhn_ca_mlp_bwd", "lhn_reduce_replicas", "lhn_plan_create", "lhn_plan_destroy", "lhn_plan_run", "lhn_plan_run_range",
+    "lhn_conv_kxk_bwd", "lhn_ew_bwd", "lhn_ew_bwd2", "lhn_maxpool2_bwd", "lhn_avgpool_bwd", "lhn_gate_bwd_reduce", "lhn_gate_bwd_reduce2", "lhn_avgpool_fwd3", "lhn_avgpool_fwd4", "lhn_ca_mlp_bwd2",
+    "lhn_ca_mlp_bwd", "lhn_reduce_replicas", "lhn_fold_stat_replicas", "lhn_plan_create", "lhn_plan_destroy", "lhn_plan_run", "lhn_plan_run_range",
 ]
 
 

@@ -621,7 +621,32 @@ int lhn_pw_bwd_split(const lhn_view* x, const float* w, const lhn_view* y, const
     if (!wgrad_ok(Cin - k0 < 128 ? Cin - k0 : 128, nto)) return -1;
   launch_dy_inplace(y, gy, s, dbias, nrep, rep_stride);
   int rc = -1;
-  if (dx) {
+  bool dgrad_done = false;
+  if (dx && Cout == 256 && x->C % 32 == 0) {
+    // K = 256 in one pass on the register-W kernel (dy as input, W transposed): no second K slice accumulating into dx
+    lhn_view dyv = *y;
+    dyv.data = const_cast<float*>(gy->dz);
+    dyv.table = nullptr;
+    dyv.gate = nullptr;
+    dyv.pend = nullptr;
+    dgrad_done = true;
+    for (int ci0 = 0; ci0 < Cin && dgrad_done; ci0 += 128) {
+      lhn_view dxv = *x;
+      dxv.data = dx;
+      dxv.table = nullptr;
+      dxv.gate = nullptr;
+      dxv.pend = nullptr;
+      dxv.coff = x->coff + ci0;
+      dxv.C = Cin - ci0 < 128 ? Cin - ci0 : 128;
+      const int r2 = lhn_pw_dgrad_wr(&dyv, w + ci0, &dxv, Cin, dx_accumulate, s);
+      if (r2 > 0) return r2;
+      if (r2 < 0) {
+        if (ci0 > 0) return 3;
+        dgrad_done = false;
+      }
+    }
+  }
+  if (dx && !dgrad_done) {
     for (int co0 = 0; co0 < Cout; co0 += 128) {
       const int cc = Cout - co0 < 128 ? Cout - co0 : 128;
       lhn_view yv = *y;

@@ -278,7 +278,7 @@ static int launch_pw_fwd(const lhn_view* x, const float* w, const float* bias, c
 // phases up: 126 us against a 55 us MFMA bound).  Waves: NCOT feature tiles x (4 / NCOT) pixel sub-tiles of 32.
 // Statistics need no cross-wave reduction: each wave owns its features.
 template <int CIN, int NCOT, int NS>
-__global__ void __launch_bounds__(256, (NS > 1 || CIN == 128) ? 2 : 3)
+__global__ void __launch_bounds__(256, (NS > 1 || CIN >= 128) ? 2 : 3)
 k_pw_fwd_wr(lhn_view x, const float* __restrict__ w, const float* __restrict__ bias, lhn_view y, double* __restrict__ stats,
             int cout, int M, int ntiles, PwExtra ex, int wstride, int yacc, int statC, int wt) {
   constexpr int LDA = CIN + 4, PXW = 4 / NCOT, BM = 32 * PXW;
@@ -453,6 +453,12 @@ static int pw_fwd_wr(const lhn_view* x, const float* w, const float* bias, const
   if (off) return -1;
   const int ci = x->C, ncot = cout <= 32 ? 1 : cout <= 64 ? 2 : 4;
   const bool ms = ex && ex->n > 0;
+  // K = 256 (hourglassnet.py: every 1x1 of the C = 256 residuals) in ONE pass: 128 VGPRs of W per lane, no second K slice that
+  // re-reads and re-writes y
+  if (ci == 256 && !ms) {
+    if (ncot == 4) return launch_pw_fwd_wr<256, 4, 1>(x, w, bias, y, stats, cout, s, ex, geo, wt);
+    return -1;      // (64 features per block would need 64-pixel tiles: 256 VGPRs and spills)
+  }
   if (ms) {
     if (ci == 128 && ncot == 4) return launch_pw_fwd_wr<128, 4, 3>(x, w, bias, y, stats, cout, s, ex, geo);
     if (ci == 64 && ncot == 2) return launch_pw_fwd_wr<64, 2, 3>(x, w, bias, y, stats, cout, s, ex, geo);
@@ -490,7 +496,7 @@ static inline int pw_cin_tile(int c) { return c <= 16 ? 16 : c <= 32 ? 32 : c <=
 // one (input slice, output slice) launch
 static int pw_fwd_slice(const lhn_view* x, const float* w, const float* bias, const lhn_view* y, double* stats, int stride,
                         float* y_nchw, int cout, const lhn_bnfin* fin, const PwGeom& geo, hipStream_t s, const PwExtra* ex = nullptr) {
-  const int ci = pw_cin_tile(x->C), nt = (cout + 31) / 32 == 3 ? 4 : (cout + 31) / 32;
+  const int ci = x->C == 256 ? 256 : pw_cin_tile(x->C), nt = (cout + 31) / 32 == 3 ? 4 : (cout + 31) / 32;
   int rc = -1;
   // fast path: whole-K slice with full-width rows, plain NHWC store, no fused finalize
   // (slices of a C = 256 convolution qualify too: the kernel takes the whole weight's row stride, accumulates later K slices
@@ -566,10 +572,19 @@ extern "C" int lhn_conv_pw_fwd2(const lhn_view* x, const float* w, const float* 
   } else {
     LHN_CHECK_ARG(!(opts && opts->sum_out), "lhn_conv_pw_fwd: sum_out without extra sources");
   }
+  // Cin = 256 with full-width rows: the register-W kernel takes the whole K at once (LHN_PW_K256=0: two K slices, the second
+  // one accumulating into y)
+  static int k256 = -1;
+  if (k256 < 0) {
+    const char* e = getenv("LHN_PW_K256");
+    k256 = (e && e[0] == '0') ? 0 : 1;
+  }
+  const int kstep = (k256 && Cin == 256 && wcols == 256 && stride == 1 && !y_nchw && ex.n == 0 && Cout % 128 == 0 && wrows == Cout &&
+                     (reinterpret_cast<uintptr_t>(w) & 15) == 0 && !(fin && stats && single)) ? 256 : 128;
   for (int co0 = 0; co0 < Cout; co0 += 128) {
     const int cc = Cout - co0 < 128 ? Cout - co0 : 128;
-    for (int k0 = 0; k0 < Cin; k0 += 128) {
-      const int kc = Cin - k0 < 128 ? Cin - k0 : 128;
+    for (int k0 = 0; k0 < Cin; k0 += kstep) {
+      const int kc = Cin - k0 < kstep ? Cin - k0 : kstep;
       const bool last = k0 + kc >= Cin;
       lhn_view xv = *x, yv = *y;
       xv.coff += k0;

@@ -832,6 +832,70 @@ __global__ void __launch_bounds__(64) k_flip_joints(float* __restrict__ joints, 
   if (k == 0) center[n * 2] = img_w - center[n * 2] - 1.f;
 }
 
+// ------------------------------------------------------------------ HSVRandomAug (datasets/data_pipeline/random_hsv.py:20-34)
+// One thread per pixel: 8-bit BGR -> HSV (OpenCV's fixed-point RGB2HSV_b, hue range 180), the reference's integer jitter
+// ((h + dh) mod 180, clip(s + ds), clip(v + dv) in int16), HSV -> BGR (OpenCV's float sector formula, rounded to nearest even).
+// cv2 is not available where this was written: the colour conversions follow OpenCV's published algorithm, parity unpinned.
+__device__ __forceinline__ int lhn_cv_round_div(int num, double den) { return (int)__builtin_rint((double)num / den); }
+__global__ void __launch_bounds__(256) k_hsv_jitter(unsigned char* __restrict__ img, const short* __restrict__ gains, int64_t hw, int N) {
+  const int64_t total = hw * N;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int n = (int)(i / hw);
+    unsigned char* p = img + i * 3;
+    const int b = p[0], g = p[1], r = p[2];
+    const int v = max(max(b, g), r), vmin = min(min(b, g), r), diff = v - vmin;
+    const int sdiv = v > 0 ? lhn_cv_round_div(255 << 12, (double)v) : 0;
+    const int hdiv = diff > 0 ? lhn_cv_round_div(180 << 12, 6.0 * diff) : 0;
+    int s = (diff * sdiv + (1 << 11)) >> 12;
+    int h = v == r ? g - b : (v == g ? b - r + 2 * diff : r - g + 4 * diff);
+    h = (h * hdiv + (1 << 11)) >> 12;
+    if (h < 0) h += 180;
+    h = min(max(h, 0), 255);
+    // the reference's jitter on int16 planes
+    const int dh = gains[n * 3 + 0], ds = gains[n * 3 + 1], dv = gains[n * 3 + 2];
+    int hj = (h + dh) % 180;
+    if (hj < 0) hj += 180;                                   // numpy's % is non-negative for a positive modulus
+    const int sj = min(max(s + ds, 0), 255), vj = min(max(v + dv, 0), 255);
+    // HSV -> BGR
+    float hf = (float)hj * (float)(6.0 / 180.0);
+    const float sf = (float)sj * (float)(1.0 / 255.0), vf = (float)vj * (float)(1.0 / 255.0);
+    float bo, go, ro;
+    if (sj == 0) {
+      bo = go = ro = vf;
+    } else {
+      if (hf >= 6.f) hf -= 6.f;
+      int sector = (int)floorf(hf);
+      float f = hf - (float)sector;
+      if (sector < 0 || sector >= 6) {
+        sector = 0;
+        f = 0.f;
+      }
+      const float t0 = vf, t1 = vf * (1.f - sf), t2 = vf * (1.f - sf * f), t3 = vf * (1.f - sf * (1.f - f));
+      switch (sector) {
+        case 0: bo = t1; go = t3; ro = t0; break;
+        case 1: bo = t1; go = t0; ro = t2; break;
+        case 2: bo = t3; go = t0; ro = t1; break;
+        case 3: bo = t0; go = t2; ro = t1; break;
+        case 4: bo = t0; go = t1; ro = t3; break;
+        default: bo = t2; go = t1; ro = t0; break;
+      }
+    }
+    p[0] = (unsigned char)min(max((int)rintf(bo * 255.f), 0), 255);
+    p[1] = (unsigned char)min(max((int)rintf(go * 255.f), 0), 255);
+    p[2] = (unsigned char)min(max((int)rintf(ro * 255.f), 0), 255);
+  }
+}
+extern "C" int lhn_hsv_jitter(unsigned char* img, const int16_t* gains, int N, int H, int W, void* stream) {
+  LHN_CHECK_ARG(img && gains && N > 0 && H > 0 && W > 0, "lhn_hsv_jitter: bad argument");
+  const int64_t hw = (int64_t)H * W;
+  int64_t blocks = (hw * N + 255) / 256;
+  const int64_t cap = (int64_t)lhn_num_cus() * 16;
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(k_hsv_jitter, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, img, gains, hw, N);
+  LHN_CHECK_LAUNCH("lhn_hsv_jitter");
+  return 0;
+}
+
 extern "C" int lhn_random_flip(float* joints, float* visible, int vis_stride, float* center, const unsigned char* flipped,
                                const int32_t* pairs, int npairs, int N, int K, int img_width, void* stream) {
   LHN_CHECK_ARG(joints && visible && center && flipped && (pairs || npairs == 0) && N > 0 && K > 0 && K <= 64 && npairs >= 0 &&

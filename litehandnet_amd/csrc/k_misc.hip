@@ -370,10 +370,41 @@ __global__ void __launch_bounds__(256) k_maxpool2_bwd(lhn_view x, lhn_view y, co
   }
 }
 
+// BatchNorms behind channel slices of one buffer (a gated buffer is written by up to two convolutions, each with its own
+// BatchNorm): saved (mean | invstd) per slice, optionally the slice's BatchNorm-backward sums.  Channels outside every slice
+// (a pass-through half) read mean 0, invstd 1.
+struct BnSlices {
+  const float* save[2];   // [2][C[k]]
+  double* sums[2];        // [LHN_STAT_REPLICAS][2][C[k]] or NULL
+  int lo[2], C[2], n;
+};
+__device__ __forceinline__ void lhn_slice_mi4(const BnSlices& sl, int c, f4& mean, f4& inv) {
+  mean = (f4){0.f, 0.f, 0.f, 0.f};
+  inv = (f4){1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+    if (k < sl.n && c >= sl.lo[k] && c < sl.lo[k] + sl.C[k]) {
+      mean = *reinterpret_cast<const f4*>(sl.save[k] + (c - sl.lo[k]));
+      inv = *reinterpret_cast<const f4*>(sl.save[k] + sl.C[k] + (c - sl.lo[k]));
+    }
+}
+__device__ __forceinline__ f4 lhn_dact4(f4 raw, const Xf4& t) {      // derivative of the pending activation at raw
+  const f4 u = raw * t.sc + t.sh;
+  return (f4){u.x > 0.f ? 1.f : t.sl.x, u.y > 0.f ? 1.f : t.sl.y, u.z > 0.f ? 1.f : t.sl.z, u.w > 0.f ? 1.f : t.sl.w};
+}
+
 // ------------------------------------------------------------------ adaptive average pool -> dense [N,OH,OW,C]
+// STAT (channel attention of a training plan): besides the bin means of the consumed value the kernel writes, per (n, bin, c),
+//   M0 = sum over the bin of act'(u)     and     M1 = sum over the bin of act'(u) * xhat        (pstat[N*OH*OW][2][C])
+// -- with them the BatchNorm-backward sums of the gated buffer follow from the gate-gradient pass alone (k_ca_bwd1), no
+// second pass over the feature map and its gradient.
+// COPY (gated RepBasicUnit, litehourglass.py:74-77 `ca(cat(left, right))`): channels [0, src.C) of the pooled buffer are the
+// pass-through half, which nobody has written yet -- this kernel reads them from `src` (pending transform and gate applied),
+// pools them AND stores them into x (each pixel by the one bin that owns it): the separate copy pass and its re-read disappear.
+template <bool STAT, bool COPY>
 __global__ void __launch_bounds__(256) k_avgpool_fwd(lhn_view x, float* __restrict__ out, int OH, int OW, lhn_pends px, int ostride,
-                                                     int ocoff) {
-  __shared__ f4 red[256];
+                                                     int ocoff, float* __restrict__ pstat, BnSlices sl, lhn_view src) {
+  __shared__ f4 red[STAT ? 768 : 256];
   __shared__ __attribute__((aligned(16))) float s_res[LHN_RESOLVE_FLOATS];
   const float* xtab = lhn_resolve_table(x, px, s_res);
   const int C4 = x.C >> 2, PL = 256 / C4;
@@ -384,20 +415,59 @@ __global__ void __launch_bounds__(256) k_avgpool_fwd(lhn_view x, float* __restri
   const int bw = w1 - w0, cnt = (h1 - h0) * bw;
   const int c4 = threadIdx.x % C4, pl = threadIdx.x / C4;
   const int ca = x.coff + 4 * c4;
-  const Xf4 xf = lhn_load_xf_t(xtab, x.cstride, ca);
+  const bool cp = COPY && 4 * c4 < src.C;                    // this thread's channels come from src
+  const int sca = src.coff + 4 * c4;
+  Xf4 xf = lhn_load_xf_t(xtab, x.cstride, ca);
+  f4 sgate = (f4){1.f, 1.f, 1.f, 1.f};
+  if (cp) {
+    xf = lhn_load_xf(src, sca);
+    if (src.gate) sgate = *reinterpret_cast<const f4*>(src.gate + (int64_t)n * src.cstride + sca);
+  }
+  f4 mean, inv;
+  if (STAT) lhn_slice_mi4(sl, ca, mean, inv);
   // four independent loads in flight per thread; the (per-image) gate factors out of the sum
-  const float* base = x.data + (int64_t)n * x.H * x.W * x.cstride + ca;
-  auto at = [&](int p) { return *reinterpret_cast<const f4*>(base + (int64_t)((h0 + p / bw) * x.W + w0 + p % bw) * x.cstride); };
-  f4 s0 = (f4){0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+  const float* base = cp ? src.data + (int64_t)n * x.H * x.W * src.cstride + sca : x.data + (int64_t)n * x.H * x.W * x.cstride + ca;
+  const int64_t pstr = cp ? src.cstride : x.cstride;
+  auto at = [&](int p) { return *reinterpret_cast<const f4*>(base + (int64_t)((h0 + p / bw) * x.W + w0 + p % bw) * pstr); };
+  // a pixel is stored by the bin whose exclusive range [lo(oh), lo(oh + 1)) x [lo(ow), lo(ow + 1)) holds it (bins overlap)
+  const int hown = ((oh + 1) * x.H) / OH, wown = ((ow + 1) * x.W) / OW;
+  float* xout = x.data + (int64_t)n * x.H * x.W * x.cstride + ca;
+  auto put = [&](int p, f4 v) {
+    const int h = h0 + p / bw, w = w0 + p % bw;
+    if (h < hown && w < wown) *reinterpret_cast<f4*>(xout + (int64_t)(h * x.W + w) * x.cstride) = v;
+  };
+  f4 s0 = (f4){0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0, m0 = s0, m1 = s0;
   int p = LHN_LANE0(pl, PL);
   for (; p + 3 * PL < cnt; p += 4 * PL) {
     const f4 a = at(p), b2 = at(p + PL), c2 = at(p + 2 * PL), d2 = at(p + 3 * PL);
-    s0 += lhn_apply_xf(a, xf);
-    s1 += lhn_apply_xf(b2, xf);
-    s2 += lhn_apply_xf(c2, xf);
-    s3 += lhn_apply_xf(d2, xf);
+    const f4 va = lhn_apply_xf(a, xf) * sgate, vb = lhn_apply_xf(b2, xf) * sgate, vc = lhn_apply_xf(c2, xf) * sgate, vd = lhn_apply_xf(d2, xf) * sgate;
+    s0 += va;
+    s1 += vb;
+    s2 += vc;
+    s3 += vd;
+    if (cp) {
+      put(p, va);
+      put(p + PL, vb);
+      put(p + 2 * PL, vc);
+      put(p + 3 * PL, vd);
+    }
+    if (STAT) {
+      const f4 da = lhn_dact4(a, xf), db = lhn_dact4(b2, xf), dc = lhn_dact4(c2, xf), dd = lhn_dact4(d2, xf);
+      m0 += (da + db) + (dc + dd);
+      m1 += (da * ((a - mean) * inv) + db * ((b2 - mean) * inv)) + (dc * ((c2 - mean) * inv) + dd * ((d2 - mean) * inv));
+    }
   }
-  for (; p < cnt; p += PL) s0 += lhn_apply_xf(at(p), xf);
+  for (; p < cnt; p += PL) {
+    const f4 a = at(p);
+    const f4 va = lhn_apply_xf(a, xf) * sgate;
+    s0 += va;
+    if (cp) put(p, va);
+    if (STAT) {
+      const f4 da = lhn_dact4(a, xf);
+      m0 += da;
+      m1 += da * ((a - mean) * inv);
+    }
+  }
   f4 s = (s0 + s1) + (s2 + s3);
   if (x.gate) s *= *reinterpret_cast<const f4*>(x.gate + (int64_t)n * x.cstride + ca);
   // power-of-two C4 <= 64: lanes of a wave that share c4 meet by xor-shuffles, the four waves through LDS; any other C4
@@ -406,20 +476,43 @@ __global__ void __launch_bounds__(256) k_avgpool_fwd(lhn_view x, float* __restri
   if (shuf)
     for (int o = C4; o < 64; o <<= 1) {
       s.x += __shfl_xor(s.x, o, 64); s.y += __shfl_xor(s.y, o, 64); s.z += __shfl_xor(s.z, o, 64); s.w += __shfl_xor(s.w, o, 64);
+      if (STAT) {
+        m0.x += __shfl_xor(m0.x, o, 64); m0.y += __shfl_xor(m0.y, o, 64); m0.z += __shfl_xor(m0.z, o, 64); m0.w += __shfl_xor(m0.w, o, 64);
+        m1.x += __shfl_xor(m1.x, o, 64); m1.y += __shfl_xor(m1.y, o, 64); m1.z += __shfl_xor(m1.z, o, 64); m1.w += __shfl_xor(m1.w, o, 64);
+      }
     }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (shuf && lane < C4) red[wave * C4 + lane] = s;
-  if (!shuf) red[threadIdx.x] = s;
+  if (shuf && lane < C4) {
+    red[wave * C4 + lane] = s;
+    if (STAT) {
+      red[256 + wave * C4 + lane] = m0;
+      red[512 + wave * C4 + lane] = m1;
+    }
+  }
+  if (!shuf) {
+    red[threadIdx.x] = s;
+    if (STAT) {
+      red[256 + threadIdx.x] = m0;
+      red[512 + threadIdx.x] = m1;
+    }
+  }
   __syncthreads();
   if (threadIdx.x < C4) {
-    f4 t = (f4){0.f, 0.f, 0.f, 0.f};
-    if (shuf) {
-      for (int j = 0; j < 4; ++j) t += red[j * C4 + threadIdx.x];
-    } else {
-      for (int j = 0; j < PL; ++j) t += red[j * C4 + threadIdx.x];
+    const int nj = shuf ? 4 : PL;
+    f4 t = (f4){0.f, 0.f, 0.f, 0.f}, t0 = t, t1 = t;
+    for (int j = 0; j < nj; ++j) {
+      t += red[j * C4 + threadIdx.x];
+      if (STAT) {
+        t0 += red[256 + j * C4 + threadIdx.x];
+        t1 += red[512 + j * C4 + threadIdx.x];
+      }
     }
-    const float inv = 1.f / (float)cnt;
-    *reinterpret_cast<f4*>(out + (int64_t)b * ostride + ocoff + 4 * threadIdx.x) = t * inv;
+    const float invc = 1.f / (float)cnt;
+    *reinterpret_cast<f4*>(out + (int64_t)b * ostride + ocoff + 4 * threadIdx.x) = t * invc;
+    if (STAT) {
+      *reinterpret_cast<f4*>(pstat + ((int64_t)b * 2 + 0) * x.C + 4 * threadIdx.x) = t0;
+      *reinterpret_cast<f4*>(pstat + ((int64_t)b * 2 + 1) * x.C + 4 * threadIdx.x) = t1;
+    }
   }
 }
 // Small bins (<= 16 pixels: the 2x2 / 4x4 bins of lite_hrnet.py:56-60, every branch pooled to the smallest map): one THREAD
@@ -588,33 +681,58 @@ __global__ void __launch_bounds__(256) k_ca2(const float* __restrict__ w1, const
 }
 
 // d(gate)[n][c] = sum_pixels dz * value_pre_gate   (one block per image)
+// tsum != NULL: also T0[n][c] = sum dz * act'(u), T1[n][c] = sum dz * act'(u) * xhat  (tsum[N][2][C]) -- the per-sample halves of
+// the gated buffer's BatchNorm-backward sums (see k_avgpool_fwd<STAT> / k_ca_bwd1)
 __global__ void __launch_bounds__(256) k_gate_bwd_reduce(lhn_view y, const float* __restrict__ dz,
-                                                         float* __restrict__ dgate) {
-  __shared__ f4 red[256];
+                                                         float* __restrict__ dgate, float* __restrict__ tsum, BnSlices sl) {
+  __shared__ f4 red[768];
   const int C4 = y.C >> 2, PL = 256 / C4, n = blockIdx.x;
   const int c4 = threadIdx.x % C4, pl = threadIdx.x / C4;
   const int ca = y.coff + 4 * c4;
   const Xf4 xf = lhn_load_xf(y, ca);
+  f4 mean, inv;
+  lhn_slice_mi4(sl, ca, mean, inv);
   const int HW = y.H * y.W;
   const int chunk = (HW + gridDim.y - 1) / gridDim.y;
   const int p0 = blockIdx.y * chunk, p1 = min(HW, p0 + chunk);
-  f4 s = (f4){0.f, 0.f, 0.f, 0.f};
-  for (int p = p0 + LHN_LANE0(pl, PL); p < p1; p += PL) {
-    const int64_t pix = (int64_t)n * HW + p;
-    const f4 raw = *reinterpret_cast<const f4*>(y.data + pix * y.cstride + ca);
-    const f4 v = lhn_apply_xf(raw, xf);
-    s += v * *reinterpret_cast<const f4*>(dz + pix * y.cstride + ca);
+  f4 s = (f4){0.f, 0.f, 0.f, 0.f}, t0 = s, t1 = s;
+  // two pixels per thread and pass: four independent loads in flight
+  for (int p = p0 + LHN_LANE0(pl, PL); p < p1; p += 2 * PL) {
+    const int64_t pixa = (int64_t)n * HW + p, pixb = (int64_t)n * HW + min(p + PL, p1 - 1);
+    const f4 rawa = *reinterpret_cast<const f4*>(y.data + pixa * y.cstride + ca);
+    const f4 rawb = *reinterpret_cast<const f4*>(y.data + pixb * y.cstride + ca);
+    const f4 dza = *reinterpret_cast<const f4*>(dz + pixa * y.cstride + ca);
+    f4 dzb = *reinterpret_cast<const f4*>(dz + pixb * y.cstride + ca);
+    if (p + PL >= p1) dzb = (f4){0.f, 0.f, 0.f, 0.f};
+    s += lhn_apply_xf(rawa, xf) * dza + lhn_apply_xf(rawb, xf) * dzb;
+    if (tsum) {
+      const f4 da = lhn_dact4(rawa, xf) * dza, db = lhn_dact4(rawb, xf) * dzb;
+      t0 += da + db;
+      t1 += da * ((rawa - mean) * inv) + db * ((rawb - mean) * inv);
+    }
   }
   red[threadIdx.x] = s;
+  red[256 + threadIdx.x] = t0;
+  red[512 + threadIdx.x] = t1;
   __syncthreads();
   if (threadIdx.x < C4) {
-    f4 t = (f4){0.f, 0.f, 0.f, 0.f};
-    for (int j = 0; j < PL; ++j) t += red[j * C4 + threadIdx.x];
+    f4 t = (f4){0.f, 0.f, 0.f, 0.f}, u0 = t, u1 = t;
+    for (int j = 0; j < PL; ++j) {
+      t += red[j * C4 + threadIdx.x];
+      u0 += red[256 + j * C4 + threadIdx.x];
+      u1 += red[512 + j * C4 + threadIdx.x];
+    }
     float* o = dgate + (int64_t)n * y.C + 4 * threadIdx.x;
     atomicAdd(o + 0, t.x);
     atomicAdd(o + 1, t.y);
     atomicAdd(o + 2, t.z);
     atomicAdd(o + 3, t.w);
+    if (tsum) {
+      float* o0 = tsum + ((int64_t)n * 2 + 0) * y.C + 4 * threadIdx.x;
+      float* o1 = tsum + ((int64_t)n * 2 + 1) * y.C + 4 * threadIdx.x;
+      atomicAdd(o0 + 0, u0.x); atomicAdd(o0 + 1, u0.y); atomicAdd(o0 + 2, u0.z); atomicAdd(o0 + 3, u0.w);
+      atomicAdd(o1 + 0, u1.x); atomicAdd(o1 + 1, u1.y); atomicAdd(o1 + 2, u1.z); atomicAdd(o1 + 3, u1.w);
+    }
   }
 }
 
@@ -671,7 +789,8 @@ __global__ void __launch_bounds__(1024) k_ca_bwd1(const float* __restrict__ pool
                                                  float* __restrict__ dpool, int cs, int coff, int H, int W,
                                                  float* __restrict__ dw3, float* __restrict__ dgamma,
                                                  float* __restrict__ dbeta, int N, int C, int training, int stage,
-                                                 double* __restrict__ gsum, double count_scale, float pgrad_scale) {
+                                                 double* __restrict__ gsum, double count_scale, float pgrad_scale,
+                                                 const float* __restrict__ tsum, const float* __restrict__ pstat, BnSlices sl) {
   // stage 0: everything; SyncBatchNorm: stage 1 = local (sum d, sum d*xhat) -> gsum[2][C], all-reduce, stage 2 = the rest
   __shared__ double rs[32][32], rq[32][32];
   __shared__ float rw[32][32][9];
@@ -716,6 +835,11 @@ __global__ void __launch_bounds__(1024) k_ca_bwd1(const float* __restrict__ pool
     dgamma[c] += (float)sdx * pgrad_scale;
     dbeta[c] += (float)sd * pgrad_scale;
   }
+  // tsum / pstat: the gated buffer's BatchNorm-backward sums, assembled here per channel from the gate-gradient pass (T0, T1),
+  // the forward pooling pass (M0, M1 per bin) and the pooled gradient e[bin] = d loss / d pooled[bin] / |bin| formed below:
+  //   sum du        = sum_n ( g * T0 + sum_bins e * M0 ),      sum du * xhat = sum_n ( g * T1 + sum_bins e * M1 )
+  const float* gsave = save + (int64_t)N * C * 2 + (int64_t)N * (C / 2);      // sigmoid gate g[n][c] of the forward
+  double bs0 = 0, bs1 = 0;
   float wt[9], dwt[9], binv[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) {
@@ -738,7 +862,38 @@ __global__ void __launch_bounds__(1024) k_ca_bwd1(const float* __restrict__ pool
         dseg[t] = da * wt[t] * binv[t];
       }
       lhn_dpool_store(dpool, n, cs, coff + c, dseg);
+      if (tsum) {
+        const float g = gsave[(int64_t)n * C + c];
+        float a0 = g * tsum[((int64_t)n * 2 + 0) * C + c], a1 = g * tsum[((int64_t)n * 2 + 1) * C + c];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          a0 += dseg[t] * pstat[(((int64_t)n * 9 + t) * 2 + 0) * C + c];
+          a1 += dseg[t] * pstat[(((int64_t)n * 9 + t) * 2 + 1) * C + c];
+        }
+        bs0 += a0;
+        bs1 += a1;
+      }
     }
+  if (tsum) {
+    __syncthreads();          // rs / rq are free again
+    rs[nl][cl] = bs0;
+    rq[nl][cl] = bs1;
+    __syncthreads();
+    if (nl == 0 && ok) {
+      double t0 = 0, t1 = 0;
+      for (int j = 0; j < NL; ++j) {
+        t0 += rs[j][cl];
+        t1 += rq[j][cl];
+      }
+      const int cb = coff + c;                    // channel of the gated buffer
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+        if (k < sl.n && sl.sums[k] && cb >= sl.lo[k] && cb < sl.lo[k] + sl.C[k]) {   // this block is the channel's only writer
+          sl.sums[k][cb - sl.lo[k]] = t0;
+          sl.sums[k][sl.C[k] + cb - sl.lo[k]] = t1;
+        }
+    }
+  }
 #pragma unroll
   for (int t = 0; t < 9; ++t) rw[nl][cl][t] = dwt[t];
   __syncthreads();
@@ -864,8 +1019,29 @@ __global__ void __launch_bounds__(256) k_reduce_replicas(float* __restrict__ out
   }
 }
 
+// SyncBatchNorm: fold the replicated sums of one BatchNorm into replica 0 (the others become zero) BEFORE they go on the wire --
+// the exchange then moves [2][C] doubles instead of [LHN_STAT_REPLICAS][2][C] (32x fewer bytes over xGMI per BatchNorm), and the
+// finalize kernels, which add all replicas, read the global sums unchanged.
+__global__ void __launch_bounds__(256) k_fold_stat_replicas(double* __restrict__ st, int64_t n, int nrep) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    double s = st[i];
+    for (int r = 1; r < nrep; ++r) {
+      s += st[(int64_t)r * n + i];
+      st[(int64_t)r * n + i] = 0.0;
+    }
+    st[i] = s;
+  }
+}
+
 // ------------------------------------------------------------------ C ABI
 extern "C" {
+
+int lhn_fold_stat_replicas(double* stats, int64_t n, int nrep, void* stream) {
+  LHN_CHECK_ARG(stats && n > 0 && nrep >= 1, "lhn_fold_stat_replicas: bad argument");
+  hipLaunchKernelGGL(k_fold_stat_replicas, dim3((unsigned)((n + 255) / 256 > 64 ? 64 : (n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, stats, n, nrep);
+  LHN_CHECK_LAUNCH("lhn_fold_stat_replicas");
+  return 0;
+}
 
 int lhn_reduce_replicas(float* out, const float* part, int64_t n, int nrep, int64_t rep_stride, void* stream) {
   LHN_CHECK_ARG(out && part && n > 0 && n % 4 == 0 && nrep >= 1 && rep_stride % 4 == 0, "lhn_reduce_replicas: bad args (n and stride multiples of 4)");
@@ -997,8 +1173,54 @@ int lhn_avgpool_fwd2(const lhn_view* x, float* out, int OH, int OW, int out_cstr
     const int64_t total = (int64_t)x->N * OH * OW * (x->C / 4);
     hipLaunchKernelGGL(k_avgpool_small, dim3(grid_cap((total + 255) / 256, 16)), dim3(256), 0, (hipStream_t)stream, *x, out, OH, OW, out_cstride, out_coff);
   } else
-    hipLaunchKernelGGL(k_avgpool_fwd, dim3(x->N * OH * OW), dim3(256), 0, (hipStream_t)stream, *x, out, OH, OW, lhn_pends_of(x), out_cstride, out_coff);
+  {
+    BnSlices sl;
+    memset(&sl, 0, sizeof(sl));
+    lhn_view nosrc;
+    memset(&nosrc, 0, sizeof(nosrc));
+    hipLaunchKernelGGL((k_avgpool_fwd<false, false>), dim3(x->N * OH * OW), dim3(256), 0, (hipStream_t)stream, *x, out, OH, OW, lhn_pends_of(x), out_cstride, out_coff,
+                       (float*)nullptr, sl, nosrc);
+  }
   LHN_CHECK_LAUNCH("lhn_avgpool_fwd");
+  return 0;
+}
+static int mk_slices(const lhn_bn_slices* in, int C, BnSlices* sl, const char* who) {
+  memset(sl, 0, sizeof(*sl));
+  if (!in) return 0;
+  LHN_CHECK_ARG(in->n >= 0 && in->n <= 2, "%s: 0..2 BatchNorm slices", who);
+  sl->n = in->n;
+  for (int k = 0; k < in->n; ++k) {
+    LHN_CHECK_ARG(in->save[k] && in->lo[k] >= 0 && in->C[k] > 0 && in->lo[k] % 4 == 0 && in->C[k] % 4 == 0 && in->lo[k] + in->C[k] <= C,
+                  "%s: BatchNorm slice %d = channels [%d, %d) of %d", who, k, in->lo[k], in->lo[k] + in->C[k], C);
+    sl->save[k] = in->save[k];
+    sl->sums[k] = in->sums[k];
+    sl->lo[k] = in->lo[k];
+    sl->C[k] = in->C[k];
+  }
+  return 0;
+}
+int lhn_avgpool_fwd3(const lhn_view* x, float* out, int OH, int OW, float* pstat, const lhn_bn_slices* slices, void* stream) {
+  return lhn_avgpool_fwd4(x, out, OH, OW, pstat, slices, nullptr, stream);
+}
+int lhn_avgpool_fwd4(const lhn_view* x, float* out, int OH, int OW, float* pstat, const lhn_bn_slices* slices, const lhn_view* copy_src,
+                     void* stream) {
+  if (!pstat && !copy_src) return lhn_avgpool_fwd2(x, out, OH, OW, x ? x->C : 0, 0, stream);
+  LHN_CHECK_ARG(lhn_view_ok(x) && out && OH > 0 && OW > 0 && x->C % 4 == 0 && x->C <= 1024 && x->coff == 0 && x->C == x->cstride && lhn_no_pend(x),
+                "lhn_avgpool_fwd4: the statistics / copy forms pool a whole buffer");
+  LHN_CHECK_ARG(!copy_src || (lhn_view_ok(copy_src) && lhn_no_pend(copy_src) && copy_src->N == x->N && copy_src->H == x->H && copy_src->W == x->W &&
+                              copy_src->C < x->C && copy_src->data != x->data),
+                "lhn_avgpool_fwd4: copy_src = the first channels of the pooled tensor, same pixels, another buffer");
+  BnSlices sl;
+  if (mk_slices(pstat ? slices : nullptr, x->C, &sl, "lhn_avgpool_fwd4")) return 1;
+  lhn_view src;
+  memset(&src, 0, sizeof(src));
+  if (copy_src) src = *copy_src;
+  const dim3 g(x->N * OH * OW), bk(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (pstat && copy_src) hipLaunchKernelGGL((k_avgpool_fwd<true, true>), g, bk, 0, s, *x, out, OH, OW, lhn_pends_of(x), x->C, 0, pstat, sl, src);
+  else if (pstat) hipLaunchKernelGGL((k_avgpool_fwd<true, false>), g, bk, 0, s, *x, out, OH, OW, lhn_pends_of(x), x->C, 0, pstat, sl, src);
+  else hipLaunchKernelGGL((k_avgpool_fwd<false, true>), g, bk, 0, s, *x, out, OH, OW, lhn_pends_of(x), x->C, 0, pstat, sl, src);
+  LHN_CHECK_LAUNCH("lhn_avgpool_fwd4");
   return 0;
 }
 int lhn_avgpool_bwd(const lhn_view* x, const float* dout, int OH, int OW, float* dx, int dx_accumulate, void* stream) {
@@ -1022,6 +1244,8 @@ int lhn_ca_mlp_fwd(const float* pooled, const float* w3, const float* gamma, con
   LHN_CHECK_ARG(C > 0 && C <= 256 && C % 2 == 0 && N > 0, "lhn_ca_mlp_fwd: C=%d (<=256)", C);
   hipStream_t s = (hipStream_t)stream;
   LHN_CHECK_ARG(stage == 0 || (gsum && stage >= 1 && stage <= 2 && count_scale >= 1), "lhn_ca_mlp_fwd: stage %d needs gsum", stage);
+  // (one launch for both kernels -- every workgroup recomputing the batch statistics from the pooled tensor -- was measured
+  // slower than the two launches: forward of the MSRB hourglass 2.770 vs 2.714 ms, round 3)
   hipLaunchKernelGGL(k_ca1, dim3((C + 31) / 32), dim3(1024), 0, s, pooled, w3, gamma, beta, rmean, rvar, nbt, dropmask, save, N, C, eps, momentum, training, stage, gsum, stage ? count_scale : 1.0);
   if (stage != 1) hipLaunchKernelGGL(k_ca2, dim3(N), dim3(128), 0, s, w1, b1, w2, b2, save, gate, gate_stride, gate_coff, N, C);
   LHN_CHECK_LAUNCH("lhn_ca_mlp_fwd");
@@ -1029,9 +1253,16 @@ int lhn_ca_mlp_fwd(const float* pooled, const float* w3, const float* gamma, con
 }
 
 int lhn_gate_bwd_reduce(const lhn_view* y, const float* dz, float* dgate, void* stream) {
+  return lhn_gate_bwd_reduce2(y, dz, dgate, nullptr, nullptr, stream);
+}
+int lhn_gate_bwd_reduce2(const lhn_view* y, const float* dz, float* dgate, float* tsum, const lhn_bn_slices* slices, void* stream) {
   LHN_CHECK_ARG(lhn_view_ok(y) && dz && dgate && y->C % 4 == 0 && y->C <= 1024 && lhn_no_pend(y), "lhn_gate_bwd_reduce: bad args");
+  LHN_CHECK_ARG(!tsum || (y->coff == 0 && y->C == y->cstride && tsum == dgate + (size_t)y->N * y->C),
+                "lhn_gate_bwd_reduce2: tsum = the 2*N*C floats behind dgate, whole-buffer view");
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(dgate, 0, (size_t)y->N * y->C * 4, s) != hipSuccess) {
+  BnSlices sl;
+  if (mk_slices(tsum ? slices : nullptr, y->C, &sl, "lhn_gate_bwd_reduce2")) return 1;
+  if (hipMemsetAsync(dgate, 0, (size_t)y->N * y->C * 4 * (tsum ? 3 : 1), s) != hipSuccess) {
     lhn_set_error("lhn_gate_bwd_reduce: memset failed");
     return 2;
   }
@@ -1039,7 +1270,7 @@ int lhn_gate_bwd_reduce(const lhn_view* y, const float* dz, float* dgate, void* 
   if (split < 1) split = 1;
   if (split > 32) split = 32;
   if (lhn_deterministic_mode()) split = 1;          // one workgroup per image: a single (ordered) writer per d(gate) element
-  hipLaunchKernelGGL(k_gate_bwd_reduce, dim3(y->N, split), dim3(256), 0, s, *y, dz, dgate);
+  hipLaunchKernelGGL(k_gate_bwd_reduce, dim3(y->N, split), dim3(256), 0, s, *y, dz, dgate, tsum, sl);
   LHN_CHECK_LAUNCH("lhn_gate_bwd_reduce");
   return 0;
 }
@@ -1050,6 +1281,17 @@ int lhn_ca_mlp_bwd(const float* pooled, const float* w3, const float* gamma, con
                    const float* dropmask, const float* save, const float* dgate, float* dpool, int cstride, int coff, int H,
                    int W, float* dw3, float* dgamma, float* dbeta, float* dw1, float* db1, float* dw2, float* db2, int N,
                    int C, int stage, double* gsum, double count_scale, float pgrad_scale, void* stream) {
+  return lhn_ca_mlp_bwd2(pooled, w3, gamma, w1, w2, dropmask, save, dgate, dpool, cstride, coff, H, W, dw3, dgamma, dbeta, dw1, db1, dw2,
+                         db2, N, C, stage, gsum, count_scale, pgrad_scale, nullptr, nullptr, nullptr, stream);
+}
+int lhn_ca_mlp_bwd2(const float* pooled, const float* w3, const float* gamma, const float* w1, const float* w2,
+                    const float* dropmask, const float* save, const float* dgate, float* dpool, int cstride, int coff, int H,
+                    int W, float* dw3, float* dgamma, float* dbeta, float* dw1, float* db1, float* dw2, float* db2, int N,
+                    int C, int stage, double* gsum, double count_scale, float pgrad_scale, const float* tsum, const float* pstat,
+                    const lhn_bn_slices* slices, void* stream) {
+  LHN_CHECK_ARG(!tsum == !pstat && (!tsum || (slices && coff == 0 && C == cstride)), "lhn_ca_mlp_bwd2: tsum, pstat and slices come together (whole buffer)");
+  BnSlices sl;
+  if (mk_slices(tsum ? slices : nullptr, cstride, &sl, "lhn_ca_mlp_bwd2")) return 1;
   LHN_CHECK_ARG(pooled && w3 && gamma && w1 && w2 && save && dgate && dpool && dw3 && dgamma && dbeta && dw1 && db1 && dw2 && db2,
                 "lhn_ca_mlp_bwd: null pointer");
   LHN_CHECK_ARG(C > 0 && C <= 256 && C % 2 == 0, "lhn_ca_mlp_bwd: C=%d", C);
@@ -1057,7 +1299,7 @@ int lhn_ca_mlp_bwd(const float* pooled, const float* w3, const float* gamma, con
   float* dahat = const_cast<float*>(save) + (int64_t)N * C * 3 + (int64_t)N * (C / 2) + 2 * C;
   LHN_CHECK_ARG(stage == 0 || (gsum && stage >= 1 && stage <= 2 && count_scale >= 1), "lhn_ca_mlp_bwd: stage %d needs gsum", stage);
   if (stage != 2) hipLaunchKernelGGL(k_ca_bwd2, dim3(lhn_deterministic_mode() ? 1 : N, 2), dim3(256), 0, s, w1, w2, save, dgate, dahat, dw1, db1, dw2, db2, N, C);
-  hipLaunchKernelGGL(k_ca_bwd1, dim3((C + 31) / 32), dim3(1024), 0, s, pooled, w3, gamma, dropmask, save, dahat, dpool, cstride, coff, H, W, dw3, dgamma, dbeta, N, C, 1, stage, gsum, stage ? count_scale : 1.0, stage ? pgrad_scale : 1.f);
+  hipLaunchKernelGGL(k_ca_bwd1, dim3((C + 31) / 32), dim3(1024), 0, s, pooled, w3, gamma, dropmask, save, dahat, dpool, cstride, coff, H, W, dw3, dgamma, dbeta, N, C, 1, stage, gsum, stage ? count_scale : 1.0, stage ? pgrad_scale : 1.f, tsum, pstat, sl);
   LHN_CHECK_LAUNCH("lhn_ca_mlp_bwd");
   return 0;
 }

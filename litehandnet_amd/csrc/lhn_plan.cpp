@@ -59,6 +59,21 @@ static lhn_gradview mkgrad(const Plan* P, void* ws, int buf, bool use_coef) {
 }
 template <typename T>
 static inline T* prm(void* const* arr, int idx) { return idx < 0 ? nullptr : static_cast<T*>(arr[idx]); }
+// BatchNorm slices of a gated buffer (lhn_bn_slices): packed (first channel << 16 | channels) in pk[0..1] (0 = none), byte offsets
+// of the saved statistics in sv[0..1] and of the backward sums in sm[0..1] (NULL: sv only)
+static lhn_bn_slices mkslices(void* ws, const int32_t* pk, const int64_t* sv, const int64_t* sm) {
+  lhn_bn_slices s;
+  memset(&s, 0, sizeof(s));
+  for (int k = 0; k < 2; ++k)
+    if (pk[k] > 0 && sv[k] >= 0) {
+      const int j = s.n++;
+      s.lo[j] = pk[k] >> 16;
+      s.C[j] = pk[k] & 0xffff;
+      s.save[j] = reinterpret_cast<const float*>(at(ws, sv[k]));
+      s.sums[j] = (sm && sm[k] >= 0) ? reinterpret_cast<double*>(at(ws, sm[k])) : nullptr;
+    }
+  return s;
+}
 
 // conv op with a trailing BatchNorm: p[2..6] = gamma, beta, running_mean, running_var, num_batches_tracked,
 // ws[1] = save(mean,invstd), ws[2] = arrival counter, f[0..2] = eps, momentum, slope
@@ -369,6 +384,16 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
       case OP_AVGPOOL: {
         lhn_view x = mkview(P, ws, o.in_buf[0], o.in_coff[0], o.in_C[0], o.i[2] == 0);
         if (has_pend && pd[0].n) x.pend = &pd[0];
+        if (o.ws[1] >= 0 || o.in_buf[1] >= 0) {
+          // channel attention: ws[1] = pooling statistics its backward assembles BatchNorm sums from (training plans);
+          // in_buf[1] = the pass-through half of a gated unit, copied into the pooled buffer by this launch
+          const lhn_bn_slices sl = mkslices(ws, &o.i[5], &o.ws[2], nullptr);
+          lhn_view src;
+          if (o.in_buf[1] >= 0) src = mkview(P, ws, o.in_buf[1], o.in_coff[1], o.in_C[1]);
+          rc = lhn_avgpool_fwd4(&x, reinterpret_cast<float*>(at(ws, o.ws[0])), o.i[0], o.i[1],
+                                o.ws[1] >= 0 ? reinterpret_cast<float*>(at(ws, o.ws[1])) : nullptr, &sl, o.in_buf[1] >= 0 ? &src : nullptr, stream);
+          break;
+        }
         rc = lhn_avgpool_fwd2(&x, reinterpret_cast<float*>(at(ws, o.ws[0])), o.i[0], o.i[1], o.i[3] > 0 ? o.i[3] : x.C, o.i[4], stream);
         break;
       }
@@ -538,14 +563,18 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
       }
       case OP_GATE_REDUCE: {
         lhn_view y = mkview(P, ws, o.out_buf, o.out_coff, o.out_C, false);
-        rc = lhn_gate_bwd_reduce(&y, reinterpret_cast<const float*>(at(ws, P->bufs[o.out_buf].grad_off)),
-                                 reinterpret_cast<float*>(at(ws, o.ws[3])), stream);
+        float* dg = reinterpret_cast<float*>(at(ws, o.ws[3]));
+        const lhn_bn_slices sl = mkslices(ws, &o.i[0], &o.ws[5], nullptr);
+        rc = lhn_gate_bwd_reduce2(&y, reinterpret_cast<const float*>(at(ws, P->bufs[o.out_buf].grad_off)), dg,
+                                  o.ws[4] >= 0 ? dg + (size_t)y.N * y.C : nullptr, &sl, stream);
         break;
       }
       case OP_CA_MLP_BWD: {
         const lhn_buf& b = P->bufs[o.out_buf];
         if (o.ws[4] < 0 && !h0) break;
-        rc = lhn_ca_mlp_bwd(reinterpret_cast<const float*>(at(ws, o.ws[0])), prm<const float>(params, o.p[0]),
+        const lhn_bn_slices sl = mkslices(ws, &o.i[0], &o.ws[6], &o.ws[8]);
+        const float* dgp = reinterpret_cast<const float*>(at(ws, o.ws[3]));
+        rc = lhn_ca_mlp_bwd2(reinterpret_cast<const float*>(at(ws, o.ws[0])), prm<const float>(params, o.p[0]),
                             prm<const float>(params, o.p[1]), prm<const float>(params, o.p[2]), prm<const float>(params, o.p[3]),
                             o.ws[2] >= 0 ? reinterpret_cast<const float*>(at(ws, o.ws[2])) : nullptr,
                             reinterpret_cast<const float*>(at(ws, o.ws[1])), reinterpret_cast<const float*>(at(ws, o.ws[3])),
@@ -553,7 +582,8 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
                             prm<float>(grads, o.p[5]), prm<float>(grads, o.p[6]), prm<float>(grads, o.p[7]),
                             prm<float>(grads, o.p[8]), prm<float>(grads, o.p[9]), prm<float>(grads, o.p[10]), b.N, o.out_C,
                             o.ws[4] >= 0 ? stage : 0, o.ws[4] >= 0 ? reinterpret_cast<double*>(at(ws, o.ws[4])) : nullptr, cscale, pscale,
-                            stream);
+                            o.ws[5] >= 0 ? dgp + (size_t)b.N * b.C : nullptr, o.ws[5] >= 0 ? reinterpret_cast<const float*>(at(ws, o.ws[5])) : nullptr,
+                            &sl, stream);
         break;
       }
       case OP_ATT_MLP_BWD: {  // p: gamma, beta, w3, wl (params) | dgamma, dbeta, dw3, db3, dwl, dbl (grads); ws: pooled, save, mask, dgate

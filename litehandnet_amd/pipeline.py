@@ -4,12 +4,54 @@ the network -- TopDownAffine (topdown_affine.py:47-114, non-UDP) + ToTensor + No
 GenerateSimDR).  Source images of one batch share their size (uint8, HWC)."""
 import ctypes as C
 
+import numpy as np
 import torch
 
 from . import _lib, heatmap
 
 IMAGENET_MEAN = (0.485, 0.456, 0.406)
 IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+def hsv_gains(n, hue_delta=5, saturation_delta=30, value_delta=30):
+    """The random draws of HSVRandomAug.__call__ (random_hsv.py:22-29) for n samples: numpy's global generator, the reference's
+    calls in the reference's order (so `np.random.seed` reproduces the reference's stream) -> int16 [n, 3]."""
+    out = np.zeros((n, 3), np.int16)
+    for i in range(n):
+        g = np.random.uniform(-1, 1, 3) * [hue_delta, saturation_delta, value_delta]
+        g *= np.random.randint(0, 2, 3)
+        out[i] = g.astype(np.int16)
+    return out
+
+
+def hsv_jitter(images_u8, gains):
+    """HSVRandomAug on a device batch of uint8 BGR images [N,H,W,3] (a copy is jittered and returned)."""
+    _lib.require_device()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    img = torch.as_tensor(images_u8).to(dev)
+    if img.dtype != torch.uint8 or img.dim() != 4 or img.shape[3] != 3:
+        raise _lib.LhnError("hsv_jitter: images must be uint8 [N,H,W,3]")
+    img = img.contiguous().clone()
+    g = torch.as_tensor(np.asarray(gains, np.int16)).to(dev).contiguous()
+    if tuple(g.shape) != (img.shape[0], 3):
+        raise _lib.LhnError("hsv_jitter: gains must be int16 [N,3]")
+    _lib.check(_lib.lib().lhn_hsv_jitter(_lib.ptr(img), _lib.ptr(g), int(img.shape[0]), int(img.shape[1]), int(img.shape[2]),
+                                         _lib.stream()), "lhn_hsv_jitter")
+    return img
+
+
+def random_scale_rotation(scale, rot_factor=40, scale_factor=0.5, rot_prob=0.6):
+    """TopDownGetRandomScaleRotation.__call__ (topdown_affine.py:28-45) for a batch: three draws per sample from numpy's global
+    generator in the reference's order (randn, randn, rand) -> (scale * s_factor [n,2], rotation [n] degrees).  Host side: three
+    numbers per sample; the arithmetic on the image is lhn_affine_warp_normalize."""
+    scale = np.asarray(scale)
+    out_s, out_r = np.empty(scale.shape, np.float64), np.empty(scale.shape[0], np.float64)
+    for i in range(scale.shape[0]):
+        s_factor = np.clip(np.random.randn() * scale_factor + 1, 1 - scale_factor, 1 + scale_factor)
+        r_factor = np.clip(np.random.randn() * rot_factor, -rot_factor * 2, rot_factor * 2)
+        out_r[i] = r_factor if np.random.rand() <= rot_prob else 0
+        out_s[i] = scale[i] * s_factor
+    return out_s, out_r
 
 
 def random_flip(joints, visible, center, flipped, flip_pairs, img_width):
@@ -83,3 +125,31 @@ class TopDownBatchPipeline:
         if self.k > 0:
             meta["simdr_x"], meta["simdr_y"] = heatmap.generate_simdr_batch(j, vis, self.image_size, self.k, self.sigma)
         return img, meta
+
+
+class TopDownTrainPipeline(TopDownBatchPipeline):
+    """The TRAINING pipeline of build_dataset.py:111-122 for a batch resident on the GPU, in the reference's order: HSVRandomAug
+    -> TopDownRandomFlip -> TopDownGetRandomScaleRotation -> TopDownAffine -> ToTensor / NormalizeTensor -> targets.  The random
+    numbers come from numpy's global generator on the host, drawn per transform for the whole batch (the reference draws them
+    per sample inside DataLoader workers, so the streams differ by construction; each transform's draws are the reference's)."""
+
+    def __init__(self, cfg, flip_pairs=()):
+        super().__init__(cfg)
+        P = cfg.PIPELINE
+        self.flip_prob = float(P.get("flip_prob", 0.5))
+        self.rot_factor, self.scale_factor, self.rot_prob = P.get("rot_factor", 40), P.get("scale_factor", 0.5), P.get("rot_prob", 0.6)
+        self.flip_pairs = list(flip_pairs)
+
+    def __call__(self, images_u8, center, scale, joints, visible):
+        n = int(torch.as_tensor(images_u8).shape[0])
+        img = hsv_jitter(images_u8, hsv_gains(n))
+        flipped = np.random.rand(n) <= self.flip_prob                       # RandomFlip.py:45
+        j, v, c = random_flip(joints, visible, center, flipped, self.flip_pairs, int(img.shape[2]))
+        s, r = random_scale_rotation(np.asarray(torch.as_tensor(scale).cpu()), self.rot_factor, self.scale_factor, self.rot_prob)
+        out, jj = affine_warp_normalize(img, c, s.astype(np.float32), r.astype(np.float32), self.image_size, j, v, use_udp=self.use_udp,
+                                        flipped=flipped)
+        target, weight = heatmap.generate_target_batch(jj, v, self.image_size, self.heatmap_size, self.sigma, self.unbiased, self.encoding)
+        meta = {"target": target, "target_weight": weight, "joints_3d": jj, "rotation": r, "scale": s, "flipped": flipped}
+        if self.k > 0:
+            meta["simdr_x"], meta["simdr_y"] = heatmap.generate_simdr_batch(jj, v, self.image_size, self.k, self.sigma)
+        return out, meta

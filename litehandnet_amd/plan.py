@@ -393,8 +393,19 @@ class PlanBuilder:
 
         if self.with_backward:
             rec["gsum_b"] = self._ws("misc", 2 * Cc * 8)
-            rec["dgate"] = self._ws("misc", self.N * Cc * 4)
+            rec["dgate"] = self._ws("misc", 3 * self.N * Cc * 4)       # dgate | T0, T1 of the gate-gradient pass (bnslices)
             b.dpool = True
+            # BatchNorm-backward sums of the convolutions that wrote this buffer: assembled by the attention's backward from the
+            # gate-gradient pass and the forward pooling pass (include/lhn.h: lhn_bn_slices) -- their lhn_bn_bwd_reduce passes
+            # over the feature map and its gradient disappear.  LHN_GATE_BN_SUMS=0: separate passes.
+            prods = [q for q in self.recs if q["op"] in (STEM, PW, DW, KXK) and q["bn"] is not None and
+                     not isinstance(q["out"], TCat) and q["out"].buf == y.buf]
+            if os.environ.get("LHN_GATE_BN_SUMS", "1") != "0" and 1 <= len(prods) <= 2 and not hasattr(ca, "rbr_reparam") and \
+                    all(not q.get("wrc", (0, 0))[0] and q.get("bn_repeat", 1) == 1 for q in prods):
+                rec["bnslices"] = prods
+                rec["pstat"] = self._ws("misc", self.N * 9 * 2 * Cc * 4)
+                for q in prods:
+                    q["sums_by_ca"] = True
         self.recs.append(rec)
         b.gate = True
         return y
@@ -491,7 +502,7 @@ class PlanBuilder:
             o.out_buf = -1
         for k in range(12):
             o.p[k] = p[k] if k < len(p) else -1
-        for k in range(6):
+        for k in range(12):
             o.ws[k] = ws[k] if k < len(ws) else -1
         for k in range(8):
             o.i[k] = i[k] if k < len(i) else 0
@@ -500,43 +511,6 @@ class PlanBuilder:
         for k in range(3):
             o.pend[k][0] = o.pend[k][1] = -1
         return o
-
-    DEFER_READERS = {PW: 3, DW: 2, EW: 3, MAXPOOL: 1, AVGPOOL: 1}      # op kind -> input slots whose kernels take lhn_pend
-
-    def _defer_finalizes(self, fwd):
-        """Hand every train-mode BatchNorm finalize to the FIRST forward reader of the convolution's output when that reader's
-        kernel can do it in its prologue (include/lhn.h: lhn_pend): the producer gets i[7] = 1 (no finalize launch in a plain
-        training run), the reader lists the producer in pend[slot].  Anything else keeps the separate launch."""
-        self.deferred = 0
-        for i, o in enumerate(fwd):
-            if o.kind not in (STEM, PW, DW, KXK) or o.p[2] < 0 or o.out_buf < 0 or o.ws[0] < 0 or o.out_C > 128 or \
-                    (o.kind == PW and o.i[2] > 0) or o.f[3] > 1:
-                continue
-            lo, hi = o.out_coff, o.out_coff + o.out_C
-            if self.bufs[o.out_buf].C > 256:
-                continue
-            for r in fwd[i + 1:]:
-                slots = [k for k in range(3) if r.in_buf[k] == o.out_buf and r.in_coff[k] < hi and lo < r.in_coff[k] + r.in_C[k]]
-                if r.kind in (PW, DW):
-                    slots = [k for k in slots if k < max(1, r.i[6])]      # in_buf[1..] only count for multi-source ops
-                elif r.kind in (MAXPOOL, AVGPOOL, KXK):
-                    slots = [k for k in slots if k == 0]
-                elif r.kind == EW:
-                    slots = [k for k in slots if k < r.i[0]]
-                elif r.kind == SHUFFLE:
-                    slots = [k for k in slots if k < 2]          # a reader whose kernel cannot finalize: no deferral
-                elif r.kind not in (PW, DW, KXK):
-                    slots = []
-                if not slots:
-                    continue
-                k = slots[0]
-                ok = r.kind in self.DEFER_READERS and k < self.DEFER_READERS[r.kind] and len(slots) == 1 and \
-                    not (r.kind == PW and (r.in_C[k] > 128 or r.i[1])) and r.pend[k][1] < 0
-                if ok:
-                    r.pend[k][0 if r.pend[k][0] < 0 else 1] = i
-                    o.i[7] = 1
-                    self.deferred += 1
-                break
 
     def _xs(self, r):
         """(input views, number of sources, coefficient slots f[4..6]) of a convolution record: the operands of a lazy sum
@@ -654,7 +628,7 @@ class PlanBuilder:
                     fwd.append(mk(KXK, ins=(x,), out=out, p=(pw, cb) + pbn, ws=(tuple(wsl) + (-1, -1, -1))[:3] + (self._abs(r["wt"]),),
                                   i=(r["stride"],), f=fl))
             elif k == EW:
-                if r.get("lazy"):
+                if r.get("lazy") or r.get("fwd_fused"):
                     continue
                 if "flat" in r:
                     # a lazy sum that had to be materialised after all (a reader that cannot add on load): launched on the
@@ -704,7 +678,13 @@ class PlanBuilder:
                               f=(bn.eps, bn.momentum)))
             elif k == CA_MLP:
                 y, ca = r["y"], r["ca"]
-                fwd.append(mk(AVGPOOL, ins=(y,), ws=(self._abs(r["pooled"]),), i=(3, 3, 1)))
+                sl = r.get("bnslices")
+                pins = (y, r["copy"]["srcs"][0]) if r.get("copy") else (y,)       # second input: pass-through half copied by this launch
+                if sl:      # pooling pass that also leaves M0, M1 per (n, bin, c) for the backward (lhn_avgpool_fwd4)
+                    fwd.append(mk(AVGPOOL, ins=pins, ws=(self._abs(r["pooled"]), self._abs(r["pstat"])) + tuple(self._abs(q["save"]) for q in sl),
+                                  i=(3, 3, 1, 0, 0) + tuple((q["out"].coff << 16) | q["out"].C for q in sl)))
+                else:
+                    fwd.append(mk(AVGPOOL, ins=pins, ws=(self._abs(r["pooled"]),), i=(3, 3, 1)))
                 bn = ca.conv3x3.bn
                 fwd.append(mk(CA_MLP, out=y,
                               p=(self._p(ca.conv3x3.conv.weight), self._p(bn.weight), self._p(bn.bias),
@@ -715,12 +695,9 @@ class PlanBuilder:
                               f=(bn.eps, bn.momentum)))
             else:
                 raise AssertionError(k)
-        # measured on MI355X (profiles/r02c_*): every workgroup of the reader re-reading the replicated sums costs more than
-        # the ~5.7 us single-workgroup launch it removes (3x3 depthwise 21.7 -> 30.3 us, forward 2.75 -> 2.88 ms), so the
-        # separate finalize stays the default; LHN_DEFER_FINALIZE=1 selects the deferred form
-        self.deferred = 0
-        if os.environ.get("LHN_DEFER_FINALIZE", "0") == "1":
-            self._defer_finalizes(fwd)
+        # (round 2's deferred finalize -- the first reader of a convolution folding the replicated statistics in its prologue --
+        # was measured slower than the separate ~5 us launch and is gone: DESIGN.md section 5.2; the kernels' lhn_pend inputs stay
+        # empty)
         # ---------------- backward
         if self.with_backward:
             written = {}
@@ -818,7 +795,7 @@ class PlanBuilder:
                     if bn is not None:
                         body.append(mk(BN_BWD, out=out, p=(self._p(bn.weight), self._p(bn.weight), self._p(bn.bias)),
                                        ws=(self._abs(r["sums"]), self._abs(r["save"]), self._abs(r["bcnt"])),
-                                       i=(r["wrc"][0] if k == PW else 0, 1 if r.get("sums_by_reader") else 0)))
+                                       i=(r["wrc"][0] if k == PW else 0, 1 if (r.get("sums_by_reader") or r.get("sums_by_ca")) else 0)))
                     if k == STEM:
                         body.append(mk(STEM_BWD, out=out, p=(pw, pw), i=(r["k"], r["stride"], r["pad"], x.H, x.W, use_coef)))
                         continue
@@ -841,8 +818,8 @@ class PlanBuilder:
                                 x.C % 32 == 0 and x.W >= 8 and not xb.gate and not xb.dpool and xb.lazy is None and
                                 conv.weight is not None and len(uses.get(x.buf, ())) == 1 and x.buf not in aliased):
                             for q in self.recs:
-                                if q["op"] in (PW, DW, KXK) and q["bn"] is not None and q["out"].buf == x.buf and \
-                                        (q["out"].coff, q["out"].C) == (x.coff, x.C) and not q["wrc"][0] and q.get("bn_repeat", 1) == 1:
+                                if q["op"] in (STEM, PW, DW, KXK) and q["bn"] is not None and q["out"].buf == x.buf and \
+                                        (q["out"].coff, q["out"].C) == (x.coff, x.C) and not q.get("wrc", (0, 0))[0] and q.get("bn_repeat", 1) == 1:
                                     prod = q
                         adds = pending_add.get(x.buf)
                         if adds and need_dx:
@@ -916,7 +893,11 @@ class PlanBuilder:
                 elif k == CA_MLP:
                     y, ca = r["y"], r["ca"]
                     bn = ca.conv3x3.bn
-                    body.append(mk(GATE_REDUCE, out=y, ws=(-1, -1, -1, self._abs(r["dgate"]))))
+                    sl = r.get("bnslices") or []
+                    pk = tuple((q["out"].coff << 16) | q["out"].C for q in sl)
+                    sv = (tuple(self._abs(q["save"]) for q in sl) + (-1, -1))[:2]
+                    sm = (tuple(self._abs(q["sums"]) for q in sl) + (-1, -1))[:2]
+                    body.append(mk(GATE_REDUCE, out=y, ws=(-1, -1, -1, self._abs(r["dgate"]), 1 if sl else -1) + sv, i=pk))
                     body.append(mk(CA_MLP_BWD, out=y,
                                    p=(self._p(ca.conv3x3.conv.weight), self._p(bn.weight), self._p(ca.conv1x1[1].weight),
                                       self._p(ca.conv1x1[3].weight),
@@ -924,7 +905,7 @@ class PlanBuilder:
                                       self._p(ca.conv1x1[1].weight), self._p(ca.conv1x1[1].bias),
                                       self._p(ca.conv1x1[3].weight), self._p(ca.conv1x1[3].bias)),
                                    ws=(self._abs(r["pooled"]), self._abs(r["save"]), self._abs(r["mask"]),
-                                       self._abs(r["dgate"]), self._abs(r["gsum_b"]))))
+                                       self._abs(r["dgate"]), self._abs(r["gsum_b"]), self._abs(r.get("pstat"))) + sv + sm, i=pk))
             if self.ar["zb"].size:
                 bwd.append(mk(MEMSET, ws=(self.arena_base["zb"], self.ar["zb"].size)))
             for b in sorted(self._needs_zero_grad):
@@ -946,19 +927,19 @@ class PlanBuilder:
                     elif o.kind == AVGPOOL_BWD and o.in_buf[0] in self._needs_zero_grad:
                         o.i[2] = 1
             bwd += body
-        # ---------------- SyncBatchNorm: (op index, byte offset, number of doubles) of every statistics buffer that has
+        # ---------------- SyncBatchNorm: (op index, byte offset, number of doubles, replicated layout?) of every statistics buffer that has
         # to be all-reduced between half-step 2*i and 2*i+1 of lhn_plan_run_range
         self.sync_points = {0: [], 1: []}
         for phase, lst in ((0, fwd), (1, bwd)):
             for i, o in enumerate(lst):
                 if o.kind in (STEM, PW, DW, KXK) and o.p[2] >= 0 and o.ws[0] >= 0:
-                    self.sync_points[0].append((i, o.ws[0], STAT_REPLICAS * 2 * o.out_C))
+                    self.sync_points[0].append((i, o.ws[0], STAT_REPLICAS * 2 * o.out_C, True))
                 elif o.kind in (CA_MLP, ATT_MLP) and o.ws[3] >= 0:
-                    self.sync_points[0].append((i, o.ws[3], 2 * o.out_C))
+                    self.sync_points[0].append((i, o.ws[3], 2 * o.out_C, False))
                 elif o.kind == BN_BWD:
-                    self.sync_points[1].append((i, o.ws[0], STAT_REPLICAS * 2 * o.out_C))
+                    self.sync_points[1].append((i, o.ws[0], STAT_REPLICAS * 2 * o.out_C, True))
                 elif o.kind in (CA_MLP_BWD, ATT_MLP_BWD) and o.ws[4] >= 0:
-                    self.sync_points[1].append((i, o.ws[4], 2 * o.out_C))
+                    self.sync_points[1].append((i, o.ws[4], 2 * o.out_C, False))
         # ---------------- C arrays
         cb = (Buf * len(self.bufs))()
         for j, b in enumerate(self.bufs):
@@ -1099,9 +1080,17 @@ class CompiledPlan:
                                           _lib.stream())
                 _lib.check(rc, "lhn_plan_run_range")
             begin = 0
-            for oi, off, n in self.pb.sync_points[phase]:
+            self.sync_wire_doubles = 0
+            for oi, off, n, replicated in self.pb.sync_points[phase]:
                 run_range(begin, 2 * oi + 1)
+                if replicated:
+                    # replicated [32][2][C] sums: folded on the device first, only [2][C] doubles cross the wire
+                    m = n // STAT_REPLICAS
+                    _lib.check(L.lhn_fold_stat_replicas(C.c_void_p(self.ws.data_ptr() + off), C.c_int64(m), STAT_REPLICAS, _lib.stream()),
+                               "lhn_fold_stat_replicas")
+                    n = m
                 allreduce(self.ws[off:off + 8 * n].view(torch.float64))
+                self.sync_wire_doubles += n
                 begin = 2 * oi + 1
             run_range(begin, nsteps)
             return

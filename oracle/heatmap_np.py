@@ -438,3 +438,86 @@ def candidate_bbox(center_maps, size_maps, num_candidates, image_size):
     cand[..., :2] *= np.float32(image_size / w)
     cand[..., 2:4] *= np.float32(image_size)
     return cand
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Training-time augmentation (datasets/build_dataset.py:111-122).  PARITY UNPINNED for the colour conversion: the reference
+# calls cv2.cvtColor, cv2 is not importable here; the 8-bit conversions below restate OpenCV's documented algorithm
+# (imgproc color_hsv: fixed-point RGB2HSV_b with hsv_shift = 12, hue range 180; HSV2RGB_b through the float sector formula).
+# The reference's own integer arithmetic on the HSV planes (random_hsv.py:22-31) and its random draws are restated exactly.
+def hsv_gains(n, hue_delta=5, saturation_delta=30, value_delta=30):
+    """random_hsv.py:22-29 for n samples in sequence (numpy's GLOBAL generator, same calls in the same order as the
+    reference's per-sample __call__): int16 [n, 3]."""
+    out = np.zeros((n, 3), np.int16)
+    for i in range(n):
+        g = np.random.uniform(-1, 1, 3) * [hue_delta, saturation_delta, value_delta]
+        g *= np.random.randint(0, 2, 3)
+        out[i] = g.astype(np.int16)
+    return out
+
+
+def _cv_round(x):
+    return np.rint(x)          # cvRound: round half to even
+
+
+def bgr2hsv_u8(img):
+    """cv2.cvtColor(img, cv2.COLOR_BGR2HSV) for uint8 [..., 3] (H in [0, 180))."""
+    b, g, r = (img[..., k].astype(np.int32) for k in range(3))
+    v = np.maximum(np.maximum(b, g), r)
+    vmin = np.minimum(np.minimum(b, g), r)
+    diff = v - vmin
+    idx = np.arange(256, dtype=np.float64)
+    with np.errstate(divide="ignore"):
+        sdiv = np.where(idx > 0, _cv_round((255 << 12) / np.maximum(idx, 1)), 0).astype(np.int64)
+        hdiv = np.where(idx > 0, _cv_round((180 << 12) / (6.0 * np.maximum(idx, 1))), 0).astype(np.int64)
+    s = (diff * sdiv[v] + (1 << 11)) >> 12
+    h = np.where(v == r, g - b, np.where(v == g, b - r + 2 * diff, r - g + 4 * diff)).astype(np.int64)
+    h = (h * hdiv[diff] + (1 << 11)) >> 12
+    h = h + np.where(h < 0, 180, 0)
+    return np.stack([np.clip(h, 0, 255), s, v], -1).astype(np.uint8)
+
+
+def hsv2bgr_u8(hsv):
+    """cv2.cvtColor(hsv, cv2.COLOR_HSV2BGR) for uint8 [..., 3]: float sector formula, h * 6/180, s, v / 255, x 255, rounded."""
+    h = hsv[..., 0].astype(np.float32) * np.float32(6.0 / 180.0)
+    s = hsv[..., 1].astype(np.float32) * np.float32(1.0 / 255.0)
+    v = hsv[..., 2].astype(np.float32) * np.float32(1.0 / 255.0)
+    h = np.where(h >= 6, h - np.float32(6.0), h)
+    sector = np.floor(h).astype(np.int32)
+    f = (h - sector.astype(np.float32)).astype(np.float32)
+    bad = (sector < 0) | (sector >= 6)
+    sector = np.where(bad, 0, sector)
+    f = np.where(bad, np.float32(0), f)
+    one = np.float32(1.0)
+    tab = np.stack([v, (v * (one - s)).astype(np.float32), (v * (one - (s * f).astype(np.float32))).astype(np.float32),
+                    (v * (one - (s * (one - f)).astype(np.float32))).astype(np.float32)], -1)
+    sd = np.array([[1, 3, 0], [1, 0, 2], [3, 0, 1], [0, 2, 1], [0, 1, 3], [2, 1, 0]])
+    pick = sd[sector]                                                   # [..., 3] indices of (b, g, r)
+    bgr = np.take_along_axis(tab, pick, -1)
+    bgr = np.where((hsv[..., 1] == 0)[..., None], v[..., None], bgr)
+    return np.clip(_cv_round(bgr.astype(np.float32) * np.float32(255.0)), 0, 255).astype(np.uint8)
+
+
+def hsv_jitter(img_bgr_u8, gains):
+    """HSVRandomAug.__call__ (random_hsv.py:20-34) with the gains given: [H, W, 3] uint8 BGR -> jittered BGR."""
+    hsv = bgr2hsv_u8(img_bgr_u8).astype(np.int16)
+    g = np.asarray(gains, np.int16)
+    hsv[..., 0] = (hsv[..., 0] + g[0]) % 180
+    hsv[..., 1] = np.clip(hsv[..., 1] + g[1], 0, 255)
+    hsv[..., 2] = np.clip(hsv[..., 2] + g[2], 0, 255)
+    return hsv2bgr_u8(hsv.astype(np.uint8))
+
+
+def random_scale_rotation(scale, rot_factor=40, scale_factor=0.5, rot_prob=0.6):
+    """TopDownGetRandomScaleRotation.__call__ (topdown_affine.py:28-45) for a batch in sequence (numpy's global generator):
+    scale [n, 2] -> (scale * s_factor, rotation [n])."""
+    scale = np.asarray(scale)
+    out_s, out_r = [], []
+    for i in range(scale.shape[0]):
+        sf, rf = scale_factor, rot_factor
+        s_factor = np.clip(np.random.randn() * sf + 1, 1 - sf, 1 + sf)
+        r_factor = np.clip(np.random.randn() * rf, -rf * 2, rf * 2)
+        r = r_factor if np.random.rand() <= rot_prob else 0
+        out_s.append(scale[i] * s_factor)
+        out_r.append(r)
+    return np.stack(out_s), np.array(out_r, np.float64)

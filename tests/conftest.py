@@ -36,7 +36,7 @@ _PARITY = {}
 def parity_record(tag, **numbers):
     e = _PARITY.setdefault(tag, {})
     for k, v in numbers.items():
-        e[k] = (float(v) if isinstance(v, (int, float)) or hasattr(v, "__float__") else v)
+        e[k] = v if isinstance(v, (str, list, dict, bool)) else float(v)
 
 
 def pytest_sessionfinish(session, exitstatus):

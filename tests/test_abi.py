@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_builds_and_loads():
     build.build_lib(verbose=False)
     L = _lib.lib()
-    assert L.lhn_version() == 2
+    assert L.lhn_version() == 3
 
 
 def test_header_symbols_exported():

@@ -343,3 +343,55 @@ def test_topk_candidates(dev, golden_dir):
     o2 = heatmap.candidate_bbox(nms, None, 5, 256.0).cpu().numpy()
     want = onp.candidate_bbox(onp.heatmap_nms(g["centre"][:, None], 11)[:, 0], None, 5, 256.0)
     assert np.array_equal(o2, want)
+
+
+def test_hsv_jitter_and_train_pipeline(dev):
+    """HSVRandomAug on the GPU (random_hsv.py:20-34) against the numpy oracle: bit-exact on random images, on all-grey pixels
+    (s = 0), saturated primaries and with every gain pattern the reference can draw (the oracle's colour conversion restates
+    OpenCV's 8-bit algorithm: parity with cv2 itself is unpinned, cv2 is not importable).  Properties that do not depend on
+    OpenCV's rounding: zero gains change no channel by more than 6 levels (8-bit hue has 180 steps).
+    Then the whole training pipeline object (HSV -> flip -> scale/rotation -> affine -> targets) against the same steps of the
+    oracle under one numpy seed."""
+    from litehandnet_amd import pipeline
+    r = np.random.Generator(np.random.PCG64(123))
+    n, h, w = 6, 40, 52
+    img = r.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+    img[0, :4] = r.integers(0, 256, (4, w, 1), dtype=np.uint8)          # grey rows: s = 0
+    img[1, 0, :6] = [[255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 0], [0, 0, 0], [255, 255, 255]]
+    gains = np.array([[0, 0, 0], [5, 30, 30], [-5, -30, -30], [4, 0, -17], [-3, 29, 0], [0, -12, 30]], np.int16)
+    out = pipeline.hsv_jitter(torch.from_numpy(img), gains).cpu().numpy()
+    for k in range(n):
+        assert np.array_equal(out[k], onp.hsv_jitter(img[k], gains[k])), k
+    assert np.abs(out[0].astype(int) - img[0].astype(int)).max() <= 6                 # zero gains: conversion round trip only
+    np.random.seed(99)
+    g1 = pipeline.hsv_gains(50)
+    np.random.seed(99)
+    assert np.array_equal(g1, onp.hsv_gains(50)) and g1.dtype == np.int16
+    assert np.abs(g1[:, 0]).max() <= 5 and np.abs(g1[:, 1:]).max() <= 30 and (g1 == 0).mean() > 0.3
+    # whole training pipeline, one numpy stream for both sides
+    cfg = litehandnet_cfg("B", image_size=64)
+    pairs = [(1, 2), (3, 4)]
+    pipe = pipeline.TopDownTrainPipeline(cfg, flip_pairs=pairs)
+    K = cfg.DATASET.num_joints
+    joints = np.zeros((n, K, 3), np.float32)
+    joints[..., :2] = r.uniform(4, 36, (n, K, 2)).astype(np.float32)
+    vis = np.ones((n, K, 3), np.float32)
+    vis[..., 2] = 0
+    center = r.uniform(18, 30, (n, 2)).astype(np.float32)
+    scale = r.uniform(0.15, 0.25, (n, 2)).astype(np.float32)
+    np.random.seed(7)
+    x, meta = pipe(torch.from_numpy(img), center, scale, joints, vis)
+    np.random.seed(7)
+    gn = onp.hsv_gains(n)
+    fl = np.random.rand(n) <= pipe.flip_prob
+    s2, r2 = onp.random_scale_rotation(scale, pipe.rot_factor, pipe.scale_factor, pipe.rot_prob)
+    assert np.array_equal(meta["flipped"], fl) and np.array_equal(meta["rotation"], r2) and np.array_equal(meta["scale"], s2)
+    assert tuple(x.shape) == (n, 3, 64, 64) and tuple(meta["target"].shape) == (n, K, 16, 16)
+    for k in range(n):
+        im = onp.hsv_jitter(img[k], gn[k])
+        jk, vk, ck = joints[k], vis[k], center[k]
+        if fl[k]:
+            im, jk, vk, ck = onp.random_flip(im, jk, vk, ck, pairs)
+        ref, M = onp.warp_affine_normalize(np.ascontiguousarray(im), ck, s2[k].astype(np.float32), np.float32(r2[k]), [64, 64])
+        d = np.abs(x[k].cpu().numpy() - ref)
+        assert (d > 1e-5).mean() < 0.02 and d.max() <= 1.01 / 255 / 0.224, (k, float(d.max()))      # see test_gpu_input_path

@@ -340,3 +340,26 @@ def test_litehrnet_fixture(golden_dir):
     m.train()
     y = m(synth.synth_images(int(g["n"]), int(g["size"]), int(g["seed"])))
     assert np.abs(y.detach().numpy() - g["heatmap"]).max() <= 1e-5 * np.abs(g["heatmap"]).max()
+
+
+def test_hsv_oracle_properties():
+    """oracle.heatmap_np HSV pieces (random_hsv.py:20-34; colour conversion = OpenCV's 8-bit algorithm restated, parity with
+    cv2 unpinned): primaries land on OpenCV's documented hues (red 0, green 60, blue 120 at hue range 180), grey has s = 0, the
+    BGR -> HSV -> BGR round trip (hue has 180 levels) moves no channel by more than 6 levels, 0.6 on average, and the integer jitter wraps hue mod 180 / clips."""
+    from oracle import heatmap_np as onp
+    prim = np.array([[[0, 0, 255], [0, 255, 0], [255, 0, 0], [128, 128, 128], [0, 255, 255]]], np.uint8)
+    hsv = onp.bgr2hsv_u8(prim)[0]
+    assert hsv[:, 0].tolist() == [0, 60, 120, 0, 30] and hsv[:, 1].tolist() == [255, 255, 255, 0, 255] and hsv[:, 2].tolist() == [255, 255, 255, 128, 255]
+    r = np.random.Generator(np.random.PCG64(3))
+    img = r.integers(0, 256, (48, 48, 3), dtype=np.uint8)
+    back = onp.hsv2bgr_u8(onp.bgr2hsv_u8(img))
+    d = np.abs(back.astype(int) - img.astype(int))
+    assert d.max() <= 6 and d.mean() < 0.6
+    assert np.array_equal(onp.hsv_jitter(img, [0, 0, 0]), back)
+    a, b = onp.hsv_jitter(img, [5, 0, 0]), onp.hsv_jitter(img, [5 - 180, 0, 0])
+    assert np.array_equal(a, b)                                       # hue wraps mod 180
+    assert onp.hsv_jitter(prim, [0, 0, 30])[0, 3].tolist() == [158, 158, 158] and onp.hsv_jitter(prim, [0, 0, -300])[0].max() == 0
+    np.random.seed(5)
+    g = onp.hsv_gains(200)
+    assert g.dtype == np.int16 and np.abs(g[:, 0]).max() <= 5 and np.abs(g[:, 1:]).max() <= 30
+    assert 0.4 < (g[:, 1] == 0).mean() < 0.65                         # randint(0, 2) switches each channel off half of the time

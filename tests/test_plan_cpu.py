@@ -47,7 +47,7 @@ def test_plan_structure(variant):
     assert pb.grad_aliases >= 4                                         # residual-add sources share their consumer's gradient
     # SyncBatchNorm cut points: one per statistics buffer and direction, in launch order
     for phase in (0, 1):
-        ois = [oi for oi, _, _ in pb.sync_points[phase]]
+        ois = [oi for oi, _, _, _ in pb.sync_points[phase]]
         assert ois == sorted(ois) and len(ois) >= 60
     # channel slices stay inside their buffers and 16-byte aligned
     for b in pb.bufs:
@@ -174,54 +174,34 @@ def test_lazy_sums_are_summed_on_load(monkeypatch):
     assert sum(1 for r in pa.recs if r["op"] == EW and r.get("lazy")) == 2
 
 
-def test_deferred_finalizes(monkeypatch):
-    """Every train-mode BatchNorm of variant B is finalized by the first reader of its convolution's output (lhn_pend): the
-    producer is flagged, exactly one later op lists it, readers are kernels that can do it and hold at most two; the
-    default (LHN_DEFER_FINALIZE unset / 0) keeps the separate launches."""
-    from litehandnet_amd.plan import AVGPOOL, DW, EW, KXK, MAXPOOL, PW, STEM
-    monkeypatch.setenv("LHN_DEFER_FINALIZE", "1")          # (off by default: measured slower, see PlanBuilder.finalize)
-    _, pb, _ = _build("B", backward=True)
-    cb, cf, cbw, nf, nb = pb.finalize()
-    fwd = [cf[i] for i in range(nf)]
-    prod = [i for i, o in enumerate(fwd) if o.kind in (STEM, PW, DW, KXK) and o.p[2] >= 0]
-    assert len(prod) == 52 and pb.deferred == 52 and all(fwd[i].i[7] == 1 for i in prod)
-    listed = {}
-    for j, o in enumerate(fwd):
-        for k in range(3):
-            for e in range(2):
-                if o.pend[k][e] >= 0:
-                    assert o.kind in (PW, DW, EW, MAXPOOL, AVGPOOL) and o.pend[k][e] < j
-                    assert o.in_buf[k] == fwd[o.pend[k][e]].out_buf
-                    listed[o.pend[k][e]] = listed.get(o.pend[k][e], 0) + 1
-    assert sorted(listed) == prod and set(listed.values()) == {1}
-    # variant A keeps separate launches where the first reader is the dense 3x3 kernel
-    _, pa, _ = _build("A", backward=False)
-    pa.finalize()
-    assert 0 < pa.deferred < sum(1 for r in pa.recs if r["op"] in (STEM, PW, DW, KXK) and r["bn"] is not None)
-    monkeypatch.setenv("LHN_DEFER_FINALIZE", "0")
-    _, p0, _ = _build("B", backward=False)
-    cb, cf, _, nf, _ = p0.finalize()
-    assert all(cf[i].i[7] == 0 and all(cf[i].pend[k][e] == -1 for k in range(3) for e in range(2)) for i in range(nf))
-
-
 def test_bn_backward_sums_ride_in_the_reader(monkeypatch):
-    """RepBasicUnit's 1x1 -> 3x3 depthwise: the depthwise backward is the only reader of the 1x1's output, so it also
-    accumulates that BatchNorm's backward sums (lhn_conv_dw_bwd2) and the producer's BN_BWD op skips its reduce pass:
-    18 of variant B's 52, none where the reader is not a stride-1 3x3 depthwise; LHN_FUSE_BN_SUMS=0 switches it off."""
-    from litehandnet_amd.plan import BN_BWD, DW_BWD
+    """RepBasicUnit's 1x1 -> 3x3 depthwise (and the stem's 3x3 -> 3x3 depthwise): the depthwise backward is the only reader of
+    the producer's output, so it also accumulates that BatchNorm's backward sums (lhn_conv_dw_bwd2) and the producer's BN_BWD
+    op skips its reduce pass: 19 of variant B's 52.  The 12 convolutions that write GATED buffers (8 MSRB branches, 4 gated
+    RepBasicUnits) get their sums from the attention's backward (lhn_ca_mlp_bwd2: lhn_bn_slices) -- also no reduce pass.
+    LHN_FUSE_BN_SUMS=0 / LHN_GATE_BN_SUMS=0 switch the two off."""
+    from litehandnet_amd.plan import BN_BWD, CA_MLP_BWD, DW_BWD, GATE_REDUCE
     _, pb, _ = _build("B", backward=True)
     cb, cf, cbw, nf, nb = pb.finalize()
     bwd = [cbw[i] for i in range(nb)]
     fused = [o for o in bwd if o.kind == DW_BWD and o.ws[4] >= 0]
     skipped = [o for o in bwd if o.kind == BN_BWD and o.i[1] == 1]
-    assert pb.fused_bn_sums == len(fused) == len(skipped) == 18
-    assert {o.ws[4] for o in fused} == {o.ws[0] for o in skipped}          # the same sums buffers
+    ca = [o for o in bwd if o.kind == CA_MLP_BWD]
+    by_ca = {o.ws[k] for o in ca for k in (8, 9) if o.ws[k] >= 0}
+    assert pb.fused_bn_sums == len(fused) == 19 and len(by_ca) == 12 and len(skipped) == 31
+    assert {o.ws[4] for o in fused} | by_ca == {o.ws[0] for o in skipped}          # the same sums buffers
     for o in fused:
         assert o.i[4] == 1 and o.i[0] == 3 and o.i[1] == 1 and o.i[3] == 1 and o.ws[5] >= 0        # dx stored, 3x3 s1 d1
+    for o in ca:
+        assert o.ws[5] >= 0 and o.ws[6] >= 0 and o.i[0] > 0           # pooling statistics, saved mean / invstd, packed slice
+    assert all(o.ws[4] >= 0 for o in bwd if o.kind == GATE_REDUCE)    # the gate-gradient pass also leaves T0, T1
+    fwd = [cf[i] for i in range(nf)]
+    assert sum(1 for o in fwd if o.kind == AVGPOOL and o.ws[1] >= 0) == 8
     monkeypatch.setenv("LHN_FUSE_BN_SUMS", "0")
+    monkeypatch.setenv("LHN_GATE_BN_SUMS", "0")
     _, p0, _ = _build("B", backward=True)
-    p0.finalize()
-    assert p0.fused_bn_sums == 0
+    cb, cf, cbw, nf, nb = p0.finalize()
+    assert p0.fused_bn_sums == 0 and not any(cbw[i].kind == BN_BWD and cbw[i].i[1] == 1 for i in range(nb))
 
 
 def test_residual_sum_gradients_ride_in_the_depthwise_backward(monkeypatch):

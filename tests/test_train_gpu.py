@@ -210,6 +210,10 @@ def _dp_worker(rank, world, port, outdir):
         y = model(x)
         ((y * g[rank * n:(rank + 1) * n].to(dev)).sum() / n).backward()
         fg = allreduce_mean_(eng.flat_grads)
+        # the replicated [32][2][C] sums are folded on the device before the exchange: [2][C] doubles per BatchNorm on the wire
+        plan = next(iter(eng.plans.values()))
+        wire = sum((n // 32 if rep else n) for _, _, n, rep in plan.pb.sync_points[1])
+        assert plan.sync_wire_doubles == wire and wire * 32 <= sum(n for _, _, n, _ in plan.pb.sync_points[1]) + 31 * 8 * 2 * 128
         sd = model.state_dict()
         k = sorted(k for k in sd if k.endswith("running_var"))[3]
         np.savez(os.path.join(outdir, f"r{rank}.npz"), y=y.detach().cpu().numpy(), grads=fg.cpu().numpy(), rv=sd[k].cpu().numpy())
