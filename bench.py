@@ -328,6 +328,10 @@ def main():
         "forward_images_per_s": round(B / (fwd_ms * 1e-3), 1),
     }
     if a_el is not None:
+        # the model the reference REGISTERS as `litehandnet` (models/__init__.py:11) is variant A; `value` is the MSRB hourglass
+        # (variant B) that north_star's roofline target names -- both at the top level so that neither reads as the other
+        out["value_registered_litehandnet"] = round(B * args.steps / a_el, 1)
+        out["value_is"] = "variant B (MSRB hourglass, litehourglass.py); value_registered_litehandnet = variant A (liteHandNet.py)"
         a_ms = a_el / args.steps * 1e3
         out["variant_A"] = {"workload": f"litehandnet variant A ({VARIANT_NAME['A']}), same batch / steps",
                             "ms_per_step": round(a_ms, 3), "images_per_s": round(B * args.steps / a_el, 1),

@@ -390,7 +390,20 @@ class PlanBuilder:
         save = self._ws("misc", (5 * self.N * Cc + self.N * (Cc // 2) + 2 * Cc) * 4)
         mask = self._ws("mask", self.N * Cc * 4) if self.p_drop > 0 else None
         rec = dict(op=CA_MLP, y=y, ca=ca, pooled=pooled, save=save, mask=mask, gsum=self._ws("misc", 2 * Cc * 8))
-
+        # gated RepBasicUnit: the copy of the pass-through half into this buffer rides in the attention's pooling launch
+        # (lhn_avgpool_fwd4: copy_src); the record stays for the backward pass.  LHN_COPY_POOL=0: separate copy.
+        copies = [q for q in self.recs if q["op"] == EW and not q.get("lazy") and "flat" not in q and not q.get("mode") and
+                  q.get("coefs") is None and not isinstance(q["out"], TCat) and q["out"].buf == y.buf]
+        writers = [q for q in self.recs if q["op"] in (STEM, PW, DW, KXK, MAXPOOL, AVGPOOL, SHUFFLE) and
+                   q.get("out") is not None and not isinstance(q["out"], TCat) and q["out"].buf == y.buf]
+        if os.environ.get("LHN_COPY_POOL", "1") != "0" and len(copies) == 1 and not hasattr(ca, "rbr_reparam"):
+            q = copies[0]
+            src = q["srcs"][0] if len(q["srcs"]) == 1 else None
+            if src is not None and not isinstance(src, TCat) and src.buf >= 0 and src.buf != y.buf and q["slope"] == 1.0 and \
+                    q["out"].coff == 0 and 0 < q["out"].C < Cc and (src.H, src.W) == (y.H, y.W) and \
+                    all(w["out"].coff >= q["out"].C for w in writers) and self.bufs[src.buf].lazy is None:
+                q["fwd_fused"] = True
+                rec["copy"] = q
         if self.with_backward:
             rec["gsum_b"] = self._ws("misc", 2 * Cc * 8)
             rec["dgate"] = self._ws("misc", 3 * self.N * Cc * 4)       # dgate | T0, T1 of the gate-gradient pass (bnslices)

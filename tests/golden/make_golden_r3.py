@@ -7,7 +7,9 @@
   scale_rotation.npz    TopDownGetRandomScaleRotation (datasets/data_pipeline/topdown_affine.py:11-45) of the REAL reference
                         under np.random.seed: scale / rotation per sample (the class never calls cv2; its module imports it).
 
-    python tests/golden/make_golden_r3.py [init|scalerot|all]
+    python tests/golden/make_golden_r3.py [init|scalerot|models|all]
+
+  model_L30_128.npz, model_H1_256.npz   Lite-HRNet-30 and the 1-stack hourglass at 256 x 256 (see model_fixtures)
 """
 import hashlib
 import json
@@ -82,9 +84,31 @@ def scalerot_fixture():
     print("written scale_rotation.npz", float(np.mean(np.array(rots) == 0)))
 
 
+def model_fixtures(ref_models, RefLoss):
+    """The two config-5 sizes round 2 left without a reference fixture: Lite-HRNet-30 (config/litehrnet/_1_*_30.py) and the
+    1-stack hourglass at 256 x 256 (config/hourglass/_3_*_h1.py).  Same recipe as make_golden.py::_model_case: the REAL reference
+    and the oracle run forward + loss + backward on seeded inputs, must agree, and the reference's outputs are stored."""
+    from make_golden import _model_case
+    from make_golden_r2_models import _stacked
+    from loss.heatmapLoss import DistanceLoss as RefDistance
+    cfg = litehandnet_cfg("L", depth=30)
+    r, o = ref_models.get_model(cfg), torch_ref.get_model(cfg)
+    assert type(r).__name__ == "LiteHRNet" and sum(p.numel() for p in r.parameters()) == 1773361
+    _model_case(r, o, 4, 128, 43, "L30_128", {"ref_loss": RefLoss(cfg), "ora_loss": torch_ref.TopdownHeatmapLoss(cfg)})
+    cfg = litehandnet_cfg("H", num_stack=1)
+    r, o = ref_models.get_model(cfg), torch_ref.get_model(cfg)
+    assert sum(p.numel() for p in r.parameters()) == 3427733            # debug_litehandnet.ipynb:542
+    lw = cfg.LOSS.loss_weight[0]
+    _model_case(r, o, 2, 256, 34, "H1_256", {"ref_loss": _stacked(RefDistance(loss_type="L2", reduction="mean", balance=True), lw),
+                                              "ora_loss": _stacked(torch_ref.distance_loss, lw)})
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     ref_models, ref_b, RefLoss, pt, gt, ev = _load_reference()
+    if what in ("models", "all"):
+        torch.manual_seed(0)
+        model_fixtures(ref_models, RefLoss)
     if what in ("init", "all"):
         init_fixture(ref_models, ref_b)
     if what in ("scalerot", "all"):

@@ -78,6 +78,10 @@ def test_model_H1_128_golden(dev, golden_dir):
     _model_case(dev, golden_dir, "H1_128", variant="H", num_stack=1)
 
 
+def test_model_H1_256_golden(dev, golden_dir):
+    _model_case(dev, golden_dir, "H1_256", variant="H", num_stack=1)
+
+
 def test_model_H2_128_golden(dev, golden_dir):
     _model_case(dev, golden_dir, "H2_128", variant="H", num_stack=2)
 

@@ -125,6 +125,11 @@ def test_model_L18_256_golden(dev, golden_dir):
     _model_case(dev, golden_dir, "L18_256", variant="L", depth=18)
 
 
+def test_model_L30_128_golden(dev, golden_dir):
+    """Lite-HRNet-30 (config/litehrnet/_1_*_30.py: 3 / 8 / 3 modules per stage) against the reference's fixture."""
+    _model_case(dev, golden_dir, "L30_128", variant="L", depth=30)
+
+
 def test_litehrnet_whole_model_gradients_elementwise(dev):
     """Every parameter gradient of the whole Lite-HRNet-18 element by element against the float64 oracle (the golden cases compare
     gradient norms): cross-branch routing, the twice-evaluated fuse layers, the iterative head (lite_hrnet.py:145-282)."""

@@ -155,7 +155,10 @@ def test_lazy_sums_are_summed_on_load(monkeypatch):
     assert len(lazy) == 4                                           # 2 MSRBs x 2 rounds
     cb, cf, cbw, nf, nb = pb.finalize()
     fwd = [cf[i] for i in range(nf)]
-    assert sum(1 for o in fwd if o.kind == EW) == sum(1 for r in pb.recs if r["op"] == EW and not r.get("lazy"))
+    # (launched combines: every record that is neither summed on load nor -- the pass-through copy of a gated RepBasicUnit --
+    # done by the attention's pooling launch)
+    assert sum(1 for o in fwd if o.kind == EW) == sum(1 for r in pb.recs if r["op"] == EW and not r.get("lazy") and not r.get("fwd_fused"))
+    assert sum(1 for r in pb.recs if r.get("fwd_fused")) == 4 == sum(1 for o in fwd if o.kind == AVGPOOL and o.in_buf[1] >= 0)
     two = [o for o in fwd if o.kind == DW and o.i[6] == 2]
     three = [o for o in fwd if o.kind == PW and o.i[6] == 3]
     assert len(two) == 4 and len(three) == 2
