@@ -513,7 +513,7 @@ extern "C" int lhn_conv_stem_fwd(const float* img, const float* w, const lhn_vie
     int grid = lhn_num_cus() * per_cu;
     if (grid > ntiles) grid = (int)ntiles;
     hipLaunchKernelGGL(k_stem7_fwd_mfma, dim3(grid), dim3(256), lds7, (hipStream_t)stream, img, w, *y, stats, Hi, Wi, stride, pad, fin);
-  } else if (k == 3 && y->C == 32 && !lhn_dw_force_gather())
+  } else if (k == 3 && y->C == 32 && !lhn_dw_force_gather()) {
     static int cap = -1;
     if (cap < 0) {
       const char* e = getenv("LHN_STEM_CAP");
@@ -522,7 +522,7 @@ extern "C" int lhn_conv_stem_fwd(const float* img, const float* w, const lhn_vie
     }
     hipLaunchKernelGGL(k_stem3_fwd_mfma, dim3(grid_for((int64_t)y->N * Ho * Wo, 256, cap)), dim3(256), 0, (hipStream_t)stream, img, w, *y,
                        stats, Hi, Wi, stride, pad, fin);
-  else
+  } else
     hipLaunchKernelGGL(k_stem_fwd, dim3(grid_for((int64_t)y->N * Ho * Wo, PL, 8)), dim3(256), lds, (hipStream_t)stream, img,
                        w, *y, stats, Hi, Wi, k, stride, pad, fin);
   LHN_CHECK_LAUNCH("lhn_conv_stem_fwd");
