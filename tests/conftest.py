@@ -40,6 +40,8 @@ def parity_record(tag, **numbers):
 
 
 def pytest_sessionfinish(session, exitstatus):
+    if _BENCH["proc"] is not None and _BENCH["proc"].poll() is None:
+        _BENCH["proc"].terminate()              # (the exact child this session started)
     if not _PARITY:
         return
     import json
@@ -57,3 +59,45 @@ def pytest_sessionfinish(session, exitstatus):
             old = {}
     old.update(_PARITY)
     json.dump({"meta": meta, "tests": old}, open(path, "w"), indent=1, sort_keys=True)
+
+
+# ---------------------------------------------------------------- CPU oracle of the full-size bench configuration, in the background
+_BENCH = {"proc": None, "dir": None}
+
+
+def _start_bench_oracle():
+    import subprocess
+    import tempfile
+    if _BENCH["proc"] is None:
+        _BENCH["dir"] = tempfile.mkdtemp(prefix="lhn_bench_oracle_")
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        log = open(os.path.join(ROOT, "gpurun_out", "bench_config_oracle.log"), "w")
+        env = {k: v for k, v in os.environ.items() if not k.startswith("LHN_")}
+        _BENCH["proc"] = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "bench_config_oracle.py"), _BENCH["dir"]],
+                                          stdout=log, stderr=subprocess.STDOUT, env=env, cwd=ROOT)
+
+
+def pytest_collection_modifyitems(config, items):
+    """A GPU session that collected the full-size bench-configuration test starts its CPU oracle right away (child process,
+    half of the host cores, no GPU): by the time that test -- sorted last -- runs, the oracle's two minutes per variant are done."""
+    import torch
+    if any("test_zz_bench_config_gpu" in it.nodeid for it in items) and torch.cuda.device_count() > 0:
+        _start_bench_oracle()
+
+
+def bench_oracle(variant, timeout=900):
+    """The npz tests/bench_config_oracle.py wrote for `variant` (waits for the child; fails loudly if it died)."""
+    import time
+
+    import numpy as np
+    _start_bench_oracle()
+    path = os.path.join(_BENCH["dir"], f"bench_oracle_{variant}.npz")
+    t0 = time.time()
+    while not os.path.exists(path):
+        rc = _BENCH["proc"].poll()
+        if rc is not None and not os.path.exists(path):
+            raise RuntimeError(f"tests/bench_config_oracle.py exited with {rc} before writing {variant}: see gpurun_out/bench_config_oracle.log")
+        if time.time() - t0 > timeout:
+            raise RuntimeError("tests/bench_config_oracle.py did not finish in time")
+        time.sleep(1.0)
+    return np.load(path)

@@ -137,7 +137,7 @@ def test_litehrnet_whole_model_gradients_elementwise(dev):
     cfg = litehandnet_cfg("L", depth=18)
     cfg.MODEL["ca_dropout"] = 0.0
     ours, ref = get_model(cfg), torch_ref.get_model(cfg)
-    _check_block(ours, ref, synth.synth_images(4, 128, 63), dev, seed=64, no_dx=True, grad_tol=2e-2)
+    _check_block(ours, ref, synth.synth_images(2, 128, 63), dev, seed=64, no_dx=True, grad_tol=2e-2)
 
 
 def test_litehrnet_eval(dev):

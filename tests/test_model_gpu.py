@@ -219,9 +219,9 @@ def _model_case(dev, golden_dir, tag, variant="B", **kw):
     # 0.5e-4 .. 1.1e-4 of the largest gradient norm depending on the arrival order of the atomics, torch's fp32 run 0.15e-4.
     # Such parameters are held to an ABSOLUTE bar, 3e-4 of the largest gradient norm, instead of a multiple of torch's luck.
     gmax = max(gn64.values())
-    zero = [k for k, p in m.named_parameters() if p.dim() == 4 and tuple(p.shape[1:]) == (1, 1, 1) and k.endswith("rbr_1x1.conv.weight")]
+    zero = [k for k, p in m.named_parameters() if p.dim() == 4 and tuple(p.shape[1:]) == (1, 1, 1) and k.endswith("rbr_1x1.conv.weight")
+            and gn64[k] <= 2e-2 * gmax]                                         # nearly cancelled (not with every weight set)
     for k in zero:
-        assert gn64[k] <= 2e-2 * gmax, (k, gn64[k] / gmax)                      # (the premise: nearly cancelled)
         assert errs[k] * (gn64[k] + floor) <= 3e-4 * gmax, (k, errs[k] * (gn64[k] + floor) / gmax)
     worst, worst32 = max(v for k, v in errs.items() if k not in zero), max(v for k, v in errs32.items() if k not in zero)
     top = sorted((k for k in errs if k not in zero), key=lambda k: -errs[k])[:3]
