@@ -95,6 +95,19 @@ typedef struct lhn_bnbwdfin {
   int32_t      cstride, coff, C;
 } lhn_bnbwdfin;
 
+/* BatchNorm-backward sums contributed by a READER.  du = dz * act'(u) is linear in dz, and dz of a convolution output is the sum
+ * of what its readers' backward kernels hand back -- so every reader that has its own part of dz in registers can add that
+ * part's  sum du  and  sum du * xhat  into the PRODUCER's replicated sums (the reader holds the raw value and the table of its
+ * input anyway, or re-reads a tile that is still in L2).  When all readers of a convolution + BatchNorm output do, its
+ * lhn_bn_bwd_reduce pass (one read of y and one of dz) is not needed.  Valid for ungated inputs without pooled gradient.
+ *   sums: [LHN_STAT_REPLICAS][2][C] of the producer's BatchNorm (zeroed by the caller), save: its [2][C] mean | invstd,
+ *   coff: the channel of that BatchNorm which the reader's input view starts at.  NULL pointer to the struct: no sums. */
+typedef struct lhn_bnsum {
+  double*      sums;
+  const float* save;
+  int32_t      C, coff;
+} lhn_bnsum;
+
 int         lhn_version(void);
 /* 1 when the library runs in its deterministic mode (environment LHN_DETERMINISTIC=1, read once): every cross-workgroup sum
  * has one writer per replica and replicas are folded in a fixed order, so two runs on the same inputs agree bit for bit
@@ -393,6 +406,16 @@ int lhn_ew_bwd2(const lhn_view* src, const lhn_view* dst, const float* ddst, con
                 float* dsrc, int accumulate, void* stream);
 int lhn_maxpool2_bwd(const lhn_view* x, const lhn_view* y, const float* dy, float* dx, int dx_accumulate,
                      void* stream);
+/* the same readers' backward kernels, also adding their part of the producer's BatchNorm-backward sums (lhn_bnsum; NULL = plain) */
+int lhn_maxpool2_bwd2(const lhn_view* x, const lhn_view* y, const float* dy, float* dx, int dx_accumulate, const lhn_bnsum* bns,
+                      void* stream);
+int lhn_ew_bwd3(const lhn_view* src, const lhn_view* dst, const float* ddst, const float* dst_dpool, float out_slope, float* dsrc,
+                int accumulate, const lhn_bnsum* bns, void* stream);
+int lhn_avgpool_bwd3(const lhn_view* x, const float* dout, int OH, int OW, int out_cstride, int out_coff, float* dx,
+                     int dx_accumulate, const lhn_bnsum* bns, void* stream);
+int lhn_conv_pw_bwd3(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx, int dx_accumulate,
+                     float* dw, float* dbias, int stride, const float* dy_nchw, int nrep, int64_t rep_stride,
+                     const lhn_pw_opts* opts, const lhn_bnsum* bns /*fused kernel only: Cin * Cout < 64 * 128, stride 1*/, void* stream);
 int lhn_avgpool_bwd(const lhn_view* x, const float* dout /*[N,OH,OW,C]*/, int OH, int OW, float* dx,
                     int dx_accumulate, void* stream);
 int lhn_gate_bwd_reduce(const lhn_view* y, const float* dz, float* dgate /*[N][C] dense*/, void* stream);

@@ -514,13 +514,8 @@ extern "C" int lhn_conv_stem_fwd(const float* img, const float* w, const lhn_vie
     if (grid > ntiles) grid = (int)ntiles;
     hipLaunchKernelGGL(k_stem7_fwd_mfma, dim3(grid), dim3(256), lds7, (hipStream_t)stream, img, w, *y, stats, Hi, Wi, stride, pad, fin);
   } else if (k == 3 && y->C == 32 && !lhn_dw_force_gather()) {
-    static int cap = -1;
-    if (cap < 0) {
-      const char* e = getenv("LHN_STEM_CAP");
-      cap = e ? atoi(e) : 3;
-      if (cap < 1) cap = 3;
-    }
-    hipLaunchKernelGGL(k_stem3_fwd_mfma, dim3(grid_for((int64_t)y->N * Ho * Wo, 256, cap)), dim3(256), 0, (hipStream_t)stream, img, w, *y,
+    // (3 / 6 / 12 blocks per CU measured in round 3: no difference, forward 2.680 / 2.677 / 2.682 ms)
+    hipLaunchKernelGGL(k_stem3_fwd_mfma, dim3(grid_for((int64_t)y->N * Ho * Wo, 256, 3)), dim3(256), 0, (hipStream_t)stream, img, w, *y,
                        stats, Hi, Wi, stride, pad, fin);
   } else
     hipLaunchKernelGGL(k_stem_fwd, dim3(grid_for((int64_t)y->N * Ho * Wo, PL, 8)), dim3(256), lds, (hipStream_t)stream, img,
@@ -1514,7 +1509,7 @@ static void launch_dwk_fwd(const lhn_view* x, const float* w, const lhn_view* y,
   const int per_cu = lds > 80 * 1024 ? 1 : (lds > 52 * 1024 ? 2 : 3);
   static LhnKernelCfg cfg;
   (void)lhn_kernel_cfg(cfg, &k_dwk_fwd_lds<K, DIL, NS>, lds, 4, nullptr);
-  const int grid = dw3_grid(ntile, cg, per_cu * 2);
+  const int grid = dw3_grid(ntile, cg, per_cu * 2);      // (2 / 3 / 4 / 8 / 16 blocks per CU measured in round 3: forward 2.65 / 2.68 / 2.66 / 2.71 / 2.71 ms)
   hipLaunchKernelGGL((k_dwk_fwd_lds<K, DIL, NS>), dim3(grid), dim3(256), lds, s, *x, w, *y, stats, th, tw, cg, fin, ps, ex, dw3_xchunk(grid, cg));
 }
 template <int K, int DIL, bool BNS = false>

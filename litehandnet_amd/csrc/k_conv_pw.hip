@@ -435,7 +435,7 @@ static int launch_pw_fwd_wr(const lhn_view* x, const float* w, const float* bias
     lhn_set_error("lhn_conv_pw_fwd: cannot reserve %zu B of LDS", lds);
     return 2;
   }
-  int grid = lhn_num_cus() * per_cu;
+  int grid = lhn_num_cus() * per_cu;      // (2 / 4 / 8 / 16 blocks per CU measured in round 3: forward 2.71 / 2.69 / 2.74 / 2.83 ms)
   if (grid > ntiles) grid = ntiles;
   hipLaunchKernelGGL((k_pw_fwd_wr<CIN, NCOT, NS>), dim3(grid), dim3(256), lds, s, *x, w, bias, *y, stats, cout, M, ntiles, ex, geo.wstride,
                      geo.yacc, geo.statC, wt);
@@ -631,11 +631,11 @@ extern "C" int lhn_conv_pw_fwd(const lhn_view* x, const float* w, const float* b
 //                                                                           fp32 atomic add per block at the end
 // NCHW = the head's gradient arrives as a plain NCHW tensor (dy_nchw); a template flag so that the NHWC instances do not
 // carry its prefetch registers (they cost k_pw_bwd<64,2> 44 -> 56 us when the switch was a runtime one)
-template <int CIN, int NTO, bool NCHW>
+template <int CIN, int NTO, bool NCHW, bool BNS = false>
 __global__ void __launch_bounds__(256, (CIN == 32 && NTO == 1 && !NCHW) ? 4 : (CIN <= 64 && NTO <= 2 && !NCHW) ? 3 : 1) k_pw_bwd(lhn_view x, const float* __restrict__ w, lhn_view y, lhn_gradview gy,
                                                 float* __restrict__ dx, int dx_acc, float* __restrict__ dw,
                                                 float* __restrict__ dbias, int stride, const float* __restrict__ dy_nchw,
-                                                int cout, int M, int ntiles, int nrep, int64_t rep_stride, PwGeom geo) {
+                                                int cout, int M, int ntiles, int nrep, int64_t rep_stride, PwGeom geo, lhn_bnsum bs) {
   constexpr int NTI = CIN / 32;
   constexpr int COP = 32 * NTO;
   constexpr int LDW = CIN + 4, LDY = COP + 4, LDX = CIN + 4;
@@ -749,6 +749,23 @@ __global__ void __launch_bounds__(256, (CIN == 32 && NTO == 1 && !NCHW) ? 4 : (C
     }
   };
 
+  // bs.sums (lhn_bnsum): this launch's dX is (part of) the gradient of the value of x, the output of a convolution + BatchNorm
+  // -- the lane that holds dX[m][ci] re-reads the raw x[m][ci] (the tile was just staged: L2) and adds du = dX * act'(u) and
+  // du * xhat to its channel's sums; stride 1, host-checked.  Channel of lane and dX tile t: ci = 32 * ((wave >> 1) + 2 t) + l31.
+  // (BNS is a template flag: as a runtime one its 14 registers spilled k_pw_bwd<64,2>)
+  constexpr int NB = BNS ? NDX : 1;
+  float b_sc[NB], b_sh[NB], b_sl[NB], b_mean[NB], b_inv[NB], b_s[NB], b_q[NB];
+#pragma unroll
+  for (int t = 0; t < NB; ++t) {
+    b_s[t] = b_q[t] = 0.f;
+    const int ci = 32 * ((wave >> 1) + 2 * t) + l31;
+    const bool ok = BNS && bs.sums && ci < x.C;
+    b_sc[t] = ok && x.table ? x.table[x.coff + ci] : 1.f;
+    b_sh[t] = ok && x.table ? x.table[x.cstride + x.coff + ci] : 0.f;
+    b_sl[t] = ok && x.table ? x.table[2 * x.cstride + x.coff + ci] : 1.f;
+    b_mean[t] = ok ? bs.save[bs.coff + ci] : 0.f;
+    b_inv[t] = ok ? bs.save[bs.C + bs.coff + ci] : 0.f;
+  }
   int tile = blockIdx.x;
   if (tile < ntiles) issue(tile);
   for (; tile < ntiles; tile += gridDim.x) {
@@ -807,6 +824,12 @@ __global__ void __launch_bounds__(256, (CIN == 32 && NTO == 1 && !NCHW) ? 4 : (C
             const int m = tile * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             if (m < M && 32 * jt + l31 < x.C) {
               float* o = dx + in_pix(m) * x.cstride + x.coff + 32 * jt + l31;
+              if (BNS) {
+                const float raw = x.data[(int64_t)m * x.cstride + x.coff + 32 * jt + l31];
+                const float du = accx[t][r] * (raw * b_sc[t] + b_sh[t] > 0.f ? 1.f : b_sl[t]);
+                b_s[t] += du;
+                b_q[t] += du * ((raw - b_mean[t]) * b_inv[t]);
+              }
               *o = dx_acc ? *o + accx[t][r] : accx[t][r];
             }
           }
@@ -816,6 +839,26 @@ __global__ void __launch_bounds__(256, (CIN == 32 && NTO == 1 && !NCHW) ? 4 : (C
     __syncthreads();
   }
 
+  if (BNS) {      // the two lane halves and the two waves (pixel halves) of a channel tile meet in LDS (Xs is free now)
+    float* bred = Xs;                                   // [NTI][2 waves][2][32]
+#pragma unroll
+    for (int t = 0; t < NB; ++t) {
+      const int jt = (wave >> 1) + 2 * t;
+      const float ss = b_s[t] + __shfl_xor(b_s[t], 32, 64), qq = b_q[t] + __shfl_xor(b_q[t], 32, 64);
+      if (jt < NTI && lh == 0) {
+        bred[((jt * 2 + (wave & 1)) * 2 + 0) * 32 + l31] = ss;
+        bred[((jt * 2 + (wave & 1)) * 2 + 1) * 32 + l31] = qq;
+      }
+    }
+    __syncthreads();
+    if (tid < NTI * 32 && tid < x.C) {
+      const int jt = tid >> 5, c = tid & 31;
+      double* st = bs.sums + (size_t)(blockIdx.x % LHN_STAT_REPLICAS) * 2 * bs.C + bs.coff + tid;
+      atomicAdd(st, (double)bred[((jt * 2 + 0) * 2 + 0) * 32 + c] + (double)bred[((jt * 2 + 1) * 2 + 0) * 32 + c]);
+      atomicAdd(st + bs.C, (double)bred[((jt * 2 + 0) * 2 + 1) * 32 + c] + (double)bred[((jt * 2 + 1) * 2 + 1) * 32 + c]);
+    }
+    __syncthreads();
+  }
   // ---- flush dW (C/D layout: row = co within tile, col = lane&31 = ci within tile)
   dw += (size_t)(blockIdx.x % nrep) * rep_stride;
 #pragma unroll
@@ -871,25 +914,25 @@ __global__ void __launch_bounds__(256) k_bias_grad_nchw(const float* __restrict_
   if (threadIdx.x == 0) atomicAdd(db + co, (float)(red[0] + red[1] + red[2] + red[3]));
 }
 
-template <int CIN, int NTO, bool NCHW>
+template <int CIN, int NTO, bool NCHW, bool BNS = false>
 static int launch_pw_bwd_t(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx, int dx_acc,
                          float* dw, float* dbias, int stride, const float* dy_nchw, int cout, int nrep, int64_t rep_stride,
-                         const PwGeom& geo, hipStream_t s) {
+                         const PwGeom& geo, hipStream_t s, const lhn_bnsum& bs) {
   const int M = y->N * y->H * y->W;
   const int ntiles = (M + 63) / 64;
   constexpr int COP = 32 * NTO;
   const size_t lds = (size_t)(COP * (CIN + 4) + 64 * (COP + 4) + 64 * (CIN + 4)) * sizeof(float);
   static LhnKernelCfg cfg;
   int per_cu = 1;
-  if (!lhn_kernel_cfg(cfg, &k_pw_bwd<CIN, NTO, NCHW>, lds, 4, &per_cu)) {
+  if (!lhn_kernel_cfg(cfg, &k_pw_bwd<CIN, NTO, NCHW, BNS>, lds, 4, &per_cu)) {
     lhn_set_error("lhn_conv_pw_bwd: cannot reserve %zu B of LDS", lds);
     return 2;
   }
   int grid = lhn_num_cus() * per_cu;
   if (grid > ntiles) grid = ntiles;
   lhn_gradview g = *gy;
-  hipLaunchKernelGGL((k_pw_bwd<CIN, NTO, NCHW>), dim3(grid), dim3(256), lds, s, *x, w, *y, g, dx, dx_acc, dw, dbias, stride, dy_nchw,
-                     cout, M, ntiles, nrep, rep_stride, geo);
+  hipLaunchKernelGGL((k_pw_bwd<CIN, NTO, NCHW, BNS>), dim3(grid), dim3(256), lds, s, *x, w, *y, g, dx, dx_acc, dw, dbias, stride, dy_nchw,
+                     cout, M, ntiles, nrep, rep_stride, geo, bs);
   if (dbias && dy_nchw)
     hipLaunchKernelGGL(k_bias_grad_nchw, dim3(geo.wrows, lhn_deterministic_mode() ? 1 : (y->N < 16 ? y->N : 16)), dim3(256), 0, s, dy_nchw, dbias, y->N, cout,
                        y->H * y->W, geo.nchw_bstride);
@@ -899,9 +942,14 @@ static int launch_pw_bwd_t(const lhn_view* x, const float* w, const lhn_view* y,
 template <int CIN, int NTO>
 static int launch_pw_bwd(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx, int dx_acc,
                          float* dw, float* dbias, int stride, const float* dy_nchw, int cout, int nrep, int64_t rep_stride,
-                         const PwGeom& geo, hipStream_t s) {
-  if (dy_nchw) return launch_pw_bwd_t<CIN, NTO, true>(x, w, y, gy, dx, dx_acc, dw, dbias, stride, dy_nchw, cout, nrep, rep_stride, geo, s);
-  return launch_pw_bwd_t<CIN, NTO, false>(x, w, y, gy, dx, dx_acc, dw, dbias, stride, dy_nchw, cout, nrep, rep_stride, geo, s);
+                         const PwGeom& geo, hipStream_t s, const lhn_bnsum& bs) {
+  if (dy_nchw) return launch_pw_bwd_t<CIN, NTO, true>(x, w, y, gy, dx, dx_acc, dw, dbias, stride, dy_nchw, cout, nrep, rep_stride, geo, s, bs);
+  if constexpr (CIN * NTO * 32 < 64 * 128) {           // reader-side BatchNorm sums: the shapes the fused kernel keeps for itself
+    if (bs.sums && dx && stride == 1)
+      return launch_pw_bwd_t<CIN, NTO, false, true>(x, w, y, gy, dx, dx_acc, dw, dbias, stride, dy_nchw, cout, nrep, rep_stride, geo, s, bs);
+  }
+  if (bs.sums) return -1;
+  return launch_pw_bwd_t<CIN, NTO, false>(x, w, y, gy, dx, dx_acc, dw, dbias, stride, dy_nchw, cout, nrep, rep_stride, geo, s, bs);
 }
 
 int lhn_pw_bwd_split(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx, int dx_accumulate,
@@ -910,7 +958,20 @@ int lhn_pw_bwd_split(const lhn_view* x, const float* w, const lhn_view* y, const
 extern "C" int lhn_conv_pw_bwd2(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx,
                                 int dx_accumulate, float* dw, float* dbias, int stride, const float* dy_nchw, int nrep,
                                 int64_t rep_stride, const lhn_pw_opts* opts, void* stream) {
+  return lhn_conv_pw_bwd3(x, w, y, gy, dx, dx_accumulate, dw, dbias, stride, dy_nchw, nrep, rep_stride, opts, nullptr, stream);
+}
+extern "C" int lhn_conv_pw_bwd3(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx,
+                                int dx_accumulate, float* dw, float* dbias, int stride, const float* dy_nchw, int nrep,
+                                int64_t rep_stride, const lhn_pw_opts* opts, const lhn_bnsum* bns, void* stream) {
   if (nrep < 1) nrep = 1;
+  lhn_bnsum bs;
+  memset(&bs, 0, sizeof(bs));
+  if (bns && bns->sums) {
+    LHN_CHECK_ARG(x && y && bns->save && dx && stride == 1 && x->C <= 128 && y->C <= 128 && x->C * y->C < 64 * 128 && !x->gate && x->table &&
+                      bns->coff >= 0 && bns->coff + x->C <= bns->C,
+                  "lhn_conv_pw_bwd3: BatchNorm sums ride in the fused kernel only (stride 1, Cin * Cout < 8192, ungated input inside the producer's channels)");
+    bs = *bns;
+  }
   LHN_CHECK_ARG(lhn_view_ok(x) && w && y && gy && dw && lhn_no_pend(x) && lhn_no_pend(y), "lhn_conv_pw_bwd: bad view / null pointer");
   LHN_CHECK_ARG(stride == 1 || stride == 2, "lhn_conv_pw_bwd: stride %d", stride);
   LHN_CHECK_ARG(stride == 1 || !dx || dx_accumulate, "lhn_conv_pw_bwd: stride-2 dgrad only accumulates into a zeroed gradient");
@@ -921,7 +982,7 @@ extern "C" int lhn_conv_pw_bwd2(const lhn_view* x, const float* w, const lhn_vie
                 wrows, wcols, Cin, Cout);
   const int64_t bstride = (opts && opts->nchw_batch_stride > 0) ? opts->nchw_batch_stride : (int64_t)Cout * HoWo;
   hipStream_t s = (hipStream_t)stream;
-  if (stride == 1 && !dy_nchw && Cin * Cout >= 64 * 128 && Cout % 32 == 0 && Cin % 32 == 0 && Cout <= 256 && wcols == Cin && wrows == Cout) {
+  if (!bs.sums && stride == 1 && !dy_nchw && Cin * Cout >= 64 * 128 && Cout % 32 == 0 && Cin % 32 == 0 && Cout <= 256 && wcols == Cin && wrows == Cout) {
     const int rc = lhn_pw_bwd_split(x, w, y, gy, dx, dx_accumulate, dw, dbias, nrep, rep_stride, s);
     if (rc == 0) {
       LHN_CHECK_LAUNCH("lhn_conv_pw_bwd");
@@ -954,7 +1015,7 @@ extern "C" int lhn_conv_pw_bwd2(const lhn_view* x, const float* w, const lhn_vie
       const int acc = dx_accumulate || co0 > 0;
       int rc = -1;
 #define PWB_CASE(CI, NTV) \
-  if (ci == CI && nto == NTV) rc = launch_pw_bwd<CI, NTV>(&xv, wv, &yv, gy, dx, acc, dwv, dbv, stride, dyv, cc, nrep, rep_stride, g, s);
+  if (ci == CI && nto == NTV) rc = launch_pw_bwd<CI, NTV>(&xv, wv, &yv, gy, dx, acc, dwv, dbv, stride, dyv, cc, nrep, rep_stride, g, s, bs);
       PWB_CASE(32, 1) PWB_CASE(32, 2) PWB_CASE(32, 4) PWB_CASE(64, 1) PWB_CASE(64, 2) PWB_CASE(64, 4) PWB_CASE(128, 1)
       PWB_CASE(128, 2) PWB_CASE(128, 4)
 #undef PWB_CASE

@@ -252,8 +252,17 @@ __global__ void __launch_bounds__(256, BIL ? 1 : 3) k_ew_fwd(EwSrcs S, int nsrc,
 // One launch per source (gather form: each source element sums the dst elements that read it).
 __global__ void __launch_bounds__(256) k_ew_bwd_src(lhn_view src, lhn_view dst, const float* __restrict__ ddst,
                                                     const float* __restrict__ dst_dpool, float out_slope,
-                                                    float* __restrict__ dsrc, int accumulate) {
+                                                    float* __restrict__ dsrc, int accumulate, lhn_bnsum bs) {
+  __shared__ f4 bred[512];
   const int C4 = src.C >> 2, c4 = threadIdx.x % C4, pl = threadIdx.x / C4, PL = 256 / C4;
+  // bs.sums: this launch's part of the BatchNorm-backward sums of the convolution that produced src (see lhn_bnsum)
+  f4 bsum = (f4){0.f, 0.f, 0.f, 0.f}, bsq = bsum, bmean = bsum, binv = bsum;
+  Xf4 bxf;
+  if (bs.sums) {
+    bxf = lhn_load_xf(src, src.coff + 4 * c4);
+    bmean = *reinterpret_cast<const f4*>(bs.save + bs.coff + 4 * c4);
+    binv = *reinterpret_cast<const f4*>(bs.save + bs.C + bs.coff + 4 * c4);
+  }
   const int fh = dst.H / src.H, fw = dst.W / src.W;  // integer fan-out (host checks divisibility)
   const int cd = dst.coff + 4 * c4;
   const int rows = src.N * src.H;
@@ -296,10 +305,17 @@ __global__ void __launch_bounds__(256) k_ew_bwd_src(lhn_view src, lhn_view dst, 
           g += e;
         }
       float* o = dsrc + ((size_t)row * src.W + w) * src.cstride + src.coff + 4 * c4;
+      if (bs.sums) {
+        const f4 raw = *reinterpret_cast<const f4*>(src.data + ((size_t)row * src.W + w) * src.cstride + src.coff + 4 * c4);
+        const f4 du = g * lhn_dact_xf(raw, bxf);
+        bsum += du;
+        bsq += du * ((raw - bmean) * binv);
+      }
       if (accumulate) g += *reinterpret_cast<const f4*>(o);
       *reinterpret_cast<f4*>(o) = g;
     }
   }
+  if (bs.sums) lhn_bns_flush(bs, bsum, bsq, C4, bred);
 }
 
 // ------------------------------------------------------------------ 2x2 stride-2 max pool (ceil_mode)
@@ -333,10 +349,16 @@ __global__ void __launch_bounds__(256) k_maxpool2_fwd(lhn_view x, lhn_view y, lh
 // re-evaluates its 2x2 window (every input pixel belongs to exactly one window), so the comparison never
 // depends on two kernels rounding the pending transform identically.
 __global__ void __launch_bounds__(256) k_maxpool2_bwd(lhn_view x, lhn_view y, const float* __restrict__ dy,
-                                                      float* __restrict__ dx, int accumulate) {
+                                                      float* __restrict__ dx, int accumulate, lhn_bnsum bs) {
+  __shared__ f4 bred[512];
   const int C4 = y.C >> 2, c4 = threadIdx.x % C4, pl = threadIdx.x / C4, PL = 256 / C4;
   const int ca = x.coff + 4 * c4;
   const Xf4 xf = lhn_load_xf(x, ca);
+  f4 bsum = (f4){0.f, 0.f, 0.f, 0.f}, bsq = bsum, bmean = bsum, binv = bsum;      // lhn_bnsum: the producer of x
+  if (bs.sums) {
+    bmean = *reinterpret_cast<const f4*>(bs.save + bs.coff + 4 * c4);
+    binv = *reinterpret_cast<const f4*>(bs.save + bs.C + bs.coff + 4 * c4);
+  }
   const int rows = y.N * y.H;
   for (int row = blockIdx.x; row < rows; row += gridDim.x) {
     const int n = row / y.H, ho = row - n * y.H;
@@ -345,11 +367,13 @@ __global__ void __launch_bounds__(256) k_maxpool2_bwd(lhn_view x, lhn_view y, co
       const f4 g = *reinterpret_cast<const f4*>(dy + ((size_t)row * y.W + wo) * y.cstride + y.coff + 4 * c4);
       f4 m = (f4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
       int arg[4] = {-1, -1, -1, -1};
+      f4 raws[4];
 #pragma unroll
       for (int o = 0; o < 4; ++o) {
         const int ih = 2 * ho + (o >> 1), iw = 2 * wo + (o & 1);
         if (ih < x.H && iw < x.W) {
-          const f4 v = lhn_apply_xf(*reinterpret_cast<const f4*>(x.data + ((size_t)(n * x.H + ih) * x.W + iw) * x.cstride + ca), xf) * gate;
+          raws[o] = *reinterpret_cast<const f4*>(x.data + ((size_t)(n * x.H + ih) * x.W + iw) * x.cstride + ca);
+          const f4 v = lhn_apply_xf(raws[o], xf) * gate;
           if (v.x > m.x || v.x != v.x || arg[0] < 0) { if (!(m.x != m.x)) { m.x = v.x; arg[0] = o; } }
           if (v.y > m.y || v.y != v.y || arg[1] < 0) { if (!(m.y != m.y)) { m.y = v.y; arg[1] = o; } }
           if (v.z > m.z || v.z != v.z || arg[2] < 0) { if (!(m.z != m.z)) { m.z = v.z; arg[2] = o; } }
@@ -362,12 +386,18 @@ __global__ void __launch_bounds__(256) k_maxpool2_bwd(lhn_view x, lhn_view y, co
         if (ih < x.H && iw < x.W) {
           f4 r = (f4){arg[0] == o ? g.x : 0.f, arg[1] == o ? g.y : 0.f, arg[2] == o ? g.z : 0.f, arg[3] == o ? g.w : 0.f};
           float* q = dx + ((size_t)(n * x.H + ih) * x.W + iw) * x.cstride + ca;
+          if (bs.sums) {
+            const f4 du = r * lhn_dact_xf(raws[o], xf);
+            bsum += du;
+            bsq += du * ((raws[o] - bmean) * binv);
+          }
           if (accumulate) r += *reinterpret_cast<const f4*>(q);
           *reinterpret_cast<f4*>(q) = r;
         }
       }
     }
   }
+  if (bs.sums) lhn_bns_flush(bs, bsum, bsq, C4, bred);
 }
 
 // BatchNorms behind channel slices of one buffer (a gated buffer is written by up to two convolutions, each with its own
@@ -538,8 +568,16 @@ __global__ void __launch_bounds__(256) k_avgpool_small(lhn_view x, float* __rest
 }
 // d(value of x) (+)= sum over bins containing the pixel of dout[bin]/|bin|
 __global__ void __launch_bounds__(256) k_avgpool_bwd(lhn_view x, const float* __restrict__ dout, int OH, int OW,
-                                                     float* __restrict__ dx, int accumulate, int ostride, int ocoff) {
+                                                     float* __restrict__ dx, int accumulate, int ostride, int ocoff, lhn_bnsum bs) {
+  __shared__ f4 bred[512];
   const int C4 = x.C >> 2, c4 = threadIdx.x % C4, pl = threadIdx.x / C4, PL = 256 / C4;
+  f4 bsum = (f4){0.f, 0.f, 0.f, 0.f}, bsq = bsum, bmean = bsum, binv = bsum;      // lhn_bnsum: the producer of x
+  Xf4 bxf;
+  if (bs.sums) {
+    bxf = lhn_load_xf(x, x.coff + 4 * c4);
+    bmean = *reinterpret_cast<const f4*>(bs.save + bs.coff + 4 * c4);
+    binv = *reinterpret_cast<const f4*>(bs.save + bs.C + bs.coff + 4 * c4);
+  }
   const int rows = x.N * x.H;
   for (int row = blockIdx.x; row < rows; row += gridDim.x) {
     const int n = row / x.H, h = row - n * x.H;
@@ -558,10 +596,17 @@ __global__ void __launch_bounds__(256) k_avgpool_bwd(lhn_view x, const float* __
         }
       }
       float* o = dx + ((size_t)row * x.W + w) * x.cstride + x.coff + 4 * c4;
+      if (bs.sums) {
+        const f4 raw = *reinterpret_cast<const f4*>(x.data + ((size_t)row * x.W + w) * x.cstride + x.coff + 4 * c4);
+        const f4 du = g * lhn_dact_xf(raw, bxf);
+        bsum += du;
+        bsq += du * ((raw - bmean) * binv);
+      }
       if (accumulate) g += *reinterpret_cast<const f4*>(o);
       *reinterpret_cast<f4*>(o) = g;
     }
   }
+  if (bs.sums) lhn_bns_flush(bs, bsum, bsq, C4, bred);
 }
 
 // ------------------------------------------------------------------ channel attention MLP (common.py:40-66)
@@ -1123,21 +1168,40 @@ int lhn_ew_bwd(const lhn_view* srcs, int nsrc, const lhn_view* dst, const float*
     LHN_CHECK_ARG(lhn_view_ok(s) && s->C == dst->C, "lhn_ew_bwd: source %d mismatch", i);
     LHN_CHECK_ARG(dst->H % s->H == 0 && dst->W % s->W == 0, "lhn_ew_bwd: non-integer upsample %dx%d -> %dx%d", s->H, s->W, dst->H, dst->W);
     LHN_CHECK_ARG(s->C % 4 == 0 && s->C <= 1024, "lhn_ew_bwd: C=%d", s->C);
+    lhn_bnsum nob;
+    memset(&nob, 0, sizeof(nob));
     hipLaunchKernelGGL(k_ew_bwd_src, dim3(grid_cap((int64_t)s->N * s->H, 8)), dim3(256), 0, (hipStream_t)stream, *s, *dst, ddst,
-                       (const float*)nullptr, out_slope, dsrcs[i], accumulate[i]);
+                       (const float*)nullptr, out_slope, dsrcs[i], accumulate[i], nob);
   }
   LHN_CHECK_LAUNCH("lhn_ew_bwd");
   return 0;
 }
 // variant used by the plan: dst may carry a channel-attention gate and its pooled-gradient (dpool)
+// a reader-side BatchNorm-sum request is valid for an ungated input view whose channels lie inside the producer's BatchNorm
+static int bns_of(const lhn_bnsum* in, const lhn_view* v, lhn_bnsum* out, const char* who) {
+  memset(out, 0, sizeof(*out));
+  if (!in || !in->sums) return 0;
+  LHN_CHECK_ARG(in->save && in->C > 0 && in->coff >= 0 && in->coff % 4 == 0 && in->coff + v->C <= in->C && !v->gate && v->table,
+                "%s: BatchNorm sums need an ungated input view with a table, inside the producer's %d channels (offset %d, view %d)", who,
+                in->C, in->coff, v->C);
+  *out = *in;
+  return 0;
+}
 int lhn_ew_bwd2(const lhn_view* src, const lhn_view* dst, const float* ddst, const float* dst_dpool, float out_slope,
                 float* dsrc, int accumulate, void* stream) {
+  return lhn_ew_bwd3(src, dst, ddst, dst_dpool, out_slope, dsrc, accumulate, nullptr, stream);
+}
+// variant used by the plan: dst may carry a channel-attention gate and its pooled-gradient (dpool)
+int lhn_ew_bwd3(const lhn_view* src, const lhn_view* dst, const float* ddst, const float* dst_dpool, float out_slope,
+                float* dsrc, int accumulate, const lhn_bnsum* bns, void* stream) {
   LHN_CHECK_ARG(lhn_view_ok(src) && lhn_view_ok(dst) && ddst && dsrc && src->C == dst->C && lhn_no_pend(src) && lhn_no_pend(dst), "lhn_ew_bwd2: bad args");
   LHN_CHECK_ARG(dst->H % src->H == 0 && dst->W % src->W == 0, "lhn_ew_bwd2: non-integer upsample");
   LHN_CHECK_ARG((out_slope != LHN_SLOPE_SILU && out_slope != LHN_SLOPE_RELU_SIGMOID) || (dst->H == src->H && dst->W == src->W), "lhn_ew_bwd2: SiLU / ReLU-sigmoid need a single same-size source");
   LHN_CHECK_ARG(src->C % 4 == 0 && src->C <= 1024, "lhn_ew_bwd2: C=%d", src->C);
+  lhn_bnsum bs;
+  if (bns_of(bns, src, &bs, "lhn_ew_bwd3")) return 1;
   hipLaunchKernelGGL(k_ew_bwd_src, dim3(grid_cap((int64_t)src->N * src->H, 8)), dim3(256), 0, (hipStream_t)stream, *src, *dst, ddst,
-                     dst_dpool, out_slope, dsrc, accumulate);
+                     dst_dpool, out_slope, dsrc, accumulate, bs);
   LHN_CHECK_LAUNCH("lhn_ew_bwd2");
   return 0;
 }
@@ -1152,9 +1216,15 @@ int lhn_maxpool2_fwd(const lhn_view* x, const lhn_view* y, void* stream) {
   return 0;
 }
 int lhn_maxpool2_bwd(const lhn_view* x, const lhn_view* y, const float* dy, float* dx, int dx_accumulate, void* stream) {
+  return lhn_maxpool2_bwd2(x, y, dy, dx, dx_accumulate, nullptr, stream);
+}
+int lhn_maxpool2_bwd2(const lhn_view* x, const lhn_view* y, const float* dy, float* dx, int dx_accumulate, const lhn_bnsum* bns,
+                      void* stream) {
   LHN_CHECK_ARG(lhn_view_ok(x) && lhn_view_ok(y) && dy && dx && x->C == y->C && lhn_no_pend(x), "lhn_maxpool2_bwd: bad args");
   LHN_CHECK_ARG(y->C % 4 == 0 && y->C <= 1024, "lhn_maxpool2_bwd: C=%d", y->C);
-  hipLaunchKernelGGL(k_maxpool2_bwd, dim3(grid_cap((int64_t)y->N * y->H, 8)), dim3(256), 0, (hipStream_t)stream, *x, *y, dy, dx, dx_accumulate);
+  lhn_bnsum bs;
+  if (bns_of(bns, x, &bs, "lhn_maxpool2_bwd2")) return 1;
+  hipLaunchKernelGGL(k_maxpool2_bwd, dim3(grid_cap((int64_t)y->N * y->H, 8)), dim3(256), 0, (hipStream_t)stream, *x, *y, dy, dx, dx_accumulate, bs);
   LHN_CHECK_LAUNCH("lhn_maxpool2_bwd");
   return 0;
 }
@@ -1228,9 +1298,15 @@ int lhn_avgpool_bwd(const lhn_view* x, const float* dout, int OH, int OW, float*
 }
 int lhn_avgpool_bwd2(const lhn_view* x, const float* dout, int OH, int OW, int out_cstride, int out_coff, float* dx,
                      int dx_accumulate, void* stream) {
+  return lhn_avgpool_bwd3(x, dout, OH, OW, out_cstride, out_coff, dx, dx_accumulate, nullptr, stream);
+}
+int lhn_avgpool_bwd3(const lhn_view* x, const float* dout, int OH, int OW, int out_cstride, int out_coff, float* dx,
+                     int dx_accumulate, const lhn_bnsum* bns, void* stream) {
   LHN_CHECK_ARG(lhn_view_ok(x) && dout && dx && out_coff >= 0 && out_coff + x->C <= out_cstride, "lhn_avgpool_bwd: bad args");
   LHN_CHECK_ARG(x->C % 4 == 0 && x->C <= 1024, "lhn_avgpool_bwd: C=%d", x->C);
-  hipLaunchKernelGGL(k_avgpool_bwd, dim3(grid_cap((int64_t)x->N * x->H, 8)), dim3(256), 0, (hipStream_t)stream, *x, dout, OH, OW, dx, dx_accumulate, out_cstride, out_coff);
+  lhn_bnsum bs;
+  if (bns_of(bns, x, &bs, "lhn_avgpool_bwd3")) return 1;
+  hipLaunchKernelGGL(k_avgpool_bwd, dim3(grid_cap((int64_t)x->N * x->H, 8)), dim3(256), 0, (hipStream_t)stream, *x, dout, OH, OW, dx, dx_accumulate, out_cstride, out_coff, bs);
   LHN_CHECK_LAUNCH("lhn_avgpool_bwd");
   return 0;
 }

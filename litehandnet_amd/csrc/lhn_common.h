@@ -491,6 +491,40 @@ __device__ __forceinline__ void lhn_block_stat_atomics_d(const double (&s)[4], c
   }
 }
 
+// ---- reader-side BatchNorm-backward sums (lhn_bnsum), elementwise thread layout (c4 = tid % C4 float4 channel groups of the
+// reader's input view, pixel lane = tid / C4; dead lanes carry zeros): block reduction + one double atomic per channel and
+// block into the producer's replica (blockIdx.x % LHN_STAT_REPLICAS).  red: >= 512 float4 of LDS nobody else is using.
+__device__ __forceinline__ void lhn_bns_flush(const lhn_bnsum& b, f4 s, f4 q, int C4, f4* red) {
+  double* st = b.sums + (size_t)(blockIdx.x % LHN_STAT_REPLICAS) * 2 * b.C + b.coff;
+  if (C4 <= 32 && (C4 & (C4 - 1)) == 0) {
+    lhn_block_stat_atomics(s, q, C4, red, st, st + b.C);
+  } else {
+    const int PL = 256 / C4;
+    __syncthreads();
+    red[threadIdx.x * 2] = s;
+    red[threadIdx.x * 2 + 1] = q;
+    __syncthreads();
+    if ((int)threadIdx.x < C4) {
+      double sd[4] = {0, 0, 0, 0}, qd[4] = {0, 0, 0, 0};
+      for (int j = 0; j < PL; ++j) {
+        const f4 a = red[(j * C4 + threadIdx.x) * 2], c = red[(j * C4 + threadIdx.x) * 2 + 1];
+        sd[0] += a.x; sd[1] += a.y; sd[2] += a.z; sd[3] += a.w;
+        qd[0] += c.x; qd[1] += c.y; qd[2] += c.z; qd[3] += c.w;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        atomicAdd(st + 4 * threadIdx.x + j, sd[j]);
+        atomicAdd(st + b.C + 4 * threadIdx.x + j, qd[j]);
+      }
+    }
+  }
+}
+// derivative of the pending activation at the raw value
+__device__ __forceinline__ f4 lhn_dact_xf(f4 raw, const Xf4& t) {
+  const f4 u = raw * t.sc + t.sh;
+  return (f4){u.x > 0.f ? 1.f : t.sl.x, u.y > 0.f ? 1.f : t.sl.y, u.z > 0.f ? 1.f : t.sl.z, u.w > 0.f ? 1.f : t.sl.w};
+}
+
 __device__ __forceinline__ float lhn_wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

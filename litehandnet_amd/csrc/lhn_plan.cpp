@@ -7,8 +7,18 @@
 #include <vector>
 #include "lhn_common.h"
 
-extern "C" int lhn_ew_bwd2(const lhn_view* src, const lhn_view* dst, const float* ddst, const float* dst_dpool,
-                           float out_slope, float* dsrc, int accumulate, void* stream);
+// reader-side BatchNorm sums (lhn_bnsum) of an op: byte offsets of the producer's sums / saved statistics, channels, offset
+static lhn_bnsum mkbns(void* ws, int64_t sums_off, int64_t save_off, int C, int coff) {
+  lhn_bnsum b;
+  memset(&b, 0, sizeof(b));
+  if (sums_off >= 0 && save_off >= 0 && C > 0) {
+    b.sums = reinterpret_cast<double*>(static_cast<char*>(ws) + sums_off);
+    b.save = reinterpret_cast<const float*>(static_cast<char*>(ws) + save_off);
+    b.C = C;
+    b.coff = coff;
+  }
+  return b;
+}
 
 enum {
   OP_STEM = 1, OP_PW = 2, OP_DW = 3, OP_KXK = 4, OP_FINALIZE = 5, OP_EW = 6, OP_MAXPOOL = 7, OP_AVGPOOL = 8,
@@ -465,8 +475,9 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
           nchw += (int64_t)o.i[6] * khw;
           po.nchw_batch_stride = (int64_t)o.i[7] * khw;
         }
-        rc = lhn_conv_pw_bwd2(&x, prm<const float>(params, o.p[0]), &y, &g, dx, o.i[2] == 2, prm<float>(grads, o.p[1]),
-                              prm<float>(grads, o.p[2]), o.i[0], nchw, nrep, rstr, &po, stream);
+        const lhn_bnsum bs = mkbns(ws, o.ws[0], o.ws[1], (int)o.f[6], (int)o.f[7]);      // ws[0..1], f[6..7]: the input's producer
+        rc = lhn_conv_pw_bwd3(&x, prm<const float>(params, o.p[0]), &y, &g, dx, o.i[2] == 2, prm<float>(grads, o.p[1]),
+                              prm<float>(grads, o.p[2]), o.i[0], nchw, nrep, rstr, &po, bs.sums ? &bs : nullptr, stream);
         break;
       }
       case OP_DW_BWD: {
@@ -533,23 +544,26 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
           rc = lhn_bilinear_bwd(&src, &d, reinterpret_cast<const float*>(at(ws, db.grad_off)),
                                 reinterpret_cast<float*>(at(ws, P->bufs[o.in_buf[0]].grad_off)), o.i[0], o.f[0], stream);
         } else {
-          rc = lhn_ew_bwd2(&src, &d, reinterpret_cast<const float*>(at(ws, db.grad_off)),
+          const lhn_bnsum bs = mkbns(ws, o.ws[0], o.ws[1], o.i[4], o.i[5]);
+          rc = lhn_ew_bwd3(&src, &d, reinterpret_cast<const float*>(at(ws, db.grad_off)),
                            reinterpret_cast<const float*>(at(ws, db.dpool_off)), o.f[0],
-                           reinterpret_cast<float*>(at(ws, P->bufs[o.in_buf[0]].grad_off)), o.i[0], stream);
+                           reinterpret_cast<float*>(at(ws, P->bufs[o.in_buf[0]].grad_off)), o.i[0], bs.sums ? &bs : nullptr, stream);
         }
         break;
       }
       case OP_MAXPOOL_BWD: {
         lhn_view x = mkview(P, ws, o.in_buf[0], o.in_coff[0], o.in_C[0]);
         lhn_view y = mkview(P, ws, o.out_buf, o.out_coff, o.out_C);
-        rc = lhn_maxpool2_bwd(&x, &y, reinterpret_cast<const float*>(at(ws, P->bufs[o.out_buf].grad_off)),
-                              reinterpret_cast<float*>(at(ws, P->bufs[o.in_buf[0]].grad_off)), o.i[0], stream);
+        const lhn_bnsum bs = mkbns(ws, o.ws[0], o.ws[1], o.i[4], o.i[5]);
+        rc = lhn_maxpool2_bwd2(&x, &y, reinterpret_cast<const float*>(at(ws, P->bufs[o.out_buf].grad_off)),
+                               reinterpret_cast<float*>(at(ws, P->bufs[o.in_buf[0]].grad_off)), o.i[0], bs.sums ? &bs : nullptr, stream);
         break;
       }
       case OP_AVGPOOL_BWD: {
         lhn_view x = mkview(P, ws, o.in_buf[0], o.in_coff[0], o.in_C[0]);
-        rc = lhn_avgpool_bwd2(&x, reinterpret_cast<const float*>(at(ws, o.ws[0])), o.i[0], o.i[1], o.i[3] > 0 ? o.i[3] : x.C, o.i[4],
-                              reinterpret_cast<float*>(at(ws, P->bufs[o.in_buf[0]].grad_off)), o.i[2], stream);
+        const lhn_bnsum bs = mkbns(ws, o.ws[1], o.ws[2], o.i[5], o.i[6]);
+        rc = lhn_avgpool_bwd3(&x, reinterpret_cast<const float*>(at(ws, o.ws[0])), o.i[0], o.i[1], o.i[3] > 0 ? o.i[3] : x.C, o.i[4],
+                              reinterpret_cast<float*>(at(ws, P->bufs[o.in_buf[0]].grad_off)), o.i[2], bs.sums ? &bs : nullptr, stream);
         break;
       }
       case OP_SHUFFLE_BWD: {     // i[0], i[1]: 0 = no gradient wanted, 1 = store, 2 = accumulate (operand a, b)

@@ -226,7 +226,7 @@ class Engine:
         plan = CompiledPlan(pb, tensors, x.device)
         plan.out_hw, plan.nchw_out = (y.H, y.W), nchw_out
         plan.stacked = bool(getattr(self.module, "stacked_output", False))
-        plan.mask_fn = self.mask_fn
+        plan.engine = self              # (the plan reads `engine.mask_fn` at RUN time: setting or clearing it later takes effect)
         self.plans[key] = plan
         return plan
 

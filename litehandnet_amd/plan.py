@@ -789,6 +789,63 @@ class PlanBuilder:
             self.fused_bn_sums = 0
             for r in self.recs:
                 r.pop("sums_by_reader", None)
+                r.pop("sums_by_readers", None)
+            # Reader-side BatchNorm sums, general form (include/lhn.h: lhn_bnsum): du is linear in dz and dz is the sum of what the
+            # readers' backward kernels hand back, so when EVERY reader of a convolution + BatchNorm output can add its part
+            # (elementwise combines, pools, the fused 1x1 backward) the producer's lhn_bn_bwd_reduce pass is not launched.
+            # bns[(id(reader record), buf, coff, C)] = (producer record, channel offset inside the producer's BatchNorm)
+            bns = {}
+            self.reader_bn_sums = 0
+            if os.environ.get("LHN_READER_BN_SUMS", "1") != "0":
+                for P in self.recs:
+                    if P["op"] not in (STEM, PW, DW, KXK) or P["bn"] is None or P.get("sums_by_ca") or isinstance(P["out"], TCat):
+                        continue
+                    o = P["out"]
+                    if o.buf < 0 or P.get("wrc", (0, 0))[0] or P.get("bn_repeat", 1) != 1 or o.buf in aliased:
+                        continue
+                    ob = self.bufs[o.buf]
+                    if ob.gate or ob.dpool or ob.lazy is not None or (self.out_ref is not None and o.buf == self.out_ref.buf):
+                        continue
+                    lo, hi = o.coff, o.coff + o.C
+                    mine, ok = [], True
+                    for q in uses.get(o.buf, ()):
+                        views = [q["x"]] if q["op"] in (PW, DW, KXK, MAXPOOL, AVGPOOL) else q["srcs"] if q["op"] == EW else [q["a"], q["b"]]
+                        for t in views:
+                            if t.buf != o.buf or t.coff + t.C <= lo or hi <= t.coff:
+                                continue
+                            if not (lo <= t.coff and t.coff + t.C <= hi):
+                                ok = False
+                            elif q["op"] == EW:
+                                ok = ok and not q.get("lazy") and "flat" not in q and not q.get("mode") and q.get("coefs") is None and \
+                                    q["slope"] not in (SLOPE_SILU, SLOPE_RELU_SIGMOID) and not isinstance(q["out"], TCat) and \
+                                    not any(a[0] == id(q) for a in pending_add.get(t.buf, ())) and \
+                                    q["out"].H % t.H == 0 and q["out"].W % t.W == 0
+                            elif q["op"] in (MAXPOOL, AVGPOOL):
+                                pass
+                            elif q["op"] == PW:
+                                # (the fused 1x1 backward kernel keeps the shapes whose TILES stay below 64 x 128: csrc/k_conv_pw.hip)
+                                ci_t = 32 if t.C <= 32 else 64 if t.C <= 64 else 128
+                                nto = (q["out"].C + 31) // 32
+                                nto = 4 if nto == 3 else nto
+                                ok = ok and q["stride"] == 1 and not q.get("nchw") and q.get("xs") is None and t.C <= 128 and \
+                                    q["out"].C <= 128 and ci_t * nto * 32 < 64 * 128 and not q["wrc"][1] and not q["wrc"][0] and \
+                                    (t.coff, t.C) == (q["x"].coff, q["x"].C)
+                            else:
+                                ok = False
+                            mine.append((q, t))
+                    if ok and mine:
+                        P["sums_by_readers"] = True
+                        self.reader_bn_sums += 1
+                        for q, t in mine:
+                            bns[(id(q), t.buf, t.coff, t.C)] = (P, t.coff - lo)
+
+            def bns_of(q, t):
+                """(ws pair, (C, coff)) of the BatchNorm sums reader record q adds for its input view t, or ((-1, -1), (0, 0))."""
+                e = bns.get((id(q), t.buf, t.coff, t.C))
+                if e is None:
+                    return (-1, -1), (0, 0)
+                P, off = e
+                return (self._abs(P["sums"]), self._abs(P["save"])), (P["out"].C, off)
             for r in reversed(self.recs):
                 k = r["op"]
                 if k in (STEM, PW, DW, KXK, EW, SHUFFLE, MAXPOOL, AVGPOOL) and not (k == PW and r.get("nchw")) and \
@@ -808,7 +865,7 @@ class PlanBuilder:
                     if bn is not None:
                         body.append(mk(BN_BWD, out=out, p=(self._p(bn.weight), self._p(bn.weight), self._p(bn.bias)),
                                        ws=(self._abs(r["sums"]), self._abs(r["save"]), self._abs(r["bcnt"])),
-                                       i=(r["wrc"][0] if k == PW else 0, 1 if (r.get("sums_by_reader") or r.get("sums_by_ca")) else 0)))
+                                       i=(r["wrc"][0] if k == PW else 0, 1 if (r.get("sums_by_reader") or r.get("sums_by_ca") or r.get("sums_by_readers")) else 0)))
                     if k == STEM:
                         body.append(mk(STEM_BWD, out=out, p=(pw, pw), i=(r["k"], r["stride"], r["pad"], x.H, x.W, use_coef)))
                         continue
@@ -820,9 +877,10 @@ class PlanBuilder:
                             mode = 2
                         o = TRef(-1, 0, out.C, out.H, out.W) if r["nchw"] else out
                         # a bias in front of a train-mode BatchNorm has an identically zero gradient
-                        body.append(mk(PW_BWD, ins=(x,), out=o, p=(pw, pw, self._p(conv.bias) if bn is None else -1),
+                        bw, bc = bns_of(r, x) if need_dx else ((-1, -1), (0, 0))
+                        body.append(mk(PW_BWD, ins=(x,), out=o, p=(pw, pw, self._p(conv.bias) if bn is None else -1), ws=bw,
                                        i=(r["stride"], 1 if r["nchw"] else 0, mode, r["wrc"][0], r["wrc"][1], use_coef,
-                                          r["stack"][0], r["stack"][1])))
+                                          r["stack"][0], r["stack"][1]), f=(0.0,) * 6 + (float(bc[0]), float(bc[1]))))
                     elif k == DW:
                         # the producer's BatchNorm-backward sums ride in this kernel when it is the only reader of x
                         # (RepBasicUnit 1x1 -> 3x3 depthwise; include/lhn.h: lhn_conv_dw_bwd2)
@@ -873,19 +931,22 @@ class PlanBuilder:
                         if any(a[0] == id(r) for a in pending_add.get(s.buf, ())):
                             continue                # d(out) joins s's gradient inside the depthwise backward kernels that read s
                         mode = self._grad_mode(written, s)
-                        body.append(mk(EW_BWD, ins=(s,), out=r["out"], i=(1 if mode == 2 else 0,), f=(r["slope"],)))
+                        bw, bc = bns_of(r, s)
+                        body.append(mk(EW_BWD, ins=(s,), out=r["out"], ws=bw, i=(1 if mode == 2 else 0, 0, 0, 0, bc[0], bc[1]), f=(r["slope"],)))
                 elif k == SHUFFLE:
                     ma = 0 if r["a"].buf == self._no_grad_buf else self._grad_mode(written, r["a"])
                     mb = 0 if r["b"].buf == self._no_grad_buf else self._grad_mode(written, r["b"])
                     body.append(mk(SHUFFLE_BWD, ins=(r["a"], r["b"]), out=r["out"], i=(ma, mb)))
                 elif k == MAXPOOL:
                     mode = self._grad_mode(written, r["x"])
-                    body.append(mk(MAXPOOL_BWD, ins=(r["x"],), out=r["out"], i=(1 if mode == 2 else 0,)))
+                    bw, bc = bns_of(r, r["x"])
+                    body.append(mk(MAXPOOL_BWD, ins=(r["x"],), out=r["out"], ws=bw, i=(1 if mode == 2 else 0, 0, 0, 0, bc[0], bc[1])))
                 elif k == AVGPOOL:
                     mode = self._grad_mode(written, r["x"])
                     ob = self.bufs[r["out"].buf]
-                    body.append(mk(AVGPOOL_BWD, ins=(r["x"],), ws=(ob.off["grad"],),
-                                   i=(r["OH"], r["OW"], 1 if mode == 2 else 0, ob.C, r["out"].coff)))
+                    bw, bc = bns_of(r, r["x"])
+                    body.append(mk(AVGPOOL_BWD, ins=(r["x"],), ws=(ob.off["grad"],) + bw,
+                                   i=(r["OH"], r["OW"], 1 if mode == 2 else 0, ob.C, r["out"].coff, bc[0], bc[1])))
                 elif k == SE_MLP:
                     y, dn, up = r["y"], r["down"], r["up"]
                     body.append(mk(GATE_REDUCE, out=y, ws=(-1, -1, -1, self._abs(r["dgate"]))))
@@ -1038,7 +1099,8 @@ class CompiledPlan:
         # dropout masks (Dropout2d of ChannelAttension, common.py:57; Dropout of mynet's attention, pose_hg_ms_att.py:171):
         # one [N, C] slice per attention module, values 0 or 1/keep.  `mask_fn(plan)`, when set, fills them instead of the
         # default bernoulli_ draw -- parity tests feed the oracle the same masks.
-        self.mask_fn = None
+        self.mask_fn = None            # plan-level override; otherwise the owning engine's `mask_fn` as it is at run time
+        self.engine = None
         self.mask_slices = []
         if pb.ar["mask"].size:
             self.mask_view = self.view_f32(pb.arena_base["mask"], pb.ar["mask"].size // 4)
@@ -1076,8 +1138,9 @@ class CompiledPlan:
             _TRAIN_RUNS += 1           # running statistics are about to move: every plan's eval tables become stale
             self._table_sig = None
         if phase == 0 and training and self.mask_view is not None:
-            if self.mask_fn is not None:
-                self.mask_fn(self)
+            fn = self.mask_fn if self.mask_fn is not None else getattr(self.engine, "mask_fn", None)
+            if fn is not None:
+                fn(self)
             else:
                 keep = 1.0 - self.pb.p_drop
                 self.mask_view.bernoulli_(keep).mul_(1.0 / keep)

@@ -108,6 +108,46 @@ def test_masks_are_per_plane_and_scaled(dev):
     assert torch.equal(snap, plan.mask_slices[0][1])
 
 
+def test_mask_injector_is_read_at_run_time_and_no_grad_forward_between(dev):
+    """`Engine.mask_fn` set AFTER the first forward of a shape takes effect, and clearing it goes back to random masks (the
+    plan used to copy it once, at creation).  And the guard of Engine against stale forwards: a training forward, then a
+    torch.no_grad() forward of the same shape (its own plan and workspace), then the backward of the first one -- allowed,
+    and equal to the backward without the extra forward; a second grad-enabled forward in between is refused."""
+    from litehandnet_amd import _lib, get_model
+    cfg = litehandnet_cfg("B")
+    m = get_model(cfg).to(dev).train()
+    x = synth.synth_images(4, 64, 3).to(dev)
+    g = torch.ones(4, 21, 16, 16, device=dev)
+    y0 = m(x)                                                 # random masks, creates the training plan
+    eng = m.__dict__["_engine"]
+    plan = [p for k, p in eng.plans.items() if k[1]][0]
+    ones = lambda pl: [v.fill_(1.0) for _, v in pl.mask_slices]      # noqa: E731
+    eng.mask_fn = ones
+    y1 = m(x)
+    assert all(float(v.min()) == 1.0 == float(v.max()) for _, v in plan.mask_slices)
+    m.zero_grad()
+    y1.backward(g)
+    g1 = torch.cat([p.grad.flatten().clone() for p in m.parameters()])
+    # the same step with a no_grad forward of the same shape in between
+    rs = {k: v.clone() for k, v in m.state_dict().items()}
+    m.load_state_dict(rs)
+    y2 = m(x)
+    with torch.no_grad():
+        m(x)
+    m.zero_grad()
+    y2.backward(g)
+    g2 = torch.cat([p.grad.flatten() for p in m.parameters()])
+    assert float((g1 - g2).norm()) <= 1e-3 * float(g1.norm())      # (running statistics moved once more: same masks, same batch)
+    y3 = m(x)
+    m(x)                                                       # a second grad-enabled forward of the same shape ...
+    with pytest.raises(_lib.LhnError):
+        y3.backward(g)                                         # ... makes the first one stale
+    eng.mask_fn = None
+    m(x)
+    assert any(float(v.min()) == 0.0 for _, v in plan.mask_slices)            # random masks again (p = 0.3 over 8 x 4 x 128 values)
+    del y0
+
+
 def test_channel_attention_with_dropout(dev):
     from litehandnet_amd.common import ChannelAttension
     r = np.random.Generator(np.random.PCG64(5))

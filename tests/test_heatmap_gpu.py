@@ -139,6 +139,30 @@ def test_loss_golden_and_oracle(dev, golden_dir):
     lg.backward()
     assert abs(float(lg) - float(lref)) <= 5e-6 * abs(float(lref))
     assert torch.allclose(og.grad.cpu(), oc.grad, rtol=1e-5, atol=1e-12)
+    # stacked hourglass output [N, S, K, H, W] (hourglassnet.py:136) with a GENUINE per-stack 5-D target and [N, S, K, 1] weights
+    # (test.py:145 indexes meta['target'][:, -1]: the reference's hourglass targets are per stack), value and gradient against
+    # the oracle; and the 4-D target form (every stack supervised by the same target: an extension, parity unpinned -- the
+    # reference's own 4-D broadcast only works when N == S) equals the 5-D form with the target repeated
+    S = 2
+    o5 = torch.randn(8, S, 21, 32, 32)
+    t5 = torch.rand(8, S, 21, 32, 32) * (torch.rand(8, S, 21, 32, 32) > 0.7)
+    w5 = (torch.rand(8, S, 21, 1) > 0.1).float()
+    oc = o5.clone().requires_grad_()
+    lref = torch_ref.distance_loss(oc, t5, w5)
+    lref.backward()
+    og = o5.cuda().requires_grad_()
+    lg, _ = crit(og, {"target": t5, "target_weight": w5})
+    lg.backward()
+    assert abs(float(lg) - float(lref)) <= 5e-6 * abs(float(lref))
+    assert torch.allclose(og.grad.cpu(), oc.grad, rtol=1e-5, atol=1e-12)
+    t4, w4 = t5[:, 0].contiguous(), w5[:, 0].contiguous()
+    og2 = o5.cuda().requires_grad_()
+    l4, _ = crit(og2, {"target": t4, "target_weight": w4})
+    l4.backward()
+    oc2 = o5.clone().requires_grad_()
+    lrep = torch_ref.distance_loss(oc2, t4.unsqueeze(1).expand(-1, S, -1, -1, -1), w4.unsqueeze(1).expand(-1, S, -1, -1))
+    lrep.backward()
+    assert abs(float(l4) - float(lrep)) <= 5e-6 * abs(float(lrep)) and torch.allclose(og2.grad.cpu(), oc2.grad, rtol=1e-5, atol=1e-12)
 
 
 def test_decode_dark_unbiased(dev, golden_dir):

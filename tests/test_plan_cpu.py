@@ -191,8 +191,13 @@ def test_bn_backward_sums_ride_in_the_reader(monkeypatch):
     skipped = [o for o in bwd if o.kind == BN_BWD and o.i[1] == 1]
     ca = [o for o in bwd if o.kind == CA_MLP_BWD]
     by_ca = {o.ws[k] for o in ca for k in (8, 9) if o.ws[k] >= 0}
-    assert pb.fused_bn_sums == len(fused) == 19 and len(by_ca) == 12 and len(skipped) == 31
-    assert {o.ws[4] for o in fused} | by_ca == {o.ws[0] for o in skipped}          # the same sums buffers
+    # ... and 19 more get them from ALL their readers' backward kernels (lhn_bnsum: elementwise combines, pools, the fused 1x1
+    # backward each add their part): 50 of 52 BatchNorms have no reduce pass (the two left are read by the stride-2 depthwise)
+    from litehandnet_amd.plan import AVGPOOL_BWD, EW_BWD, MAXPOOL_BWD, PW_BWD
+    by_readers = {o.ws[0] for o in bwd if o.kind in (EW_BWD, MAXPOOL_BWD, PW_BWD) and o.ws[0] >= 0} | \
+                 {o.ws[1] for o in bwd if o.kind == AVGPOOL_BWD and o.ws[1] >= 0}
+    assert pb.fused_bn_sums == len(fused) == 19 and len(by_ca) == 12 and pb.reader_bn_sums == len(by_readers) == 19 and len(skipped) == 50
+    assert {o.ws[4] for o in fused} | by_ca | by_readers == {o.ws[0] for o in skipped}          # the same sums buffers
     for o in fused:
         assert o.i[4] == 1 and o.i[0] == 3 and o.i[1] == 1 and o.i[3] == 1 and o.ws[5] >= 0        # dx stored, 3x3 s1 d1
     for o in ca:
@@ -202,6 +207,7 @@ def test_bn_backward_sums_ride_in_the_reader(monkeypatch):
     assert sum(1 for o in fwd if o.kind == AVGPOOL and o.ws[1] >= 0) == 8
     monkeypatch.setenv("LHN_FUSE_BN_SUMS", "0")
     monkeypatch.setenv("LHN_GATE_BN_SUMS", "0")
+    monkeypatch.setenv("LHN_READER_BN_SUMS", "0")
     _, p0, _ = _build("B", backward=True)
     cb, cf, cbw, nf, nb = p0.finalize()
     assert p0.fused_bn_sums == 0 and not any(cbw[i].kind == BN_BWD and cbw[i].i[1] == 1 for i in range(nb))

@@ -347,9 +347,9 @@ def test_bench_two_ranks_gloo_rehearsal(dev):
 
 
 def test_run_to_run_spread(dev):
-    """No deterministic mode is built: BatchNorm statistics, weight-gradient replicas and the gate / pool
-    reductions are accumulated with double / float atomics, so the last bits depend on workgroup arrival order.  This bounds
-    the spread: the SAME training forward + backward (same weights, inputs, dropout masks) run three times gives outputs and
+    """DEFAULT mode (the deterministic one is LHN_DETERMINISTIC=1, see test_deterministic_mode_is_bit_reproducible): BatchNorm
+    statistics, weight-gradient replicas and the gate / pool reductions are accumulated with double / float atomics, so the
+    last bits depend on workgroup arrival order.  This bounds the spread: the SAME training forward + backward (same weights, inputs, dropout masks) run three times gives outputs and
     parameter gradients equal to 1e-5 relative (norm-wise), running statistics to 1e-6."""
     from litehandnet_amd import get_loss, get_model
     cfg = litehandnet_cfg("B")
