@@ -23,29 +23,6 @@ extern "C" {
  * layout double[LHN_STAT_REPLICAS][2][C]; a block adds into replica (blockIdx % LHN_STAT_REPLICAS). */
 #define LHN_STAT_REPLICAS 32
 
-/* A train-mode BatchNorm whose batch statistics have been accumulated by the producing convolution but not yet turned into
- * the buffer's (scale, shift, slope) table.  Instead of a ~6 us single-workgroup launch between producer and consumer, the
- * FIRST kernel that reads the buffer does it in its prologue: every workgroup folds the replicated sums into a private LDS
- * copy of the table (same arithmetic as lhn_bn_finalize), workgroup 0 also stores the table, the running statistics, the
- * saved mean / invstd and bumps num_batches_tracked.  Later readers find the table in memory. */
-typedef struct lhn_pend {
-  const double* stats;            /* [LHN_STAT_REPLICAS][2][C] */
-  const float*  gamma;
-  const float*  beta;
-  float*        running_mean;
-  float*        running_var;
-  int64_t*      num_batches_tracked;
-  float*        save_mean_invstd; /* [2][C] or NULL */
-  const float*  conv_bias;        /* see lhn_bn_finalize */
-  double        count;
-  float         eps, momentum, slope;
-  int32_t       coff, C;          /* channel slice of the buffer */
-} lhn_pend;
-typedef struct lhn_pends {
-  lhn_pend p[2];
-  int32_t  n;                     /* 0..2 pending slices */
-} lhn_pends;
-
 typedef struct lhn_view {
   float*       data;    /* base of the [N,H,W,cstride] buffer                                        */
   const float* table;   /* [3][cstride] scale | shift | slope, absolute channel index; NULL=identity */
@@ -54,9 +31,7 @@ typedef struct lhn_view {
   int32_t cstride;      /* channels of the underlying buffer                                          */
   int32_t coff;         /* first channel of the view                                                  */
   int32_t C;            /* channels of the view                                                       */
-  const lhn_pends* pend; /* HOST pointer or NULL: BatchNorms this reader has to finalize first (forward readers that support
-                          * it: lhn_conv_pw_fwd*, lhn_conv_dw_fwd*, lhn_ew_fwd*, lhn_maxpool2_fwd, lhn_avgpool_fwd; every other
-                          * entry point rejects a non-NULL value).  `table` must then be writable memory.           */
+  const void* pend;      /* reserved, must be NULL (round 2's deferred BatchNorm finalize is gone; the field keeps the layout) */
 } lhn_view;
 
 /* gradient-side companion of a BatchNorm'd conv output (see DESIGN.md "backward") */
@@ -460,7 +435,7 @@ int lhn_ca_mlp_bwd(const float* pooled, const float* w3, const float* gamma, con
 typedef struct lhn_op {
   int32_t kind;
   int32_t in_buf[3], in_coff[3], in_C[3];
-  int32_t pend[3][2];  /* forward ops: per input, indices of the producer ops whose BatchNorm this op finalizes, -1 = none */
+  int32_t reserved[6]; /* (round 2: deferred-finalize indices) */
   int32_t out_buf, out_coff, out_C;
   int32_t p[12];       /* parameter / state indices into the params array, -1 = none              */
   int64_t ws[12];      /* byte offsets into the workspace, -1 = none                               */

@@ -29,7 +29,7 @@ class GradView(C.Structure):
 
 class Op(C.Structure):
     _fields_ = [("kind", C.c_int32),
-                ("in_buf", C.c_int32 * 3), ("in_coff", C.c_int32 * 3), ("in_C", C.c_int32 * 3), ("pend", (C.c_int32 * 2) * 3),
+                ("in_buf", C.c_int32 * 3), ("in_coff", C.c_int32 * 3), ("in_C", C.c_int32 * 3), ("reserved", C.c_int32 * 6),
                 ("out_buf", C.c_int32), ("out_coff", C.c_int32), ("out_C", C.c_int32),
                 ("p", C.c_int32 * 12), ("ws", C.c_int64 * 12), ("i", C.c_int32 * 8), ("f", C.c_float * 8)]
 

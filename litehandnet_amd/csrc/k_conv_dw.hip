@@ -11,7 +11,7 @@
 template <int K>
 __global__ void __launch_bounds__(256) k_dw_fwd(lhn_view x, const float* __restrict__ w, lhn_view y,
                                                 double* __restrict__ stats, int stride, int pad, int dil, lhn_bnfin fin,
-                                                lhn_pends px) {
+                                                int /*unused*/) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int C = x.C, C4 = C >> 2;
   constexpr int KK = K * K;
@@ -21,8 +21,7 @@ __global__ void __launch_bounds__(256) k_dw_fwd(lhn_view x, const float* __restr
   const int c4 = tid % C4, pl = tid / C4, PL = 256 / C4;
   const int cin = x.coff + 4 * c4, cout = y.coff + 4 * c4;
   // pending BatchNorm of the input (LDS: >= 8 KB, weights staged after)
-  const Xf4 xf = lhn_load_xf_t(lhn_resolve_table(x, px, smem), x.cstride, cin);
-  if (px.n > 0) __syncthreads();
+  const Xf4 xf = lhn_load_xf(x, cin);
   for (int i = tid; i < KK * C; i += 256) {
     const int c = i / KK, t = i - c * KK;
     Ws[t * C + c] = w ? w[i] : 1.f;
@@ -403,7 +402,6 @@ struct DwExtra {
   lhn_view v;
   float coef[2];
   int n;             // 0 or 1
-  lhn_pends pend[2]; // BatchNorms to finalize first: [0] = x, [1] = v (see lhn_pend)
   float* sum_out;    // the summed input (tile interiors) is also written here, or NULL (lhn_pw_opts.sum_out)
   int so_cstride, so_coff;
 };
@@ -411,7 +409,7 @@ struct DwExtra {
 int lhn_dwk_fwd_lds(const lhn_view* x, const float* w, const lhn_view* y, double* stats, int k, int dil, lhn_bnfin fin,
                     hipStream_t s, const DwExtra* ex);
 struct DwBnSum;
-static int dws2_fwd(const lhn_view* x, const float* w, const lhn_view* y, double* stats, lhn_bnfin fin, const lhn_pends& px, hipStream_t s);
+static int dws2_fwd(const lhn_view* x, const float* w, const lhn_view* y, double* stats, lhn_bnfin fin, hipStream_t s);
 static int dws2_bwd(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx, int dx_acc, float* dw,
                     int nrep, int64_t rep_stride, hipStream_t s);
 int lhn_dwk_bwd_lds(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx, int dx_acc,
@@ -467,17 +465,15 @@ extern "C" int lhn_conv_dw_fwd(const lhn_view* x, const float* w, const lhn_view
   const size_t lds = (size_t)(k * k * x->C) * 4 + 256 * 2 * 16;
   const int grid = grid_for((int64_t)y->N * Ho, 1, 8);
   hipStream_t s = (hipStream_t)stream;
-  LHN_CHECK_ARG(lhn_pend_ok(x), "lhn_conv_dw_fwd: bad pending BatchNorm on the input view");
-  const lhn_pends px = lhn_pends_of(x);
+  LHN_CHECK_ARG(lhn_no_pend(x), "lhn_conv_dw_fwd: lhn_view.pend is reserved (NULL)");
+  const int px = 0;
   DwExtra ex0;
   ex0.n = 0;
-  ex0.pend[0] = px;
-  ex0.pend[1].n = 0;
   ex0.sum_out = nullptr;
   if (w && stride == 1 && pad == dil * (k - 1) / 2 && x->C % 4 == 0 && y->W >= 8 && !lhn_dw_force_gather() &&
       lhn_dwk_fwd_lds(x, w, y, stats, k, dil, fin, s, &ex0)) {
   } else if (w && k == 3 && stride == 2 && pad == 1 && dil == 1 && x->C % 4 == 0 && !lhn_dw_force_gather() &&
-             dws2_fwd(x, w, y, stats, fin, px, s)) {
+             dws2_fwd(x, w, y, stats, fin, s)) {
   } else if (k == 3)
     hipLaunchKernelGGL((k_dw_fwd<3>), dim3(grid), dim3(256), lds, s, *x, w, *y, stats, stride, pad, dil, fin, px);
   else if (k == 7)
@@ -1128,11 +1124,8 @@ __global__ void __launch_bounds__(256) k_dwk_fwd_lds(lhn_view x, const float* __
   int t = bid;
   if (t < ntile) issue(t);
   // (the tile region is free until the first commit, which follows a barrier)
-  xf = lhn_load_xf_t(lhn_resolve_table(x, ex.pend[0], smem), x.cstride, cin);
-  if (NS > 1) {
-    if (ex.pend[0].n > 0 && ex.pend[1].n > 0) __syncthreads();
-    xf2 = lhn_load_xf_t(lhn_resolve_table(ex.v, ex.pend[1], smem), ex.v.cstride, cin2);
-  }
+  xf = lhn_load_xf(x, cin);
+  if (NS > 1) xf2 = lhn_load_xf(ex.v, cin2);
   for (; t < ntile; t += gridDim.x) {
     int r = t / cgroups;
     const int tw = r % tiles_w;
@@ -1500,7 +1493,7 @@ template <int K, int DIL, int NS = 1>
 static void launch_dwk_fwd(const lhn_view* x, const float* w, const lhn_view* y, double* stats, lhn_bnfin fin, hipStream_t s, int ps = 1,
                            const DwExtra* exp = nullptr) {
   DwExtra ex;
-  if (exp) ex = *exp; else { ex.n = 0; ex.pend[0].n = ex.pend[1].n = 0; ex.sum_out = nullptr; }
+  if (exp) ex = *exp; else { ex.n = 0; ex.sum_out = nullptr; }
   constexpr int TH = 8, TW = 32, P = DIL * (K - 1) / 2;
   const int cg = (x->C + 31) / 32;
   const int sh = (y->H + ps - 1) / ps, sw = (y->W + ps - 1) / ps;       // largest parity sub-lattice
@@ -1540,7 +1533,7 @@ struct DwS2 {
 };
 
 __global__ void __launch_bounds__(256) k_dws2_fwd_lds(lhn_view x, const float* __restrict__ w, lhn_view y, double* __restrict__ stats,
-                                                      int tiles_h, int tiles_w, int cgroups, lhn_bnfin fin, lhn_pends px) {
+                                                      int tiles_h, int tiles_w, int cgroups, lhn_bnfin fin) {
   using T = DwS2;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   f4* tx = reinterpret_cast<f4*>(smem);          // [XPIX][8]
@@ -1557,7 +1550,7 @@ __global__ void __launch_bounds__(256) k_dws2_fwd_lds(lhn_view x, const float* _
     const int k = i >> 3, cc = cg * 32 + 4 * min(i & 7, cvalid - 1);
     wl[i] = (f4){w[(cc + 0) * 9 + k], w[(cc + 1) * 9 + k], w[(cc + 2) * 9 + k], w[(cc + 3) * 9 + k]};
   }
-  const Xf4 xf = lhn_load_xf_t(lhn_resolve_table(x, px, smem), x.cstride, cin);
+  const Xf4 xf = lhn_load_xf(x, cin);
   double sd[4] = {0, 0, 0, 0}, qd[4] = {0, 0, 0, 0};
   constexpr int NIT = (T::XPIX + 31) / 32;
   for (int t = blockIdx.x; t < ntile; t += gridDim.x) {
@@ -1768,15 +1761,14 @@ __global__ void __launch_bounds__(256, 2) k_dws2_bwd_lds(lhn_view x, const float
 }
 
 // returns 1 if the stride-2 tiled kernel was launched
-static int dws2_fwd(const lhn_view* x, const float* w, const lhn_view* y, double* stats, lhn_bnfin fin, const lhn_pends& px, hipStream_t s) {
+static int dws2_fwd(const lhn_view* x, const float* w, const lhn_view* y, double* stats, lhn_bnfin fin, hipStream_t s) {
   using T = DwS2;
   const int cg = (x->C + 31) / 32;
   const int th = (y->H + T::TH - 1) / T::TH, tw = (y->W + T::TW - 1) / T::TW, ntile = y->N * th * tw * cg;
   size_t lds = (size_t)(T::XPIX * 8 + 512 + 72) * 16;
-  if (lds < LHN_RESOLVE_FLOATS * 4) lds = LHN_RESOLVE_FLOATS * 4;
   static LhnKernelCfg cfg;
   if (!lhn_kernel_cfg(cfg, &k_dws2_fwd_lds, lds, 4, nullptr)) return 0;
-  hipLaunchKernelGGL(k_dws2_fwd_lds, dim3(dw3_grid(ntile, cg, 6)), dim3(256), lds, s, *x, w, *y, stats, th, tw, cg, fin, px);
+  hipLaunchKernelGGL(k_dws2_fwd_lds, dim3(dw3_grid(ntile, cg, 6)), dim3(256), lds, s, *x, w, *y, stats, th, tw, cg, fin);
   return 1;
 }
 static int dws2_bwd(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx, int dx_acc, float* dw,
@@ -1825,14 +1817,12 @@ int lhn_dwk_bwd_lds(const lhn_view* x, const float* w, const lhn_view* y, const 
 static int dw_fwd_extra(const lhn_view* x, const float* w, const lhn_view* y, double* stats, int k, int stride, int pad, int dil,
                         lhn_bnfin fin, const lhn_view* extra, const float* coef, const lhn_view* so, hipStream_t s) {
   if (!(stride == 1 && pad == dil * (k - 1) / 2 && x->C % 4 == 0 && y->W >= 8)) return 0;
-  if (!lhn_pend_ok(x) || !lhn_pend_ok(extra)) return 0;
+  if (!lhn_no_pend(x) || !lhn_no_pend(extra)) return 0;
   DwExtra ex;
   ex.v = *extra;
   ex.coef[0] = coef[0];
   ex.coef[1] = coef[1];
   ex.n = 1;
-  ex.pend[0] = lhn_pends_of(x);
-  ex.pend[1] = lhn_pends_of(extra);
   ex.sum_out = so ? so->data : nullptr;
   ex.so_cstride = so ? so->cstride : 0;
   ex.so_coff = so ? so->coff : 0;

@@ -51,7 +51,6 @@ struct PwExtra {
   lhn_view v[2];
   float coef[3];
   int n;             // number of EXTRA sources in v (0..2)
-  lhn_pends pend[3]; // BatchNorms to finalize first: [0] = x, [1..2] = v[0..1] (see lhn_pend)
   float* sum_out;    // the summed input is ALSO written here (NULL: not): training needs it once, for the weight gradient
   int so_cstride, so_coff;
 };
@@ -75,8 +74,7 @@ __global__ void __launch_bounds__(256, NS > 1 ? 1 : ((CIN == 64 && NT == 2) || (
   const int c4 = tid % C4, row0 = tid / C4;
   const bool kok = 4 * c4 < x.C;                     // channel groups beyond the view are zero columns of the tile
   const int cabs = x.coff + (kok ? 4 * c4 : 0);
-  const bool pending = ex.pend[0].n > 0 || (NS > 1 && (ex.pend[1].n > 0 || ex.pend[2].n > 0));
-  const Xf4 xf = lhn_load_xf_t(lhn_resolve_table(x, ex.pend[0], smem), x.cstride, cabs);
+  const Xf4 xf = lhn_load_xf(x, cabs);
   const int HoWo = y.H * y.W;
   // extra sources (NS > 1): own buffer, table, gate, channel offset
   int ecabs[NS > 1 ? NS - 1 : 1];
@@ -87,11 +85,9 @@ __global__ void __launch_bounds__(256, NS > 1 ? 1 : ((CIN == 64 && NT == 2) || (
     for (int e = 0; e < NS - 1; ++e)
       if (e < ex.n) {
         ecabs[e] = ex.v[e].coff + (kok ? 4 * c4 : 0);
-        if (pending) __syncthreads();               // the previous table copy has been read by everybody
-        exf[e] = lhn_load_xf_t(lhn_resolve_table(ex.v[e], ex.pend[e + 1], smem), ex.v[e].cstride, ecabs[e]);
+        exf[e] = lhn_load_xf(ex.v[e], ecabs[e]);
       }
   }
-  if (pending) __syncthreads();
   pw_stage_w<CIN>(Ws, LDA, w, 32 * NT, geo);
 
   f4 pre[PF];
@@ -250,7 +246,7 @@ static int launch_pw_fwd(const lhn_view* x, const float* w, const float* bias, c
                          int stride, float* y_nchw, int cout, const lhn_bnfin* fin, const PwGeom& geo, hipStream_t s,
                          const PwExtra* exp = nullptr) {
   PwExtra ex;
-  if (exp) ex = *exp; else { ex.n = 0; ex.pend[0].n = ex.pend[1].n = ex.pend[2].n = 0; ex.sum_out = nullptr; }
+  if (exp) ex = *exp; else { ex.n = 0; ex.sum_out = nullptr; }
   lhn_bnfin f;
   if (fin && stats) f = *fin; else f.counter = nullptr;
   const int M = y->N * y->H * y->W;
@@ -306,7 +302,6 @@ k_pw_fwd_wr(lhn_view x, const float* __restrict__ w, const float* __restrict__ b
   // ---- loader geometry
   const int c4 = tid % C4, row0 = tid / C4;
   const int cabs = x.coff + 4 * c4;
-  const bool pending = ex.pend[0].n > 0 || (NS > 1 && (ex.pend[1].n > 0 || ex.pend[2].n > 0));
   const int HoWo = y.H * y.W;
   int ecabs[NS > 1 ? NS - 1 : 1];
   if (NS > 1) {
@@ -356,16 +351,14 @@ k_pw_fwd_wr(lhn_view x, const float* __restrict__ w, const float* __restrict__ b
   double ssum = 0.0, ssq = 0.0;       // fp32 partials per tile, promoted per tile (see k_pw_fwd)
   int tile = blockIdx.x, buf = 0;
   if (tile < ntiles) issue(tile);     // the first tile's loads are in flight while pending BatchNorms are finalized
-  xf = lhn_load_xf_t(lhn_resolve_table(x, ex.pend[0], smem), x.cstride, cabs);
+  xf = lhn_load_xf(x, cabs);
   if (NS > 1) {
 #pragma unroll
     for (int e = 0; e < NS - 1; ++e)
       if (e < ex.n) {
-        if (pending) __syncthreads();
-        exf[e] = lhn_load_xf_t(lhn_resolve_table(ex.v[e], ex.pend[e + 1], smem), ex.v[e].cstride, ecabs[e]);
+        exf[e] = lhn_load_xf(ex.v[e], ecabs[e]);
       }
   }
-  if (pending) __syncthreads();               // the table copies lived in the pixel-tile buffers
   if (tile < ntiles) {
     commit(tile, smem);
     if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x);
@@ -425,7 +418,7 @@ template <int CIN, int NCOT, int NS>
 static int launch_pw_fwd_wr(const lhn_view* x, const float* w, const float* bias, const lhn_view* y, double* stats, int cout,
                             hipStream_t s, const PwExtra* exp, const PwGeom& geo, int wt = 0) {
   PwExtra ex;
-  if (exp) ex = *exp; else { ex.n = 0; ex.pend[0].n = ex.pend[1].n = ex.pend[2].n = 0; ex.sum_out = nullptr; }
+  if (exp) ex = *exp; else { ex.n = 0; ex.sum_out = nullptr; }
   constexpr int BM = 32 * (4 / NCOT);
   const int M = y->N * y->H * y->W, ntiles = (M + BM - 1) / BM;
   const size_t lds = (size_t)2 * BM * (CIN + 4) * sizeof(float);
@@ -546,18 +539,14 @@ extern "C" int lhn_conv_pw_fwd2(const lhn_view* x, const float* w, const float* 
   ex.n = 0;
   ex.sum_out = nullptr;
   ex.so_cstride = ex.so_coff = 0;
-  LHN_CHECK_ARG(lhn_pend_ok(x), "lhn_conv_pw_fwd: bad pending BatchNorm on the input view");
-  ex.pend[0] = lhn_pends_of(x);
-  ex.pend[1].n = ex.pend[2].n = 0;
-  LHN_CHECK_ARG(ex.pend[0].n == 0 || Cin <= 128, "lhn_conv_pw_fwd: a pending BatchNorm needs an unsliced input (<= 128 channels)");
+  LHN_CHECK_ARG(lhn_no_pend(x), "lhn_conv_pw_fwd: lhn_view.pend is reserved (NULL)");
   if (opts && opts->n_extra > 0) {
     LHN_CHECK_ARG(opts->n_extra <= 2 && opts->extra && single && stride == 1, "lhn_conv_pw_fwd: extra sources need stride 1 and <= 128 channels");
     ex.n = opts->n_extra;
     for (int e = 0; e < ex.n; ++e) {
       const lhn_view* v = &opts->extra[e];
-      LHN_CHECK_ARG(lhn_view_ok(v) && v->C == Cin && v->N == x->N && v->H == x->H && v->W == x->W && lhn_pend_ok(v), "lhn_conv_pw_fwd: extra source %d geometry", e);
+      LHN_CHECK_ARG(lhn_view_ok(v) && v->C == Cin && v->N == x->N && v->H == x->H && v->W == x->W && lhn_no_pend(v), "lhn_conv_pw_fwd: extra source %d geometry", e);
       ex.v[e] = *v;
-      ex.pend[e + 1] = lhn_pends_of(v);
     }
     for (int e = 0; e < 3; ++e) ex.coef[e] = opts->coef[e];
     if (opts->sum_out) {
@@ -600,7 +589,6 @@ extern "C" int lhn_conv_pw_fwd2(const lhn_view* x, const float* w, const float* 
       g.yacc = k0 > 0;
       g.statC = Cout;
       g.nchw_bstride = bstride;
-      if (co0 > 0 || k0 > 0) ex.pend[0].n = ex.pend[1].n = ex.pend[2].n = 0;      // later slices find the table in memory
       const int rc = pw_fwd_slice(&xv, w + (int64_t)co0 * wcols + k0, (last && bias) ? bias + co0 : nullptr, &yv,
                                   (last && stats) ? stats + co0 : nullptr, stride, y_nchw ? y_nchw + (int64_t)co0 * HoWo : nullptr,
                                   cc, single ? fin : nullptr, g, s, &ex);

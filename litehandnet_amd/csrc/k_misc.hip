@@ -100,7 +100,6 @@ __global__ void k_table_bias(float* __restrict__ table, int cs, int coff, int C,
 struct EwSrcs {
   lhn_view v[3];
   float coef[3];     // dst = act(sum_i coef[i] * value_i)
-  lhn_pends pend[3]; // BatchNorms to finalize first (see lhn_pend)
   int mode;          // bit 0: PRODUCT of the sources instead of their sum (lite_hrnet.py:105-107: s * interpolate(a));
                      // bit 1: smaller sources are resampled bilinearly with align_corners=True (lite_hrnet.py:272-274)
 };
@@ -133,18 +132,15 @@ __device__ __forceinline__ int nearest_src(int d, int in, int out) {
 }
 template <bool BIL>
 __global__ void __launch_bounds__(256, BIL ? 1 : 3) k_ew_fwd(EwSrcs S, int nsrc, lhn_view dst, float out_slope) {
-  __shared__ __attribute__((aligned(16))) float s_res[LHN_RESOLVE_FLOATS];
   const int C4 = dst.C >> 2, c4 = threadIdx.x % C4, pl = threadIdx.x / C4, PL = 256 / C4;
   const int rows = dst.N * dst.H;
   Xf4 xf[3];
   int ca[3];
-  const bool pending = S.pend[0].n > 0 || S.pend[1].n > 0 || S.pend[2].n > 0;
 #pragma unroll
   for (int k = 0; k < 3; ++k)
     if (k < nsrc) {
       ca[k] = S.v[k].coff + 4 * c4;
-      if (pending && k > 0) __syncthreads();       // the previous table copy has been read by everybody
-      xf[k] = lhn_load_xf_t(lhn_resolve_table(S.v[k], S.pend[k], s_res), S.v[k].cstride, ca[k]);
+      xf[k] = lhn_load_xf(S.v[k], ca[k]);
     }
   for (int row = blockIdx.x; row < rows; row += gridDim.x) {
     const int n = row / dst.H, h = row - n * dst.H;
@@ -319,11 +315,10 @@ __global__ void __launch_bounds__(256) k_ew_bwd_src(lhn_view src, lhn_view dst, 
 }
 
 // ------------------------------------------------------------------ 2x2 stride-2 max pool (ceil_mode)
-__global__ void __launch_bounds__(256) k_maxpool2_fwd(lhn_view x, lhn_view y, lhn_pends px) {
-  __shared__ __attribute__((aligned(16))) float s_res[LHN_RESOLVE_FLOATS];
+__global__ void __launch_bounds__(256) k_maxpool2_fwd(lhn_view x, lhn_view y) {
   const int C4 = y.C >> 2, c4 = threadIdx.x % C4, pl = threadIdx.x / C4, PL = 256 / C4;
   const int ca = x.coff + 4 * c4;
-  const Xf4 xf = lhn_load_xf_t(lhn_resolve_table(x, px, s_res), x.cstride, ca);
+  const Xf4 xf = lhn_load_xf(x, ca);
   const int rows = y.N * y.H;
   for (int row = blockIdx.x; row < rows; row += gridDim.x) {
     const int n = row / y.H, ho = row - n * y.H;
@@ -432,11 +427,9 @@ __device__ __forceinline__ f4 lhn_dact4(f4 raw, const Xf4& t) {      // derivati
 // pass-through half, which nobody has written yet -- this kernel reads them from `src` (pending transform and gate applied),
 // pools them AND stores them into x (each pixel by the one bin that owns it): the separate copy pass and its re-read disappear.
 template <bool STAT, bool COPY>
-__global__ void __launch_bounds__(256) k_avgpool_fwd(lhn_view x, float* __restrict__ out, int OH, int OW, lhn_pends px, int ostride,
+__global__ void __launch_bounds__(256) k_avgpool_fwd(lhn_view x, float* __restrict__ out, int OH, int OW, int ostride,
                                                      int ocoff, float* __restrict__ pstat, BnSlices sl, lhn_view src) {
   __shared__ f4 red[STAT ? 768 : 256];
-  __shared__ __attribute__((aligned(16))) float s_res[LHN_RESOLVE_FLOATS];
-  const float* xtab = lhn_resolve_table(x, px, s_res);
   const int C4 = x.C >> 2, PL = 256 / C4;
   const int b = blockIdx.x;
   const int ow = b % OW, oh = (b / OW) % OH, n = b / (OW * OH);
@@ -447,7 +440,7 @@ __global__ void __launch_bounds__(256) k_avgpool_fwd(lhn_view x, float* __restri
   const int ca = x.coff + 4 * c4;
   const bool cp = COPY && 4 * c4 < src.C;                    // this thread's channels come from src
   const int sca = src.coff + 4 * c4;
-  Xf4 xf = lhn_load_xf_t(xtab, x.cstride, ca);
+  Xf4 xf = lhn_load_xf(x, ca);
   f4 sgate = (f4){1.f, 1.f, 1.f, 1.f};
   if (cp) {
     xf = lhn_load_xf(src, sca);
@@ -784,47 +777,37 @@ __global__ void __launch_bounds__(256) k_gate_bwd_reduce(lhn_view y, const float
 // backward of the MLP; writes dpool[n][bin][cs] (already divided by the bin size) and parameter grads
 __global__ void __launch_bounds__(256) k_ca_bwd2(const float* __restrict__ w1, const float* __restrict__ w2,
                                                  const float* __restrict__ save, const float* __restrict__ dgate,
-                                                 float* __restrict__ dahat /*[N][C]*/, float* __restrict__ dw1,
-                                                 float* __restrict__ db1, float* __restrict__ dw2, float* __restrict__ db2,
-                                                 int N, int C) {
-  __shared__ float sdv[256], sdh[128], sa[256], shh[128];
-  const int Ch = C / 2;
-  for (int n = blockIdx.x; n < N; n += gridDim.x) {      // (deterministic mode: gridDim.x == 1, samples in order; see k_att_bwd2)
-  __syncthreads();
-  const float* ahat = save + (int64_t)N * C + (int64_t)n * C;
+                                                 float* __restrict__ dahat /*[N][C]*/, float* __restrict__ dvbuf /*[N][C]*/,
+                                                 float* __restrict__ dhbuf /*[N][C/2]*/, int N, int C) {
+  // One workgroup per sample: back through the sigmoid, the second 1x1, the leaky ReLU and the first 1x1.  The parameter
+  // gradients (sums over the batch of outer products) are formed by k_ca_bwd1 from the dv / dh rows stored here -- the first
+  // version added them with one float atomic per (sample, weight): a million atomics onto 16k addresses per attention.
+  __shared__ float sdv[256], sdh[128], shh[128];
+  const int Ch = C / 2, n = blockIdx.x;
   const float* h = save + (int64_t)N * C * 2 + (int64_t)n * Ch;
   const float* g = save + (int64_t)N * C * 2 + (int64_t)N * Ch + (int64_t)n * C;
-  // two blocks per sample (blockIdx.y): 0 = second layer's parameter gradients, 1 = back through it and the first layer
-  const bool second = blockIdx.y == 0;
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     const float gg = g[c];
     const float dv = dgate[(int64_t)n * C + c] * gg * (1.f - gg);
     sdv[c] = dv;
-    sa[c] = ahat[c];
-    if (second) atomicAdd(db2 + c, dv);
+    dvbuf[(int64_t)n * C + c] = dv;
   }
   for (int j = threadIdx.x; j < Ch; j += blockDim.x) shh[j] = h[j];
   __syncthreads();
-  if (second) {
-    for (int i = threadIdx.x; i < C * Ch; i += blockDim.x) atomicAdd(dw2 + i, sdv[i / Ch] * shh[i % Ch]);
-    continue;
-  }
   for (int j = threadIdx.x; j < Ch; j += blockDim.x) {
     float d = 0.f;
 #pragma unroll 8
     for (int c = 0; c < C; ++c) d += w2[c * Ch + j] * sdv[c];      // (unrolled: the loads of a mat-vec row in flight together)
     d *= shh[j] > 0.f ? 1.f : 0.01f;
     sdh[j] = d;
-    atomicAdd(db1 + j, d);
+    dhbuf[(int64_t)n * Ch + j] = d;
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < Ch * C; i += blockDim.x) atomicAdd(dw1 + i, sdh[i / C] * sa[i % C]);
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     float d = 0.f;
 #pragma unroll 8
     for (int j = 0; j < Ch; ++j) d += w1[j * C + c] * sdh[j];
     dahat[(int64_t)n * C + c] = d;
-  }
   }
 }
 // grid = C/32 blocks; thread = (channel lane, sample lane) as in k_ca1
@@ -835,7 +818,10 @@ __global__ void __launch_bounds__(1024) k_ca_bwd1(const float* __restrict__ pool
                                                  float* __restrict__ dw3, float* __restrict__ dgamma,
                                                  float* __restrict__ dbeta, int N, int C, int training, int stage,
                                                  double* __restrict__ gsum, double count_scale, float pgrad_scale,
-                                                 const float* __restrict__ tsum, const float* __restrict__ pstat, BnSlices sl) {
+                                                 const float* __restrict__ tsum, const float* __restrict__ pstat, BnSlices sl,
+                                                 const float* __restrict__ dvbuf, const float* __restrict__ dhbuf,
+                                                 float* __restrict__ dw1, float* __restrict__ db1, float* __restrict__ dw2,
+                                                 float* __restrict__ db2) {
   // stage 0: everything; SyncBatchNorm: stage 1 = local (sum d, sum d*xhat) -> gsum[2][C], all-reduce, stage 2 = the rest
   __shared__ double rs[32][32], rq[32][32];
   __shared__ float rw[32][32][9];
@@ -949,6 +935,38 @@ __global__ void __launch_bounds__(1024) k_ca_bwd1(const float* __restrict__ pool
       for (int j = 0; j < NL; ++j) v += rw[j][cl][t];
       dw3[c * 9 + t] += v;
     }
+  }
+  // ---- parameter gradients of the two 1x1 layers: sums over the batch of the rows k_ca_bwd2 stored (this block owns the 32
+  // channels [32 blockIdx.x, +32): one writer per element, samples added in order -- deterministic, no atomics)
+  {
+    const int Ch = C / 2, c0 = blockIdx.x * 32, nc = min(32, C - c0);
+    const float* ahat = save + (int64_t)N * C;
+    const float* hh = save + (int64_t)N * C * 2;
+    for (int o = threadIdx.x; o < nc * Ch; o += blockDim.x) {           // dW2[c][j] = sum_n dv[n][c] * h[n][j]
+      const int cc = o / Ch, j = o - cc * Ch;
+      float v = 0.f;
+#pragma unroll 8
+      for (int n = 0; n < N; ++n) v += dvbuf[(int64_t)n * C + c0 + cc] * hh[(int64_t)n * Ch + j];
+      dw2[(int64_t)(c0 + cc) * Ch + j] += v;
+    }
+    for (int o = threadIdx.x; o < Ch * nc; o += blockDim.x) {           // dW1[j][c] = sum_n dh[n][j] * ahat[n][c]
+      const int j = o / nc, cc = o - j * nc;
+      float v = 0.f;
+#pragma unroll 8
+      for (int n = 0; n < N; ++n) v += dhbuf[(int64_t)n * Ch + j] * ahat[(int64_t)n * C + c0 + cc];
+      dw1[(int64_t)j * C + c0 + cc] += v;
+    }
+    if ((int)threadIdx.x < nc) {                                          // db2[c] = sum_n dv[n][c]
+      float v = 0.f;
+      for (int n = 0; n < N; ++n) v += dvbuf[(int64_t)n * C + c0 + threadIdx.x];
+      db2[c0 + threadIdx.x] += v;
+    }
+    if (blockIdx.x == 0)
+      for (int j = threadIdx.x; j < Ch; j += blockDim.x) {               // db1[j] = sum_n dh[n][j]
+        float v = 0.f;
+        for (int n = 0; n < N; ++n) v += dhbuf[(int64_t)n * Ch + j];
+        db1[j] += v;
+      }
   }
 }
 
@@ -1144,10 +1162,9 @@ int lhn_ew_fwd3(const lhn_view* srcs, int nsrc, const float* coef, const lhn_vie
   memset(&S, 0, sizeof(S));
   S.mode = mode;
   for (int i = 0; i < nsrc; ++i) {
-    LHN_CHECK_ARG(lhn_view_ok(&srcs[i]) && srcs[i].C == dst->C && srcs[i].N == dst->N && lhn_pend_ok(&srcs[i]), "lhn_ew_fwd: source %d mismatch", i);
+    LHN_CHECK_ARG(lhn_view_ok(&srcs[i]) && srcs[i].C == dst->C && srcs[i].N == dst->N && lhn_no_pend(&srcs[i]), "lhn_ew_fwd: source %d mismatch", i);
     S.v[i] = srcs[i];
     S.coef[i] = coef ? coef[i] : 1.f;
-    S.pend[i] = lhn_pends_of(&srcs[i]);
   }
   LHN_CHECK_ARG(dst->C % 4 == 0 && dst->C <= 1024, "lhn_ew_fwd: C=%d", dst->C);
   if (S.mode & 2)
@@ -1210,8 +1227,8 @@ int lhn_maxpool2_fwd(const lhn_view* x, const lhn_view* y, void* stream) {
   LHN_CHECK_ARG(lhn_view_ok(x) && lhn_view_ok(y) && x->C == y->C, "lhn_maxpool2_fwd: bad views");
   LHN_CHECK_ARG(y->H == (x->H + 1) / 2 && y->W == (x->W + 1) / 2 && y->N == x->N, "lhn_maxpool2_fwd: geometry");
   LHN_CHECK_ARG(y->C % 4 == 0 && y->C <= 1024, "lhn_maxpool2_fwd: C=%d", y->C);
-  LHN_CHECK_ARG(lhn_pend_ok(x), "lhn_maxpool2_fwd: bad pending BatchNorm");
-  hipLaunchKernelGGL(k_maxpool2_fwd, dim3(grid_cap((int64_t)y->N * y->H, 8)), dim3(256), 0, (hipStream_t)stream, *x, *y, lhn_pends_of(x));
+  LHN_CHECK_ARG(lhn_no_pend(x), "lhn_maxpool2_fwd: lhn_view.pend is reserved (NULL)");
+  hipLaunchKernelGGL(k_maxpool2_fwd, dim3(grid_cap((int64_t)y->N * y->H, 8)), dim3(256), 0, (hipStream_t)stream, *x, *y);
   LHN_CHECK_LAUNCH("lhn_maxpool2_fwd");
   return 0;
 }
@@ -1237,9 +1254,9 @@ int lhn_avgpool_fwd2(const lhn_view* x, float* out, int OH, int OW, int out_cstr
                     out_coff + x->C <= out_cstride,
                 "lhn_avgpool_fwd: bad args");
   LHN_CHECK_ARG(x->C % 4 == 0 && x->C <= 1024, "lhn_avgpool_fwd: C=%d", x->C);
-  LHN_CHECK_ARG(lhn_pend_ok(x), "lhn_avgpool_fwd: bad pending BatchNorm");
+  LHN_CHECK_ARG(lhn_no_pend(x), "lhn_avgpool_fwd: lhn_view.pend is reserved (NULL)");
   const int binmax = ((x->H + OH - 1) / OH + 1) * ((x->W + OW - 1) / OW + 1);
-  if (!x->pend && binmax <= 25) {          // bins of at most 4x4 (+1: adaptive bins may overlap by a pixel)
+  if (binmax <= 25) {          // bins of at most 4x4 (+1: adaptive bins may overlap by a pixel)
     const int64_t total = (int64_t)x->N * OH * OW * (x->C / 4);
     hipLaunchKernelGGL(k_avgpool_small, dim3(grid_cap((total + 255) / 256, 16)), dim3(256), 0, (hipStream_t)stream, *x, out, OH, OW, out_cstride, out_coff);
   } else
@@ -1248,7 +1265,7 @@ int lhn_avgpool_fwd2(const lhn_view* x, float* out, int OH, int OW, int out_cstr
     memset(&sl, 0, sizeof(sl));
     lhn_view nosrc;
     memset(&nosrc, 0, sizeof(nosrc));
-    hipLaunchKernelGGL((k_avgpool_fwd<false, false>), dim3(x->N * OH * OW), dim3(256), 0, (hipStream_t)stream, *x, out, OH, OW, lhn_pends_of(x), out_cstride, out_coff,
+    hipLaunchKernelGGL((k_avgpool_fwd<false, false>), dim3(x->N * OH * OW), dim3(256), 0, (hipStream_t)stream, *x, out, OH, OW, out_cstride, out_coff,
                        (float*)nullptr, sl, nosrc);
   }
   LHN_CHECK_LAUNCH("lhn_avgpool_fwd");
@@ -1287,9 +1304,9 @@ int lhn_avgpool_fwd4(const lhn_view* x, float* out, int OH, int OW, float* pstat
   if (copy_src) src = *copy_src;
   const dim3 g(x->N * OH * OW), bk(256);
   hipStream_t s = (hipStream_t)stream;
-  if (pstat && copy_src) hipLaunchKernelGGL((k_avgpool_fwd<true, true>), g, bk, 0, s, *x, out, OH, OW, lhn_pends_of(x), x->C, 0, pstat, sl, src);
-  else if (pstat) hipLaunchKernelGGL((k_avgpool_fwd<true, false>), g, bk, 0, s, *x, out, OH, OW, lhn_pends_of(x), x->C, 0, pstat, sl, src);
-  else hipLaunchKernelGGL((k_avgpool_fwd<false, true>), g, bk, 0, s, *x, out, OH, OW, lhn_pends_of(x), x->C, 0, pstat, sl, src);
+  if (pstat && copy_src) hipLaunchKernelGGL((k_avgpool_fwd<true, true>), g, bk, 0, s, *x, out, OH, OW, x->C, 0, pstat, sl, src);
+  else if (pstat) hipLaunchKernelGGL((k_avgpool_fwd<true, false>), g, bk, 0, s, *x, out, OH, OW, x->C, 0, pstat, sl, src);
+  else hipLaunchKernelGGL((k_avgpool_fwd<false, true>), g, bk, 0, s, *x, out, OH, OW, x->C, 0, pstat, sl, src);
   LHN_CHECK_LAUNCH("lhn_avgpool_fwd4");
   return 0;
 }
@@ -1372,10 +1389,13 @@ int lhn_ca_mlp_bwd2(const float* pooled, const float* w3, const float* gamma, co
                 "lhn_ca_mlp_bwd: null pointer");
   LHN_CHECK_ARG(C > 0 && C <= 256 && C % 2 == 0, "lhn_ca_mlp_bwd: C=%d", C);
   hipStream_t s = (hipStream_t)stream;
+  // scratch behind the forward's save area: dahat [N][C] | dv [N][C] | dh [N][C/2]  (save holds 6 N C + 2 C floats in all)
   float* dahat = const_cast<float*>(save) + (int64_t)N * C * 3 + (int64_t)N * (C / 2) + 2 * C;
+  float* dvbuf = dahat + (int64_t)N * C;
+  float* dhbuf = dvbuf + (int64_t)N * C;
   LHN_CHECK_ARG(stage == 0 || (gsum && stage >= 1 && stage <= 2 && count_scale >= 1), "lhn_ca_mlp_bwd: stage %d needs gsum", stage);
-  if (stage != 2) hipLaunchKernelGGL(k_ca_bwd2, dim3(lhn_deterministic_mode() ? 1 : N, 2), dim3(256), 0, s, w1, w2, save, dgate, dahat, dw1, db1, dw2, db2, N, C);
-  hipLaunchKernelGGL(k_ca_bwd1, dim3((C + 31) / 32), dim3(1024), 0, s, pooled, w3, gamma, dropmask, save, dahat, dpool, cstride, coff, H, W, dw3, dgamma, dbeta, N, C, 1, stage, gsum, stage ? count_scale : 1.0, stage ? pgrad_scale : 1.f, tsum, pstat, sl);
+  if (stage != 2) hipLaunchKernelGGL(k_ca_bwd2, dim3(N), dim3(256), 0, s, w1, w2, save, dgate, dahat, dvbuf, dhbuf, N, C);
+  hipLaunchKernelGGL(k_ca_bwd1, dim3((C + 31) / 32), dim3(1024), 0, s, pooled, w3, gamma, dropmask, save, dahat, dpool, cstride, coff, H, W, dw3, dgamma, dbeta, N, C, 1, stage, gsum, stage ? count_scale : 1.0, stage ? pgrad_scale : 1.f, tsum, pstat, sl, dvbuf, dhbuf, dw1, db1, dw2, db2);
   LHN_CHECK_LAUNCH("lhn_ca_mlp_bwd");
   return 0;
 }

@@ -33,22 +33,8 @@ void lhn_set_error(const char* fmt, ...);
     }                                                                             \
   } while (0)
 
-// entry points that cannot finalize a pending BatchNorm must not be handed one
-static inline int lhn_no_pend(const lhn_view* v) { return !v || !v->pend || v->pend->n == 0; }
-static inline int lhn_pend_ok(const lhn_view* v) {      // what lhn_resolve_table handles
-  if (!v || !v->pend || v->pend->n == 0) return 1;
-  if (v->pend->n < 0 || v->pend->n > 2 || v->cstride > 256 || !v->table) return 0;
-  for (int k = 0; k < v->pend->n; ++k) {
-    const lhn_pend& p = v->pend->p[k];
-    if (!p.stats || p.C <= 0 || p.C > 128 || p.coff < 0 || p.coff + p.C > v->cstride || p.count < 1) return 0;
-  }
-  return 1;
-}
-static inline lhn_pends lhn_pends_of(const lhn_view* v) {
-  lhn_pends p;
-  if (v && v->pend) p = *v->pend; else p.n = 0;
-  return p;
-}
+// lhn_view.pend is reserved (round 2's deferred BatchNorm finalize, removed): every entry point wants NULL
+static inline int lhn_no_pend(const lhn_view* v) { return !v || !v->pend; }
 
 static inline int lhn_view_ok(const lhn_view* v) {
   return v && v->data && v->N > 0 && v->H > 0 && v->W > 0 && v->C > 0 && v->coff >= 0 &&
@@ -335,90 +321,7 @@ __device__ __forceinline__ void lhn_block_stat_atomics(f4 s, f4 q, int C4, f4* r
   }
 }
 
-// ---- pending BatchNorms (lhn_pend): called by EVERY thread of the block at kernel start, before the first lhn_load_xf of
-// the view.  scratch: >= LHN_RESOLVE_FLOATS floats of LDS that nothing else uses until the caller's next __syncthreads()
-// after its table loads.  On return v.table points at the block's private LDS copy [3][cstride] with the pending slices
-// filled in; block (0,0,0) has also written them to memory together with the BatchNorm's state.
-#define LHN_RESOLVE_FLOATS (3 * 256 + 2 * 2 * 256)      /* table for cstride <= 256 + double partials [g][2][C] (g*C <= 128) of two slices */
-// Two phases, two barriers: (A) every thread issues its share of ALL global loads at once -- the table copy and, per
-// pending slice, the replicated sums of its (channel, replica group) -- and parks partial sums in LDS; (B) one thread per
-// channel folds the groups, computes (scale, shift) and fills the LDS table.  The latency is one round of L2 loads plus the
-// double-precision divide / sqrt (the first version walked through four dependent phases and cost as much as the launch
-// it replaced).
-__device__ __forceinline__ void lhn_resolve_A(const lhn_pend& p, double* part) {
-  const int C = p.C, nt = blockDim.x;
-  int ng = 128 / C;                         // replica groups summed in parallel; ng * C <= 128 (the partials' LDS budget)
-  ng = ng < 1 ? 1 : (ng > 8 ? 8 : ng);
-  for (int t = threadIdx.x; t < ng * C; t += nt) {
-    const int c = t % C, g = t / C;
-    double s1 = 0, s2 = 0;
-    for (int r = g; r < LHN_STAT_REPLICAS; r += ng) {
-      s1 += p.stats[(size_t)r * 2 * C + c];
-      s2 += p.stats[(size_t)r * 2 * C + C + c];
-    }
-    part[(g * 2 + 0) * C + c] = s1;
-    part[(g * 2 + 1) * C + c] = s2;
-  }
-}
-__device__ __forceinline__ void lhn_resolve_B(const lhn_pend& p, float* tab, const double* part, float* gtab, int cs, bool first) {
-  const int C = p.C, nt = blockDim.x;
-  int ng = 128 / C;
-  ng = ng < 1 ? 1 : (ng > 8 ? 8 : ng);
-  for (int c = threadIdx.x; c < C; c += nt) {
-    double s1 = 0, s2 = 0;
-    for (int g = 0; g < ng; ++g) {
-      s1 += part[(g * 2 + 0) * C + c];
-      s2 += part[(g * 2 + 1) * C + c];
-    }
-    const double mean = s1 / p.count;
-    double var = s2 / p.count - mean * mean;
-    if (var < 0) var = 0;
-    const float invstd = (float)(1.0 / sqrt(var + (double)p.eps));
-    const float gm = p.gamma ? p.gamma[c] : 1.f, bt = p.beta ? p.beta[c] : 0.f;
-    const float sc = gm * invstd, sh = bt - (float)mean * sc;
-    tab[p.coff + c] = sc;
-    tab[cs + p.coff + c] = sh;
-    tab[2 * cs + p.coff + c] = p.slope;
-    if (first) {
-      gtab[p.coff + c] = sc;
-      gtab[cs + p.coff + c] = sh;
-      gtab[2 * cs + p.coff + c] = p.slope;
-      if (p.running_mean) {
-        const double bm = mean + (p.conv_bias ? (double)p.conv_bias[c] : 0.0);
-        p.running_mean[c] = (float)((1.0 - (double)p.momentum) * (double)p.running_mean[c] + (double)p.momentum * bm);
-        const double unb = p.count > 1 ? var * p.count / (p.count - 1.0) : var;
-        p.running_var[c] = (float)((1.0 - (double)p.momentum) * (double)p.running_var[c] + (double)p.momentum * unb);
-      }
-      if (p.save_mean_invstd) {
-        p.save_mean_invstd[c] = (float)mean;
-        p.save_mean_invstd[C + c] = invstd;
-      }
-    }
-  }
-  if (first && threadIdx.x == 0 && p.num_batches_tracked) p.num_batches_tracked[0] += 1;
-}
-// Returns the table to read the view's pending transform from: v.table when nothing is pending, else the block's LDS copy.
-// (Nothing here writes to a kernel argument or indexes one dynamically: either would push the argument struct into
-// scratch memory.)  The caller needs a __syncthreads() between its last read of the returned table and its next use of
-// `scratch`.
-__device__ __forceinline__ const float* lhn_resolve_table(const lhn_view& v, const lhn_pends& P, float* scratch) {
-  if (P.n == 0) return v.table;               // block-uniform
-  const int cs = v.cstride;
-  float* tab = scratch;
-  double* part0 = reinterpret_cast<double*>(scratch + 3 * 256);
-  double* part1 = part0 + 256;
-  float* gtab = const_cast<float*>(v.table);
-  const bool first = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
-  for (int i = threadIdx.x; i < 3 * cs; i += blockDim.x) tab[i] = gtab[i];
-  lhn_resolve_A(P.p[0], part0);
-  if (P.n > 1) lhn_resolve_A(P.p[1], part1);
-  __syncthreads();
-  lhn_resolve_B(P.p[0], tab, part0, gtab, cs, first);
-  if (P.n > 1) lhn_resolve_B(P.p[1], tab, part1, gtab, cs, first);
-  __syncthreads();
-  return tab;
-}
-// lhn_load_xf from an explicit table pointer (global or the LDS copy above); tab == NULL = identity
+// lhn_load_xf from an explicit table pointer; tab == NULL = identity
 __device__ __forceinline__ Xf4 lhn_load_xf_t(const float* tab, int cstride, int c_abs) {
   Xf4 t;
   if (tab) {

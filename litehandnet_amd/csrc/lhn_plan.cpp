@@ -51,7 +51,7 @@ static inline char* at(void* ws, int64_t off) { return off < 0 ? nullptr : stati
 static lhn_view mkview(const Plan* P, void* ws, int buf, int coff, int C, bool with_gate = true) {
   const lhn_buf& b = P->bufs[buf];
   lhn_view v;
-  v.pend = nullptr;
+  v.pend = nullptr;      // (reserved)
   v.data = reinterpret_cast<float*>(at(ws, b.data_off));
   v.table = reinterpret_cast<const float*>(at(ws, b.table_off));
   v.gate = with_gate ? reinterpret_cast<const float*>(at(ws, b.gate_off)) : nullptr;
@@ -130,26 +130,6 @@ static int sep_finalize(const lhn_bnfin& f, const double* stats, int training, v
   return rc;
 }
 
-// Deferred BatchNorm finalize (see lhn_pend): in a plain training run a convolution flagged i[7] leaves its statistics to
-// the first reader of its output, whose op lists it in pend[slot][]; eval / SyncBatchNorm / fused-finalize runs keep the
-// separate launch.
-static void mkpends(const Plan* P, void* ws, const std::vector<lhn_op>& ops, const lhn_op& o, int slot, void* const* params,
-                    double cscale, lhn_pends* out) {
-  out->n = 0;
-  for (int k = 0; k < 2; ++k) {
-    const int pi = o.pend[slot][k];
-    if (pi < 0) continue;
-    const lhn_op& po = ops[pi];
-    const lhn_bnfin f = mkfin(P, ws, po, params);
-    lhn_pend& p = out->p[out->n++];
-    p.stats = reinterpret_cast<const double*>(at(ws, po.ws[0]));
-    p.gamma = f.gamma; p.beta = f.beta; p.running_mean = f.running_mean; p.running_var = f.running_var;
-    p.num_batches_tracked = f.num_batches_tracked; p.save_mean_invstd = f.save_mean_invstd; p.conv_bias = f.conv_bias;
-    p.count = f.count * cscale; p.eps = f.eps; p.momentum = f.momentum; p.slope = f.slope;
-    p.coff = f.coff; p.C = f.C;
-  }
-}
-
 extern "C" {
 
 void* lhn_plan_create(const lhn_buf* bufs, int nbufs, const lhn_op* fwd, int nfwd, const lhn_op* bwd, int nbwd) {
@@ -198,21 +178,9 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
   hipStream_t s = static_cast<hipStream_t>(stream);
   int rc = 0;
   const bool whole = (sb == 0 && se >= 2 * ops.size());
-  const bool defer_ok = training && whole && phase == 0 && !fuse_finalize();     // consumers finalize flagged BatchNorms
-  lhn_pends pd[3];
   for (size_t oi = 0; oi < ops.size() && rc == 0; ++oi) {
     const lhn_op& o = ops[oi];
-    const bool deferred = defer_ok && o.i[7] == 1 && (o.kind == OP_STEM || o.kind == OP_PW || o.kind == OP_DW || o.kind == OP_KXK);
-    bool has_pend = false;
-    if (defer_ok && phase == 0)
-      for (int k = 0; k < 3; ++k) {
-        pd[k].n = 0;
-        if (o.pend[k][0] >= 0 || o.pend[k][1] >= 0) {
-          mkpends(P, ws, ops, o, k, params, cscale, &pd[k]);
-          has_pend = true;
-        }
-      }
-    (void)has_pend;
+    const bool deferred = false;      // (round 2's deferred finalize is gone: every BatchNorm has its finalize launch)
     const bool h0 = 2 * oi >= sb && 2 * oi < se, h1 = 2 * oi + 1 >= sb && 2 * oi + 1 < se;
     if (!h0 && !h1) continue;
     const bool two_half = o.kind == OP_STEM || o.kind == OP_PW || o.kind == OP_DW || o.kind == OP_KXK || o.kind == OP_CA_MLP ||
@@ -252,7 +220,6 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
       }
       case OP_PW: {
         lhn_view x = mkview(P, ws, o.in_buf[0], o.in_coff[0], o.in_C[0]);
-        if (has_pend && pd[0].n) x.pend = &pd[0];
         lhn_view y;
         float* nchw = nullptr;
         if (o.i[1]) {  // NCHW head: geometry from the input, channels from out_C
@@ -279,7 +246,6 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
           po.n_extra = o.i[6] - 1;
           for (int e = 0; e < po.n_extra; ++e) {
             extra[e] = mkview(P, ws, o.in_buf[e + 1], o.in_coff[e + 1], o.in_C[e + 1]);
-            if (has_pend && pd[e + 1].n) extra[e].pend = &pd[e + 1];
           }
           po.extra = extra;
           for (int e = 0; e < 3; ++e) po.coef[e] = o.f[4 + e];
@@ -308,7 +274,6 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
       }
       case OP_DW: {
         lhn_view x = mkview(P, ws, o.in_buf[0], o.in_coff[0], o.in_C[0]);
-        if (has_pend && pd[0].n) x.pend = &pd[0];
         lhn_view y = mkview(P, ws, o.out_buf, o.out_coff, o.out_C);
         const bool bn = conv_has_bn(o);
         lhn_bnfin fin;
@@ -320,7 +285,6 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
         const float coef2[2] = {o.f[4], o.f[5]};
         if (o.i[6] > 1) {                                                                 // second source summed on load
           extra = mkview(P, ws, o.in_buf[1], o.in_coff[1], o.in_C[1]);
-          if (has_pend && pd[1].n) extra.pend = &pd[1];
         }
         lhn_view sumv;           // ws[4], ws[5]: see OP_PW
         const bool so = o.i[6] > 1 && o.ws[4] >= 0;
@@ -370,7 +334,6 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
         lhn_view srcs[3];
         for (int k = 0; k < o.i[0]; ++k) {
           srcs[k] = mkview(P, ws, o.in_buf[k], o.in_coff[k], o.in_C[k]);
-          if (has_pend && pd[k].n) srcs[k].pend = &pd[k];
         }
         lhn_view d = mkview(P, ws, o.out_buf, o.out_coff, o.out_C);
         const float coef[3] = {o.f[4], o.f[5], o.f[6]};
@@ -379,7 +342,6 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
       }
       case OP_MAXPOOL: {
         lhn_view x = mkview(P, ws, o.in_buf[0], o.in_coff[0], o.in_C[0]);
-        if (has_pend && pd[0].n) x.pend = &pd[0];
         lhn_view y = mkview(P, ws, o.out_buf, o.out_coff, o.out_C);
         rc = lhn_maxpool2_fwd(&x, &y, stream);
         break;
@@ -393,7 +355,6 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
       }
       case OP_AVGPOOL: {
         lhn_view x = mkview(P, ws, o.in_buf[0], o.in_coff[0], o.in_C[0], o.i[2] == 0);
-        if (has_pend && pd[0].n) x.pend = &pd[0];
         if (o.ws[1] >= 0 || o.in_buf[1] >= 0) {
           // channel attention: ws[1] = pooling statistics its backward assembles BatchNorm sums from (training plans);
           // in_buf[1] = the pass-through half of a gated unit, copied into the pooled buffer by this launch

@@ -387,7 +387,7 @@ class PlanBuilder:
         assert not b.gate, "buffer is already gated"
         Cc = y.C
         pooled = self._ws("misc", self.N * 9 * Cc * 4)
-        save = self._ws("misc", (5 * self.N * Cc + self.N * (Cc // 2) + 2 * Cc) * 4)
+        save = self._ws("misc", (6 * self.N * Cc + 2 * Cc) * 4)          # forward rows + backward scratch (lhn_ca_mlp_bwd)
         mask = self._ws("mask", self.N * Cc * 4) if self.p_drop > 0 else None
         rec = dict(op=CA_MLP, y=y, ca=ca, pooled=pooled, save=save, mask=mask, gsum=self._ws("misc", 2 * Cc * 8))
         # gated RepBasicUnit: the copy of the pass-through half into this buffer rides in the attention's pooling launch
@@ -521,8 +521,6 @@ class PlanBuilder:
             o.i[k] = i[k] if k < len(i) else 0
         for k in range(8):
             o.f[k] = f[k] if k < len(f) else 0.0
-        for k in range(3):
-            o.pend[k][0] = o.pend[k][1] = -1
         return o
 
     def _xs(self, r):
