@@ -1223,7 +1223,7 @@ __global__ void __launch_bounds__(256) k_dwk_fwd_lds(lhn_view x, const float* __
     const int C = x.C;
     double* st = stats + (size_t)((bid / cgroups) % LHN_STAT_REPLICAS) * 2 * C + cg * 32;
     lhn_block_stat_atomics_d(sd, qd, 8, reinterpret_cast<double*>(red), st, st + C, cvalid);
-    if (fin.counter && lhn_last_block(fin.counter)) lhn_bn_finalize_block(fin, stats);
+    if (fin.counter && lhn_last_block(fin.counter)) lhn_bn_finalize_block_par(fin, stats, reinterpret_cast<double*>(red));
   }
 }
 

@@ -237,7 +237,7 @@ __global__ void __launch_bounds__(256, NS > 1 ? 1 : ((CIN == 64 && NT == 2) || (
       atomicAdd(st + tid, s);
       atomicAdd(st + geo.statC + tid, q);
     }
-    if (fin.counter && lhn_last_block(fin.counter)) lhn_bn_finalize_block(fin, stats);
+    if (fin.counter && lhn_last_block(fin.counter)) lhn_bn_finalize_block_par(fin, stats, redd);
   }
 }
 
@@ -276,7 +276,7 @@ static int launch_pw_fwd(const lhn_view* x, const float* w, const float* bias, c
 template <int CIN, int NCOT, int NS>
 __global__ void __launch_bounds__(256, (NS > 1 || CIN >= 128) ? 2 : 3)
 k_pw_fwd_wr(lhn_view x, const float* __restrict__ w, const float* __restrict__ bias, lhn_view y, double* __restrict__ stats,
-            int cout, int M, int ntiles, PwExtra ex, int wstride, int yacc, int statC, int wt) {
+            int cout, int M, int ntiles, PwExtra ex, int wstride, int yacc, int statC, int wt, lhn_bnfin fin) {
   constexpr int LDA = CIN + 4, PXW = 4 / NCOT, BM = 32 * PXW;
   constexpr int C4 = CIN / 4, RP = 256 / C4, PF = BM / RP;      // float4 loads per thread, tile and source
   static_assert(PF >= 1, "tile too small for the loader");
@@ -412,11 +412,13 @@ k_pw_fwd_wr(lhn_view x, const float* __restrict__ w, const float* __restrict__ b
       atomicAdd(st + statC + co, q);
     }
   }
+  // fused BatchNorm finalize (single-launch convolutions only, see pw_fwd_slice): the pixel tiles in LDS are dead by now
+  if (stats && fin.counter && lhn_last_block(fin.counter)) lhn_bn_finalize_block_par(fin, stats, reinterpret_cast<double*>(smem));
 }
 
 template <int CIN, int NCOT, int NS>
 static int launch_pw_fwd_wr(const lhn_view* x, const float* w, const float* bias, const lhn_view* y, double* stats, int cout,
-                            hipStream_t s, const PwExtra* exp, const PwGeom& geo, int wt = 0) {
+                            hipStream_t s, const PwExtra* exp, const PwGeom& geo, int wt = 0, const lhn_bnfin* finp = nullptr) {
   PwExtra ex;
   if (exp) ex = *exp; else { ex.n = 0; ex.sum_out = nullptr; }
   constexpr int BM = 32 * (4 / NCOT);
@@ -430,14 +432,16 @@ static int launch_pw_fwd_wr(const lhn_view* x, const float* w, const float* bias
   }
   int grid = lhn_num_cus() * per_cu;      // (2 / 4 / 8 / 16 blocks per CU measured in round 3: forward 2.71 / 2.69 / 2.74 / 2.83 ms)
   if (grid > ntiles) grid = ntiles;
+  lhn_bnfin fin;
+  if (finp) fin = *finp; else fin.counter = nullptr;
   hipLaunchKernelGGL((k_pw_fwd_wr<CIN, NCOT, NS>), dim3(grid), dim3(256), lds, s, *x, w, bias, *y, stats, cout, M, ntiles, ex, geo.wstride,
-                     geo.yacc, geo.statC, wt);
+                     geo.yacc, geo.statC, wt, fin);
   return 0;
 }
 
 // returns -1 when the register-resident-weights kernel has no instance for the shape
 static int pw_fwd_wr(const lhn_view* x, const float* w, const float* bias, const lhn_view* y, double* stats, int cout, hipStream_t s,
-                     const PwExtra* ex, const PwGeom& geo, int wt = 0) {
+                     const PwExtra* ex, const PwGeom& geo, int wt = 0, const lhn_bnfin* fin = nullptr) {
   static int off = -1;
   if (off < 0) {
     const char* e = getenv("LHN_PW_LDSW");      // 1 = always take the LDS-resident-W kernel (A/B comparisons)
@@ -449,15 +453,15 @@ static int pw_fwd_wr(const lhn_view* x, const float* w, const float* bias, const
   // K = 256 (hourglassnet.py: every 1x1 of the C = 256 residuals) in ONE pass: 128 VGPRs of W per lane, no second K slice that
   // re-reads and re-writes y
   if (ci == 256 && !ms) {
-    if (ncot == 4) return launch_pw_fwd_wr<256, 4, 1>(x, w, bias, y, stats, cout, s, ex, geo, wt);
+    if (ncot == 4) return launch_pw_fwd_wr<256, 4, 1>(x, w, bias, y, stats, cout, s, ex, geo, wt, fin);
     return -1;      // (64 features per block would need 64-pixel tiles: 256 VGPRs and spills)
   }
   if (ms) {
-    if (ci == 128 && ncot == 4) return launch_pw_fwd_wr<128, 4, 3>(x, w, bias, y, stats, cout, s, ex, geo);
-    if (ci == 64 && ncot == 2) return launch_pw_fwd_wr<64, 2, 3>(x, w, bias, y, stats, cout, s, ex, geo);
+    if (ci == 128 && ncot == 4) return launch_pw_fwd_wr<128, 4, 3>(x, w, bias, y, stats, cout, s, ex, geo, 0, fin);
+    if (ci == 64 && ncot == 2) return launch_pw_fwd_wr<64, 2, 3>(x, w, bias, y, stats, cout, s, ex, geo, 0, fin);
     return -1;
   }
-#define WR(CI, NC) if (ci == CI && ncot == NC) return launch_pw_fwd_wr<CI, NC, 1>(x, w, bias, y, stats, cout, s, ex, geo, wt);
+#define WR(CI, NC) if (ci == CI && ncot == NC) return launch_pw_fwd_wr<CI, NC, 1>(x, w, bias, y, stats, cout, s, ex, geo, wt, fin);
   WR(128, 4) WR(128, 2) WR(64, 4) WR(64, 2) WR(64, 1) WR(32, 4) WR(32, 2) WR(32, 1)
 #undef WR
   return -1;
@@ -491,12 +495,12 @@ static int pw_fwd_slice(const lhn_view* x, const float* w, const float* bias, co
                         float* y_nchw, int cout, const lhn_bnfin* fin, const PwGeom& geo, hipStream_t s, const PwExtra* ex = nullptr) {
   const int ci = x->C == 256 ? 256 : pw_cin_tile(x->C), nt = (cout + 31) / 32 == 3 ? 4 : (cout + 31) / 32;
   int rc = -1;
-  // fast path: whole-K slice with full-width rows, plain NHWC store, no fused finalize
+  // fast path: whole-K slice with full-width rows, plain NHWC store (a fused finalize only when this launch is the whole conv)
   // (slices of a C = 256 convolution qualify too: the kernel takes the whole weight's row stride, accumulates later K slices
   // into y and addresses the statistics of the whole BatchNorm)
   if (stride == 1 && !y_nchw && x->C == ci && geo.kvalid == ci && geo.wstride % 4 == 0 && geo.wrows == cout &&
-      !(geo.yacc && ex && ex->n > 0) && !(fin && stats) && (reinterpret_cast<uintptr_t>(w) & 15) == 0) {
-    rc = pw_fwd_wr(x, w, bias, y, stats, cout, s, ex, geo);
+      !(geo.yacc && ex && ex->n > 0) && !(fin && stats && (geo.yacc || geo.statC != cout)) && (reinterpret_cast<uintptr_t>(w) & 15) == 0) {
+    rc = pw_fwd_wr(x, w, bias, y, stats, cout, s, ex, geo, 0, stats ? fin : nullptr);
     if (rc != -1) return rc;
   }
   if (ex && ex->n > 0) {      // summed-on-load sources: the square 1x1 of MSRB (litehourglass.py:30,49), C = 64 / 128

@@ -823,6 +823,41 @@ __global__ void __launch_bounds__(1024) k_ca_bwd1(const float* __restrict__ pool
                                                  float* __restrict__ dw1, float* __restrict__ db1, float* __restrict__ dw2,
                                                  float* __restrict__ db2) {
   // stage 0: everything; SyncBatchNorm: stage 1 = local (sum d, sum d*xhat) -> gsum[2][C], all-reduce, stage 2 = the rest
+  const int nmain = (C + 31) / 32;
+  if ((int)blockIdx.x >= nmain) {
+    // ---- extra workgroups, beside the ones below: parameter gradients of the two 1x1 layers = sums over the batch of the rows
+    // k_ca_bwd2 stored.  One thread per weight, samples added in order: one writer per element, no atomics, deterministic.
+    if (stage == 1) return;
+    const int Ch = C / 2, o = ((int)blockIdx.x - nmain) * blockDim.x + threadIdx.x, nw = C * Ch;
+    const float* ahat = save + (int64_t)N * C;
+    const float* hh = save + (int64_t)N * C * 2;
+    if (o < nw) {                                                         // dW2[c][j] = sum_n dv[n][c] * h[n][j]
+      const int cc = o / Ch, j = o - cc * Ch;
+      float v = 0.f;
+#pragma unroll 8
+      for (int n = 0; n < N; ++n) v += dvbuf[(int64_t)n * C + cc] * hh[(int64_t)n * Ch + j];
+      dw2[o] += v;
+    } else if (o < 2 * nw) {                                              // dW1[j][c] = sum_n dh[n][j] * ahat[n][c]
+      const int q = o - nw, j = q / C, cc = q - j * C;
+      float v = 0.f;
+#pragma unroll 8
+      for (int n = 0; n < N; ++n) v += dhbuf[(int64_t)n * Ch + j] * ahat[(int64_t)n * C + cc];
+      dw1[q] += v;
+    } else if (o < 2 * nw + C) {                                          // db2[c] = sum_n dv[n][c]
+      const int cc = o - 2 * nw;
+      float v = 0.f;
+#pragma unroll 8
+      for (int n = 0; n < N; ++n) v += dvbuf[(int64_t)n * C + cc];
+      db2[cc] += v;
+    } else if (o < 2 * nw + C + Ch) {                                     // db1[j] = sum_n dh[n][j]
+      const int j = o - 2 * nw - C;
+      float v = 0.f;
+#pragma unroll 8
+      for (int n = 0; n < N; ++n) v += dhbuf[(int64_t)n * Ch + j];
+      db1[j] += v;
+    }
+    return;
+  }
   __shared__ double rs[32][32], rq[32][32];
   __shared__ float rw[32][32][9];
   const int NL = blockDim.x >> 5;   // sample lanes (32 at the 1024-thread launch)
@@ -935,38 +970,6 @@ __global__ void __launch_bounds__(1024) k_ca_bwd1(const float* __restrict__ pool
       for (int j = 0; j < NL; ++j) v += rw[j][cl][t];
       dw3[c * 9 + t] += v;
     }
-  }
-  // ---- parameter gradients of the two 1x1 layers: sums over the batch of the rows k_ca_bwd2 stored (this block owns the 32
-  // channels [32 blockIdx.x, +32): one writer per element, samples added in order -- deterministic, no atomics)
-  {
-    const int Ch = C / 2, c0 = blockIdx.x * 32, nc = min(32, C - c0);
-    const float* ahat = save + (int64_t)N * C;
-    const float* hh = save + (int64_t)N * C * 2;
-    for (int o = threadIdx.x; o < nc * Ch; o += blockDim.x) {           // dW2[c][j] = sum_n dv[n][c] * h[n][j]
-      const int cc = o / Ch, j = o - cc * Ch;
-      float v = 0.f;
-#pragma unroll 8
-      for (int n = 0; n < N; ++n) v += dvbuf[(int64_t)n * C + c0 + cc] * hh[(int64_t)n * Ch + j];
-      dw2[(int64_t)(c0 + cc) * Ch + j] += v;
-    }
-    for (int o = threadIdx.x; o < Ch * nc; o += blockDim.x) {           // dW1[j][c] = sum_n dh[n][j] * ahat[n][c]
-      const int j = o / nc, cc = o - j * nc;
-      float v = 0.f;
-#pragma unroll 8
-      for (int n = 0; n < N; ++n) v += dhbuf[(int64_t)n * Ch + j] * ahat[(int64_t)n * C + c0 + cc];
-      dw1[(int64_t)j * C + c0 + cc] += v;
-    }
-    if ((int)threadIdx.x < nc) {                                          // db2[c] = sum_n dv[n][c]
-      float v = 0.f;
-      for (int n = 0; n < N; ++n) v += dvbuf[(int64_t)n * C + c0 + threadIdx.x];
-      db2[c0 + threadIdx.x] += v;
-    }
-    if (blockIdx.x == 0)
-      for (int j = threadIdx.x; j < Ch; j += blockDim.x) {               // db1[j] = sum_n dh[n][j]
-        float v = 0.f;
-        for (int n = 0; n < N; ++n) v += dhbuf[(int64_t)n * Ch + j];
-        db1[j] += v;
-      }
   }
 }
 
@@ -1395,7 +1398,7 @@ int lhn_ca_mlp_bwd2(const float* pooled, const float* w3, const float* gamma, co
   float* dhbuf = dvbuf + (int64_t)N * C;
   LHN_CHECK_ARG(stage == 0 || (gsum && stage >= 1 && stage <= 2 && count_scale >= 1), "lhn_ca_mlp_bwd: stage %d needs gsum", stage);
   if (stage != 2) hipLaunchKernelGGL(k_ca_bwd2, dim3(N), dim3(256), 0, s, w1, w2, save, dgate, dahat, dvbuf, dhbuf, N, C);
-  hipLaunchKernelGGL(k_ca_bwd1, dim3((C + 31) / 32), dim3(1024), 0, s, pooled, w3, gamma, dropmask, save, dahat, dpool, cstride, coff, H, W, dw3, dgamma, dbeta, N, C, 1, stage, gsum, stage ? count_scale : 1.0, stage ? pgrad_scale : 1.f, tsum, pstat, sl, dvbuf, dhbuf, dw1, db1, dw2, db2);
+  hipLaunchKernelGGL(k_ca_bwd1, dim3((C + 31) / 32 + (C * C + C + C / 2 + 1023) / 1024), dim3(1024), 0, s, pooled, w3, gamma, dropmask, save, dahat, dpool, cstride, coff, H, W, dw3, dgamma, dbeta, N, C, 1, stage, gsum, stage ? count_scale : 1.0, stage ? pgrad_scale : 1.f, tsum, pstat, sl, dvbuf, dhbuf, dw1, db1, dw2, db2);
   LHN_CHECK_LAUNCH("lhn_ca_mlp_bwd");
   return 0;
 }

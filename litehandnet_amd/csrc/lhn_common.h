@@ -226,13 +226,21 @@ __device__ __forceinline__ f4 lhn_dy_fast(const Xf4& t, const Gr4& gr, f4 raw, f
 // each wave waits until its own atomics are acknowledged (vmcnt(0)), the block meets at a barrier, ONE lane
 // takes a ticket with a device-scope atomic; the block that draws the last ticket reads the sums with
 // device-scope (sc1, L1-bypassing) loads.  Nothing else in the launch ever reads those addresses.
+// Tickets in TWO levels (counter[0] = top, counter[1 + g] = group g = block % 32): returning atomics on ONE word are served at
+// ~88 per us, so 1,024 workgroups finishing together queued 12 us on a single word (round 1: fused finalize slower than the
+// launch it replaced); 32 group words take their tickets in parallel, the last of each group takes one of 32 top tickets.
+#define LHN_TICKET_WORDS 33
 __device__ __forceinline__ bool lhn_last_block(unsigned* counter) {
   __shared__ int s_last;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
-    const unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = (t == gridDim.x * gridDim.y - 1u);
+    const unsigned nb = gridDim.x * gridDim.y, b = blockIdx.x + blockIdx.y * gridDim.x;
+    const unsigned g = b & 31u, ng = nb < 32u ? nb : 32u, gsize = (nb - g + 31u) >> 5;
+    int last = 0;
+    if (__hip_atomic_fetch_add(counter + 1 + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1u)
+      last = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ng - 1u;
+    s_last = last;
   }
   __syncthreads();
   return s_last != 0;
@@ -270,6 +278,55 @@ __device__ __forceinline__ void lhn_bn_finalize_block(const lhn_bnfin& f, const 
     }
   }
   if (f.num_batches_tracked && threadIdx.x == 0) f.num_batches_tracked[0] += 1;
+}
+// the same by a whole block with the replica fold spread over its threads (blockDim.x / C groups of replicas per channel meet in
+// `part`, LDS for 2 * blockDim.x doubles that nobody else is using any more): one memory latency instead of 64 dependent loads
+__device__ __forceinline__ void lhn_bn_finalize_block_par(const lhn_bnfin& f, const double* stats, double* part) {
+  const int C = f.C, nt = blockDim.x, tid = threadIdx.x;
+  int G = nt / C;
+  G = G < 1 ? 1 : (G > LHN_STAT_REPLICAS ? LHN_STAT_REPLICAS : G);
+  __syncthreads();      // (part may alias LDS the block was still reading)
+  for (int c0 = 0; c0 < C; c0 += nt) {
+    const int g = G > 1 ? tid / C : 0, c = c0 + (G > 1 ? tid - g * C : tid);
+    if (c0) __syncthreads();
+    if (g < G && c < C) {
+      double s1 = 0, s2 = 0;
+#pragma unroll 4
+      for (int r = g; r < LHN_STAT_REPLICAS; r += G) {
+        s1 += lhn_ld_agent(stats + (size_t)r * 2 * C + c);
+        s2 += lhn_ld_agent(stats + (size_t)r * 2 * C + C + c);
+      }
+      part[2 * tid] = s1;
+      part[2 * tid + 1] = s2;
+    }
+    __syncthreads();
+    if (g != 0 || c >= C) continue;
+    double s1 = 0, s2 = 0;
+    for (int k = 0; k < G; ++k) {
+      s1 += part[2 * (k * C + tid)];
+      s2 += part[2 * (k * C + tid) + 1];
+    }
+    const double mean = s1 / f.count;
+    double var = s2 / f.count - mean * mean;
+    if (var < 0) var = 0;
+    if (f.running_mean) {
+      const double bm = mean + (f.conv_bias ? (double)f.conv_bias[c] : 0.0);
+      f.running_mean[c] = (float)((1.0 - (double)f.momentum) * (double)f.running_mean[c] + (double)f.momentum * bm);
+      const double unb = f.count > 1 ? var * f.count / (f.count - 1.0) : var;
+      f.running_var[c] = (float)((1.0 - (double)f.momentum) * (double)f.running_var[c] + (double)f.momentum * unb);
+    }
+    const float invstd = (float)(1.0 / sqrt(var + (double)f.eps));
+    const float gm = f.gamma ? f.gamma[c] : 1.f, b = f.beta ? f.beta[c] : 0.f;
+    const float sc = gm * invstd;
+    f.table[f.coff + c] = sc;
+    f.table[f.cstride + f.coff + c] = b - (float)mean * sc;
+    f.table[2 * f.cstride + f.coff + c] = f.slope;
+    if (f.save_mean_invstd) {
+      f.save_mean_invstd[c] = (float)mean;
+      f.save_mean_invstd[C + c] = invstd;
+    }
+  }
+  if (f.num_batches_tracked && tid == 0) f.num_batches_tracked[0] += 1;
 }
 __device__ __forceinline__ void lhn_bn_bwd_finalize_block(const lhn_bnbwdfin& f, const double* sums, const float* save) {
   const int C = f.C;

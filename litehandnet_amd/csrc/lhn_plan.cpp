@@ -105,11 +105,10 @@ static lhn_bnfin mkfin(const Plan* P, void* ws, const lhn_op& o, void* const* pa
   f.conv_bias = prm<const float>(params, o.p[1]);   // biased conv + BN: the bias lives in the finalize only
   return f;
 }
-// The finalize runs as its own tiny launch unless LHN_FUSE_FINALIZE=1: measured on MI355X the in-kernel
-// last-block hand-off (one returning ticket atomic per workgroup on one word, ~88 tickets/us) costs MORE than
-// the ~5.5 us launch it replaces (variant B step 13.5 ms fused vs 12.9 ms separate), so separate is the default.
-// Fusing only the small maps does not pay either (B step, fuse when N*H*W <= 0 / 4096 / 16384 / 65536:
-// 10.57 / 10.62 / 10.67 / 10.86 ms): back-to-back launches overlap their ~5 us with the previous kernel's tail.
+// LHN_FUSE_FINALIZE: the last workgroup of a convolution folds the statistics and writes the table (lhn_bnfin) instead of a
+// separate 1-workgroup launch.  Round 1 measured it SLOWER (one returning ticket atomic per workgroup on one word, ~88 tickets
+// per us: 13.5 vs 12.9 ms per step of variant B); round 3 takes the tickets in two levels (32 group words + 1 top word) and
+// folds the replicas with the whole block, see lhn_last_block / lhn_bn_finalize_block_par.
 static bool fuse_finalize() {
   static int v = -1;
   if (v < 0) {
@@ -180,7 +179,12 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
   const bool whole = (sb == 0 && se >= 2 * ops.size());
   for (size_t oi = 0; oi < ops.size() && rc == 0; ++oi) {
     const lhn_op& o = ops[oi];
-    const bool deferred = false;      // (round 2's deferred finalize is gone: every BatchNorm has its finalize launch)
+    const bool deferred = false;      // (round 2's deferred finalize is gone)
+    // fused finalize (last workgroup of the convolution): whole-plan runs only (SyncBatchNorm splits the op at the exchange), not
+    // for padded channel counts (the in-kernel form has one channel count) nor for units the reference evaluates twice
+    const bool is_conv = o.kind == OP_STEM || o.kind == OP_PW || o.kind == OP_DW || o.kind == OP_KXK;
+    const bool fz = is_conv && training && fuse_finalize() && whole && !(o.kind == OP_PW && o.i[2] > 0) &&
+                    !((o.kind == OP_PW || o.kind == OP_DW) && (int)o.f[3] > 1);
     const bool h0 = 2 * oi >= sb && 2 * oi < se, h1 = 2 * oi + 1 >= sb && 2 * oi + 1 < se;
     if (!h0 && !h1) continue;
     const bool two_half = o.kind == OP_STEM || o.kind == OP_PW || o.kind == OP_DW || o.kind == OP_KXK || o.kind == OP_CA_MLP ||
@@ -214,8 +218,8 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
         }
         if (h0) rc = lhn_conv_stem_fwd(static_cast<const float*>(io[0]), prm<const float>(params, o.p[0]), &y,
                                (training && o.ws[0] >= 0) ? reinterpret_cast<double*>(at(ws, o.ws[0])) : nullptr, o.i[3], o.i[4], o.i[0], o.i[1],
-                               o.i[2], (bn && training && fuse_finalize() && whole) ? &fin : nullptr, stream);
-        if (!rc && bn && h1 && !skip_tables && !deferred && !(training && fuse_finalize() && whole)) rc = sep_finalize(fin, reinterpret_cast<const double*>(at(ws, o.ws[0])), training, stream);
+                               o.i[2], (bn && fz) ? &fin : nullptr, stream);
+        if (!rc && bn && h1 && !skip_tables && !deferred && !fz) rc = sep_finalize(fin, reinterpret_cast<const double*>(at(ws, o.ws[0])), training, stream);
         break;
       }
       case OP_PW: {
@@ -267,8 +271,8 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
         }
         if (h0) rc = lhn_conv_pw_fwd2(&x, prm<const float>(params, o.p[0]), bn ? nullptr : prm<const float>(params, o.p[1]), &y,
                               (training && o.ws[0] >= 0) ? reinterpret_cast<double*>(at(ws, o.ws[0])) : nullptr, o.i[0], nchw,
-                              (bn && training && fuse_finalize() && whole) ? &fin : nullptr, &po, stream);
-        if (!rc && bn && h1 && !skip_tables && !deferred && !(training && fuse_finalize() && whole))
+                              (bn && fz) ? &fin : nullptr, &po, stream);
+        if (!rc && bn && h1 && !skip_tables && !deferred && !fz)
           rc = sep_finalize(fin, reinterpret_cast<const double*>(at(ws, o.ws[0])), training, stream, o.i[2], (int)o.f[3]);
         break;
       }
@@ -296,9 +300,9 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
         }
         if (h0) rc = lhn_conv_dw_fwd3(&x, prm<const float>(params, o.p[0]), &y,
                               (training && o.ws[0] >= 0) ? reinterpret_cast<double*>(at(ws, o.ws[0])) : nullptr, o.i[0], o.i[1], o.i[2], o.i[3],
-                              (bn && training && fuse_finalize() && whole) ? &fin : nullptr, o.i[6] > 1 ? &extra : nullptr, coef2,
+                              (bn && fz) ? &fin : nullptr, o.i[6] > 1 ? &extra : nullptr, coef2,
                               so ? &sumv : nullptr, stream);
-        if (!rc && bn && h1 && !skip_tables && !deferred && !(training && fuse_finalize() && whole))
+        if (!rc && bn && h1 && !skip_tables && !deferred && !fz)
           rc = sep_finalize(fin, reinterpret_cast<const double*>(at(ws, o.ws[0])), training, stream, 0, (int)o.f[3]);
         break;
       }
@@ -313,9 +317,9 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
         }
         if (h0) rc = lhn_conv_kxk_fwd(&x, prm<const float>(params, o.p[0]), &y,
                               (training && o.ws[0] >= 0) ? reinterpret_cast<double*>(at(ws, o.ws[0])) : nullptr, o.i[0],
-                              (bn && training && fuse_finalize() && whole) ? &fin : nullptr,
+                              (bn && fz) ? &fin : nullptr,
                               o.ws[3] >= 0 ? reinterpret_cast<float*>(at(ws, o.ws[3])) : nullptr, stream);
-        if (!rc && bn && h1 && !skip_tables && !deferred && !(training && fuse_finalize() && whole)) rc = sep_finalize(fin, reinterpret_cast<const double*>(at(ws, o.ws[0])), training, stream);
+        if (!rc && bn && h1 && !skip_tables && !deferred && !fz) rc = sep_finalize(fin, reinterpret_cast<const double*>(at(ws, o.ws[0])), training, stream);
         break;
       }
       case OP_FINALIZE: {

@@ -32,6 +32,7 @@ EW_MUL, EW_BILINEAR = 1, 2   # EwSrcs.mode bits: product of the sources / biline
 
 ALIGN = 256
 STAT_REPLICAS = 32     # LHN_STAT_REPLICAS in include/lhn.h
+TICKET_WORDS = 33      # arrival counters of a fused finalize (lhn_bnfin.counter: one top word + 32 group words)
 
 
 def _al(n):
@@ -240,11 +241,11 @@ class PlanBuilder:
         if bn is not None:
             sc = max(cout, cpad)        # statistics are laid out for the (padded) output view
             rec["stats"] = self._ws("zf", STAT_REPLICAS * 2 * sc * 8)
-            rec["cnt"] = self._ws("zf", 4)
+            rec["cnt"] = self._ws("zf", 4 * TICKET_WORDS)
             rec["save"] = self._ws("misc", 2 * sc * 4)
             if self.with_backward:
                 rec["sums"] = self._ws("zb", STAT_REPLICAS * 2 * sc * 8)
-                rec["bcnt"] = self._ws("zb", 4)
+                rec["bcnt"] = self._ws("zb", 4 * TICKET_WORDS)
                 self.bufs[out.buf].coef = True
         self.recs.append(rec)
         if bn is None and not nchw_out:
@@ -265,11 +266,11 @@ class PlanBuilder:
         out = self.new(x.H, x.W, x.C)
         rec = dict(op=DW, x=x, out=out, conv=_IDENT, bn=bn, slope=float(slope), k=1, stride=1, pad=0, dil=1, nchw=False)
         rec["stats"] = self._ws("zf", STAT_REPLICAS * 2 * x.C * 8)
-        rec["cnt"] = self._ws("zf", 4)
+        rec["cnt"] = self._ws("zf", 4 * TICKET_WORDS)
         rec["save"] = self._ws("misc", 2 * x.C * 4)
         if self.with_backward:
             rec["sums"] = self._ws("zb", STAT_REPLICAS * 2 * x.C * 8)
-            rec["bcnt"] = self._ws("zb", 4)
+            rec["bcnt"] = self._ws("zb", 4 * TICKET_WORDS)
             self.bufs[out.buf].coef = True
         self.recs.append(rec)
         return out

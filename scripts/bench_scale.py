@@ -39,9 +39,13 @@ for N in (64, 128, 256):
         i = nxt(); L.lhn_conv_pw_fwd(C.byref(vx[i]), _lib.ptr(w1), None, C.byref(vy[i]), _lib.ptr(stats), 1, None, None, st)
     def dw():
         i = nxt(); L.lhn_conv_dw_fwd(C.byref(vx[i]), _lib.ptr(w3), C.byref(vy[i]), _lib.ptr(stats), 3, 1, 1, 1, None, st)
+    def pw0():
+        i = nxt(); L.lhn_conv_pw_fwd(C.byref(vx[i]), _lib.ptr(w1), None, C.byref(vy[i]), None, 1, None, None, st)
+    def dw0():
+        i = nxt(); L.lhn_conv_dw_fwd(C.byref(vx[i]), _lib.ptr(w3), C.byref(vy[i]), None, 3, 1, 1, 1, None, st)
     def cp():
         i = nxt(); ys[i].copy_(xs[i])
-    for name, fn in (("pw64->64", pw), ("dw3x3", dw), ("copy", cp)):
+    for name, fn in (("pw64->64", pw), ("pw nostat", pw0), ("dw3x3", dw), ("dw nostat", dw0), ("copy", cp)):
         us = timeit(fn, 4 * NP)
         print(f"N={N:4d} {name:10s} {us:8.1f} us  {byts / us / 1e6:6.2f} TB/s", flush=True)
     del xs, ys
