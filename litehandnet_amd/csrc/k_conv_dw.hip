@@ -196,7 +196,7 @@ __global__ void __launch_bounds__(256) k_stem3_fwd_mfma(const float* __restrict_
   constexpr int CO = 32, LDV = 36;
   __shared__ __attribute__((aligned(16))) float Vs[256 * LDV];      // [pixel][tap], columns 27..31 stay zero
   __shared__ double redd[4][2 * CO];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, lh = lane >> 5;
   // B fragments: MFMA step ks, lane (n = l31, k = lh) holds W[tap = 16 lh + ks][co = l31]  (the A reads use the same K order)
   float wreg[16];
 #pragma unroll
@@ -294,7 +294,7 @@ __global__ void __launch_bounds__(256, 2) k_stem7_fwd_mfma(const float* __restri
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Vs = smem;                                   // [BMP][LDV], columns 147..159 stay zero
   double* redd = reinterpret_cast<double*>(smem + BMP * LDV);      // [2 pixel groups][2 * CO]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, lh = lane >> 5;
   const int cot = wave & 1, pg = wave >> 1, co = cot * 32 + l31;
   float wreg[NKS];                                    // step ks, lane (n = l31, k = lh): W[co][tap = NKS * lh + ks]
 #pragma unroll
@@ -726,7 +726,7 @@ __global__ void __launch_bounds__(256) k_stem3_bwd_mfma(const float* __restrict_
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* dYs = smem;                     // [256][LDY] pixel-major dy; reused for the final cross-wave sum (4096 floats)
   float* Vs = smem + 256 * LDY;          // [256][LDV] pixel-major patch, columns 27..31 stay zero
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, lh = lane >> 5;
   const int c4 = tid & 7, prow = tid >> 3;
   const int cy = y.coff + 4 * c4;
   const Xf4 yxf = lhn_load_xf(y, cy);
@@ -819,7 +819,7 @@ __global__ void __launch_bounds__(256, 2) k_stem7_bwd_mfma(const float* __restri
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* dYs = smem;                     // [BMP][LDY]
   float* Vs = smem + BMP * LDY;          // [BMP][LDV], columns 147..159 stay zero
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, lh = lane >> 5;
   const int c4 = tid & 15, prow = tid >> 4;
   const int cy = y.coff + 4 * c4;
   const Xf4 yxf = lhn_load_xf(y, cy);

@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(256) k_kxk(lhn_view x, const float* __restrict
   float* Ws = smem;                   // [32*NT][LDA]
   float* As = smem + 32 * NT * LDA;   // [128][LDA]
   float* red = As + BM * LDA;         // [4][32*NT][2]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, lh = lane >> 5;
   const int c4 = tid % C4, row0 = tid / C4;
   const int n0 = blockIdx.y * 32 * NT;        // N split: this block's first output feature (small M: more blocks)
   const lhn_view& av = MODE == 0 ? x : y;
@@ -344,7 +344,7 @@ __global__ void __launch_bounds__(256) k_kxk_wgrad(lhn_view x, lhn_view y, lhn_g
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* dYs = smem;               // [64][LDY]
   float* Xs = dYs + 64 * LDY;      // [64][LDX]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, lh = lane >> 5;
   const int tap = blockIdx.y, kh = TAPS == 1 ? 1 : tap / 3, kw = TAPS == 1 ? 1 : tap - (tap / 3) * 3;
   constexpr int XC4 = CIN / 4, XRP = 256 / XC4, XPF = 64 / XRP;
   constexpr int YC4 = COP / 4, YRP = 256 / YC4, YPF = 64 / YRP;
@@ -419,17 +419,37 @@ __global__ void __launch_bounds__(256) k_kxk_wgrad(lhn_view x, lhn_view y, lhn_g
     commit();
     __syncthreads();
     if (PF && tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x);
-    const int kpart = KS > 1 ? wave % KS : 0;
+    if constexpr (KS == 1 && T % 4 == 0 && 4 % NTI == 0) {
+      // whole tiles per wave: NO predicate around the MFMAs and the wave index in a scalar register.  With `if (tl < T)` in this
+      // loop the compiler emitted exec-mask branches and an lgkmcnt(0) wait in front of every MFMA group: 128 -> 128 3x3 at
+      // 64 x 64 took 840 us (58 % of the fp32 MFMA peak); this form: hourglass step 66.4 -> 64.3 ms, A 19.87 -> 19.39.  (A variant
+      // with the three taps of a kernel row per workgroup -- one dY tile, a 66-pixel X run, 12 accumulator tiles per wave, one
+      // workgroup per CU -- was built on top and measured 0.1-1 % SLOWER than one tap per workgroup: removed.)
+      const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+      const float* ap = dYs + lh * LDY + l31 + 32 * (wv / NTI);
+      const float* bp = Xs + lh * LDX + l31 + 32 * (wv % NTI);
 #pragma unroll 4
-    for (int ks = kpart * (32 / KS); ks < (kpart + 1) * (32 / KS); ++ks) {
-      const float* dyr = dYs + (2 * ks + lh) * LDY + l31;
-      const float* xr = Xs + (2 * ks + lh) * LDX + l31;
+      for (int ks = 0; ks < 32; ++ks) {
+        const float b = bp[(2 * ks) * LDX];
+        float a[NDW];
 #pragma unroll
-      for (int t = 0; t < NDW; ++t) {
-        const int tl = (wave + 4 * t) / KS;
-        if (tl < T) {
-          const int it = tl / NTI, jt = tl % NTI;
-          accw[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(dyr[32 * it], xr[32 * jt], accw[t], 0, 0, 0);
+        for (int t = 0; t < NDW; ++t) a[t] = ap[(2 * ks) * LDY + 32 * (4 / NTI) * t];
+#pragma unroll
+        for (int t = 0; t < NDW; ++t) accw[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b, accw[t], 0, 0, 0);
+      }
+    } else {
+      const int kpart = KS > 1 ? wave % KS : 0;
+#pragma unroll 4
+      for (int ks = kpart * (32 / KS); ks < (kpart + 1) * (32 / KS); ++ks) {
+        const float* dyr = dYs + (2 * ks + lh) * LDY + l31;
+        const float* xr = Xs + (2 * ks + lh) * LDX + l31;
+#pragma unroll
+        for (int t = 0; t < NDW; ++t) {
+          const int tl = (wave + 4 * t) / KS;
+          if (tl < T) {
+            const int it = tl / NTI, jt = tl % NTI;
+            accw[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(dyr[32 * it], xr[32 * jt], accw[t], 0, 0, 0);
+          }
         }
       }
     }

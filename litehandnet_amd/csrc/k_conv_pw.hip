@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(256, NS > 1 ? 1 : ((CIN == 64 && NT == 2) || (
   float* Ws = smem;                    // [32*NT][LDA]
   float* As = smem + 32 * NT * LDA;    // [128][LDA]
   float* red = As;                     // [4][32*NT][2]: aliases the A tile after the last tile's trailing barrier
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: wave-uniform predicates become scalar branches)
   const int l31 = lane & 31, lh = lane >> 5;
 
   const int c4 = tid % C4, row0 = tid / C4;
@@ -281,7 +281,7 @@ k_pw_fwd_wr(lhn_view x, const float* __restrict__ w, const float* __restrict__ b
   constexpr int C4 = CIN / 4, RP = 256 / C4, PF = BM / RP;      // float4 loads per thread, tile and source
   static_assert(PF >= 1, "tile too small for the loader");
   extern __shared__ __attribute__((aligned(16))) float smem[];   // [2][BM][LDA]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, lh = lane >> 5;
   const int cot = wave % NCOT, pxs = wave / NCOT;
   const int co = cot * 32 + l31;
   // ---- B fragments: wreg[kc*4 + j] = W[co][8*kc + 4*lh + j]  (same K permutation as the A reads below)
@@ -623,8 +623,11 @@ extern "C" int lhn_conv_pw_fwd(const lhn_view* x, const float* w, const float* b
 //                                                                           fp32 atomic add per block at the end
 // NCHW = the head's gradient arrives as a plain NCHW tensor (dy_nchw); a template flag so that the NHWC instances do not
 // carry its prefetch registers (they cost k_pw_bwd<64,2> 44 -> 56 us when the switch was a runtime one)
+#ifndef LHN_PWB_BNS_OCC
+#define LHN_PWB_BNS_OCC 3      // (2 = no spills: B step 8.45 vs 8.41 ms -- the 9 spilled registers cost less than the third workgroup gives)
+#endif
 template <int CIN, int NTO, bool NCHW, bool BNS = false>
-__global__ void __launch_bounds__(256, (CIN == 32 && NTO == 1 && !NCHW) ? 4 : (CIN <= 64 && NTO <= 2 && !NCHW) ? 3 : 1) k_pw_bwd(lhn_view x, const float* __restrict__ w, lhn_view y, lhn_gradview gy,
+__global__ void __launch_bounds__(256, (CIN == 32 && NTO == 1 && !NCHW) ? 4 : (CIN <= 64 && NTO <= 2 && !NCHW) ? (BNS ? LHN_PWB_BNS_OCC : 3) : 1) k_pw_bwd(lhn_view x, const float* __restrict__ w, lhn_view y, lhn_gradview gy,
                                                 float* __restrict__ dx, int dx_acc, float* __restrict__ dw,
                                                 float* __restrict__ dbias, int stride, const float* __restrict__ dy_nchw,
                                                 int cout, int M, int ntiles, int nrep, int64_t rep_stride, PwGeom geo, lhn_bnsum bs) {
@@ -644,7 +647,7 @@ __global__ void __launch_bounds__(256, (CIN == 32 && NTO == 1 && !NCHW) ? 4 : (C
   float* Ws = smem;                 // [COP][LDW]
   float* dYs = Ws + COP * LDW;      // [64][LDY]
   float* Xs = dYs + 64 * LDY;       // [64][LDX]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, lh = lane >> 5;
   const int HoWo = y.H * y.W;
 
   pw_stage_w<CIN>(Ws, LDW, w, COP, geo);
@@ -767,7 +770,21 @@ __global__ void __launch_bounds__(256, (CIN == 32 && NTO == 1 && !NCHW) ? 4 : (C
 
     // ---- dW += dY^T X   (K = 64 pixels)
     const int dwave = DW_HI ? wave - 2 : wave;
-    if (dwave >= 0) {
+    if constexpr (!DW_HI && KS == 1 && T % 4 == 0 && 4 % NTI == 0) {
+      // every wave owns whole dW tiles (tile wave + 4 t: row wave / NTI + (4 / NTI) t, column wave % NTI): no predicate around
+      // the MFMAs -- with `if (tl < T)` here the compiler wrapped each one in exec-mask branches and lgkmcnt(0) waits (k_conv_kxk.hip)
+      const float* ap = dYs + lh * LDY + l31 + 32 * (wave / NTI);
+      const float* bp = Xs + lh * LDX + l31 + 32 * (wave % NTI);
+#pragma unroll 4
+      for (int ks = 0; ks < 32; ++ks) {
+        const float b = bp[(2 * ks) * LDX];
+        float a[NDW];
+#pragma unroll
+        for (int t = 0; t < NDW; ++t) a[t] = ap[(2 * ks) * LDY + 32 * (4 / NTI) * t];
+#pragma unroll
+        for (int t = 0; t < NDW; ++t) accw[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b, accw[t], 0, 0, 0);
+      }
+    } else if (dwave >= 0) {
       const int kpart = KS > 1 ? dwave % KS : 0;
 #pragma unroll 4
       for (int ks = kpart * (32 / KS); ks < (kpart + 1) * (32 / KS); ++ks) {
@@ -799,7 +816,7 @@ __global__ void __launch_bounds__(256, (CIN == 32 && NTO == 1 && !NCHW) ? 4 : (C
 #pragma unroll
         for (int t = 0; t < NDX; ++t) {
           const int jt = (wave >> 1) + 2 * t;
-          if (jt < NTI) {
+          if (NTI % 2 == 0 || jt < NTI) {        // (even NTI: always true, folded at compile time)
             accx[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, wr[0 * LDW + 32 * jt], accx[t], 0, 0, 0);
             accx[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, wr[1 * LDW + 32 * jt], accx[t], 0, 0, 0);
             accx[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, wr[2 * LDW + 32 * jt], accx[t], 0, 0, 0);
@@ -922,6 +939,8 @@ static int launch_pw_bwd_t(const lhn_view* x, const float* w, const lhn_view* y,
   }
   int grid = lhn_num_cus() * per_cu;
   if (grid > ntiles) grid = ntiles;
+  // (one tile per workgroup on small maps is the fastest split: fewer, longer workgroups -- 2 / 4 / 8 tiles each -- took Lite-HRNet's
+  // step from 36.9 to 40.1 / 47.4 / 55.3 ms; the weight-gradient atomics are not what these launches wait for)
   lhn_gradview g = *gy;
   hipLaunchKernelGGL((k_pw_bwd<CIN, NTO, NCHW, BNS>), dim3(grid), dim3(256), lds, s, *x, w, *y, g, dx, dx_acc, dw, dbias, stride, dy_nchw,
                      cout, M, ntiles, nrep, rep_stride, geo, bs);
