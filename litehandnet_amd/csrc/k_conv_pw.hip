@@ -311,6 +311,12 @@ k_pw_fwd_wr(lhn_view x, const float* __restrict__ w, const float* __restrict__ b
   }
   f4 pre[PF], epre[NS > 1 ? NS - 1 : 1][PF];
   Xf4 xf, exf[NS > 1 ? NS - 1 : 1];          // filled after the first tile's loads have been issued (see below)
+  // gates: one sample per tile whenever H*W is a multiple of the tile (every map of the models here but 8x8 at BM = 128), so the
+  // gate of a tile is ONE float4 per thread, fetched with the tile's pixels a tile ahead (the general commit below loads it per
+  // row and waits for it: a vmcnt(0) in the middle of the loop that also drained the prefetch)
+  const bool uni = HoWo % BM == 0;
+  const f4 one4 = (f4){1.f, 1.f, 1.f, 1.f};
+  f4 gpre = one4, egpre[NS > 1 ? NS - 1 : 1];
   auto issue = [&](int tile) __attribute__((always_inline)) {
 #pragma unroll
     for (int p = 0; p < PF; ++p) {
@@ -322,29 +328,43 @@ k_pw_fwd_wr(lhn_view x, const float* __restrict__ w, const float* __restrict__ b
           if (e < ex.n) epre[e][p] = *reinterpret_cast<const f4*>(ex.v[e].data + (int64_t)m * ex.v[e].cstride + ecabs[e]);
       }
     }
+    if (uni) {
+      const int n = min(tile * BM, M - 1) / HoWo;
+      gpre = x.gate ? *reinterpret_cast<const f4*>(x.gate + (int64_t)n * x.cstride + cabs) : one4;
+      if (NS > 1) {
+#pragma unroll
+        for (int e = 0; e < NS - 1; ++e)
+          if (e < ex.n) egpre[e] = ex.v[e].gate ? *reinterpret_cast<const f4*>(ex.v[e].gate + (int64_t)n * ex.v[e].cstride + ecabs[e]) : one4;
+      }
+    }
   };
   auto commit = [&](int tile, float* As) __attribute__((always_inline)) {
+    // one straight-line form: rows >= M were loaded from a clamped (valid) address and are zeroed by a select, not a branch
 #pragma unroll
     for (int p = 0; p < PF; ++p) {
       const int row = row0 + p * RP, m = tile * BM + row;
-      f4 v = (f4){0.f, 0.f, 0.f, 0.f};
-      if (m < M) {
-        const int n = m / HoWo;
-        v = lhn_apply_xf(pre[p], xf);
-        if (x.gate) v *= *reinterpret_cast<const f4*>(x.gate + (int64_t)n * x.cstride + cabs);
-        if (NS > 1) {
-          v *= ex.coef[0];
-#pragma unroll
-          for (int e = 0; e < NS - 1; ++e)
-            if (e < ex.n) {
-              f4 u = lhn_apply_xf(epre[e][p], exf[e]);
-              if (ex.v[e].gate) u *= *reinterpret_cast<const f4*>(ex.v[e].gate + (int64_t)n * ex.v[e].cstride + ecabs[e]);
-              v += u * ex.coef[e + 1];
-            }
-          if (ex.sum_out) *reinterpret_cast<f4*>(ex.sum_out + (int64_t)m * ex.so_cstride + ex.so_coff + 4 * c4) = v;
-        }
+      const bool ok = m < M;
+      f4 g = gpre;
+      if (!uni) {      // (a tile that spans samples: the gate per row)
+        const int n = min(m, M - 1) / HoWo;
+        g = x.gate ? *reinterpret_cast<const f4*>(x.gate + (int64_t)n * x.cstride + cabs) : one4;
       }
-      *reinterpret_cast<f4*>(As + row * LDA + 4 * c4) = v;
+      f4 v = lhn_apply_xf(pre[p], xf) * g;
+      if (NS > 1) {
+        v *= ex.coef[0];
+#pragma unroll
+        for (int e = 0; e < NS - 1; ++e)
+          if (e < ex.n) {
+            f4 ge = egpre[e];
+            if (!uni) {
+              const int n = min(m, M - 1) / HoWo;
+              ge = ex.v[e].gate ? *reinterpret_cast<const f4*>(ex.v[e].gate + (int64_t)n * ex.v[e].cstride + ecabs[e]) : one4;
+            }
+            v += lhn_apply_xf(epre[e][p], exf[e]) * ge * ex.coef[e + 1];
+          }
+        if (ex.sum_out && ok) *reinterpret_cast<f4*>(ex.sum_out + (int64_t)m * ex.so_cstride + ex.so_coff + 4 * c4) = v;
+      }
+      *reinterpret_cast<f4*>(As + row * LDA + 4 * c4) = ok ? v : (f4){0.f, 0.f, 0.f, 0.f};
     }
   };
 
@@ -390,14 +410,33 @@ k_pw_fwd_wr(lhn_view x, const float* __restrict__ w, const float* __restrict__ b
       float* yo = y.data + y.coff + co;
       TileStat ts;
       ts.reset();
+      if (CIN < 256 && tile * BM + BM <= M && !yacc) {      // (K = 256 holds 128 registers of W: the batched stores below would spill)
+        // whole tile inside the tensor (every tile but possibly the last): 16 plain stores off one base pointer.  The general
+        // form below costs ~20 instructions and two branches per stored element (64-bit address product, row predicate, the
+        // accumulate switch, the first-value select of TileStat) -- more issue slots than the tile's 16 MFMAs
+        float* yp = yo + (int64_t)mbase * y.cstride;
+        const int cs = y.cstride;
+        const float k0 = acc[0] + bv;
+        float sd = 0.f, qd = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = mbase + (r & 3) + 8 * (r >> 2);
-        if (m < M) {
-          float v = acc[r] + bv;
-          if (yacc) v += yo[(int64_t)m * y.cstride];       // second K slice of a wide input (C = 256): statistics see the sum
-          yo[(int64_t)m * y.cstride] = v;
-          ts.add(v);
+        for (int r = 0; r < 16; ++r) {
+          const float v = acc[r] + bv;
+          yp[((r & 3) + 8 * (r >> 2)) * cs] = v;
+          const float d = v - k0;
+          sd += d;
+          qd += d * d;
+        }
+        ts.k = k0; ts.s = sd; ts.q = qd; ts.n = 16;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mbase + (r & 3) + 8 * (r >> 2);
+          if (m < M) {
+            float v = acc[r] + bv;
+            if (yacc) v += yo[(int64_t)m * y.cstride];       // second K slice of a wide input (C = 256): statistics see the sum
+            yo[(int64_t)m * y.cstride] = v;
+            ts.add(v);
+          }
         }
       }
       ts.flush(ssum, ssq);
