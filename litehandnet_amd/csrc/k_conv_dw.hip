@@ -1358,6 +1358,8 @@ __global__ void __launch_bounds__(256) k_dwk_bwd_lds(lhn_view x, const float* __
             sdux += du * ((raw - tmi[c4]) * tmi[8 + c4]);
           }
           if (dx && cok) {
+            // (issuing these loads for all four rows BEFORE the tap loops -- one memory latency per tile instead of four -- was
+            // measured: 2 more spilled registers in the BNS instance and variant B 8.19 -> 8.29 ms per step; not kept)
             float* o = dx + ((size_t)(n * x.H + pa + ps * hh) * x.W + pb + ps * wcol) * x.cstride + cx;
             if (dx_acc) accx += *reinterpret_cast<const f4*>(o);
             if (bs.add[0]) accx += *reinterpret_cast<const f4*>(bs.add[0] + (o - dx));
