@@ -2,7 +2,7 @@
 parameter gradients and buffers agree bit for bit.  With LHN_DETERMINISTIC=1 they must (exit code 3 otherwise); without it
 the script only reports (atomics make the last bits order-dependent).  Used by tests/test_train_gpu.py."""
 import os, sys, hashlib
-ROOT = os.environ.get("LHN_REPO") or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.environ.get("LHN_REPO") or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))      # (tests/: may import the oracle's input generators)
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from litehandnet_amd import _lib, get_loss, get_model

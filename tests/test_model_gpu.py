@@ -513,7 +513,7 @@ def test_hipgraph_replay_matches_plain_launches(dev):
     res = {}
     for mode in ("0", "1"):
         env = dict(os.environ, LHN_GRAPH=mode)
-        out = subprocess.run([sys.executable, os.path.join(root, "scripts", "check_graph.py")], env=env, capture_output=True,
+        out = subprocess.run([sys.executable, os.path.join(root, "tests", "check_graph.py")], env=env, capture_output=True,
                              text=True, timeout=300)
         assert out.returncode == 0, out.stderr[-2000:]
         line = [l for l in out.stdout.splitlines() if l.startswith("CHECK")][0]

@@ -390,13 +390,40 @@ def test_run_to_run_spread(dev):
 def test_deterministic_mode_is_bit_reproducible(dev):
     """LHN_DETERMINISTIC=1 (include/lhn.h: lhn_deterministic): two runs of the same two training steps -- outputs, loss,
     every parameter gradient, every running statistic, dropout on -- agree BIT FOR BIT for variants B, A, mynet, Lite-HRNet
-    and the stacked hourglass (scripts/check_determinism.py; without the switch the same script reports a mismatch for every one).
+    and the stacked hourglass (tests/check_determinism.py; without the switch the same script reports a mismatch for every one).
     The switch is read once per process, so the check runs in a child process (started before it touches the GPU)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, LHN_DETERMINISTIC="1", LHN_REPO=root)
-    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "check_determinism.py")], env=env, capture_output=True, text=True,
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "check_determinism.py")], env=env, capture_output=True, text=True,
                        timeout=900)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
     assert "DET" in r.stdout and "False" not in r.stdout.split("DET")[1]
+
+
+def test_fused_finalize_agrees_with_separate_finalize(dev, tmp_path):
+    """LHN_FUSE_FINALIZE=1 (include/lhn.h: lhn_bnfin -- the last workgroup of a convolution writes the BatchNorm table; two-level
+    arrival tickets, block-wide replica fold) against the default separate finalize launch: two training steps of variant B,
+    outputs, loss, every gradient and every running statistic.  Same sums, another fold order: fp32-level agreement.  The
+    switch is read once per process, so both runs are child processes."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = []
+    for mode in ("0", "1"):
+        out = str(tmp_path / f"fin{mode}.npz")
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "finalize_child.py"), out], env=dict(os.environ, LHN_FUSE_FINALIZE=mode),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+        res.append(np.load(out))
+    a, b = res
+    assert set(a.files) == set(b.files)
+    gmax = max(float(np.linalg.norm(a[k])) for k in a.files if k.startswith("g0."))
+    for k in a.files:
+        x, y = a[k].astype(np.float64), b[k].astype(np.float64)
+        if k.startswith("g"):
+            assert np.linalg.norm(x - y) <= 1e-4 * (np.linalg.norm(x) + 1e-3 * gmax), k
+        else:
+            assert np.abs(x - y).max() <= 1e-5 * (np.abs(x).max() + 1e-12), k
+
