@@ -82,6 +82,17 @@ typedef struct lhn_bnsum {
   const float* save;
   int32_t      C, coff;
 } lhn_bnsum;
+/* Gradient contributions of OTHER readers of x that join the store of lhn_maxpool2_bwd3 (the hourglass skip tensor is read by
+ * a 2x2 max-pool, an adaptive average pool and a plain sum: litehourglass.py:139-163, pose_hg_ms_att.py -- three read-modify-write
+ * passes over its gradient otherwise).  same: gradient of a sum that reads x at its own resolution with coefficient 1 and no
+ * activation behind it (x's geometry); pooled: gradient of adaptive_avg_pool2d(x, (OH, OW)) as [N][OH][OW][pooled_cstride].
+ * Either may be NULL.  x.H and x.W must be even (every pixel of x sits in one pooling window). */
+typedef struct lhn_grad_adds {
+  const float* same;
+  int32_t      same_cstride, same_coff;
+  const float* pooled;
+  int32_t      OH, OW, pooled_cstride, pooled_coff;
+} lhn_grad_adds;
 
 int         lhn_version(void);
 /* 1 when the library runs in its deterministic mode (environment LHN_DETERMINISTIC=1, read once): every cross-workgroup sum
@@ -384,6 +395,8 @@ int lhn_maxpool2_bwd(const lhn_view* x, const lhn_view* y, const float* dy, floa
 /* the same readers' backward kernels, also adding their part of the producer's BatchNorm-backward sums (lhn_bnsum; NULL = plain) */
 int lhn_maxpool2_bwd2(const lhn_view* x, const lhn_view* y, const float* dy, float* dx, int dx_accumulate, const lhn_bnsum* bns,
                       void* stream);
+int lhn_maxpool2_bwd3(const lhn_view* x, const lhn_view* y, const float* dy, float* dx, int dx_accumulate, const lhn_bnsum* bns,
+                      const lhn_grad_adds* adds /*or NULL*/, void* stream);
 int lhn_ew_bwd3(const lhn_view* src, const lhn_view* dst, const float* ddst, const float* dst_dpool, float out_slope, float* dsrc,
                 int accumulate, const lhn_bnsum* bns, void* stream);
 int lhn_avgpool_bwd3(const lhn_view* x, const float* dout, int OH, int OW, int out_cstride, int out_coff, float* dx,

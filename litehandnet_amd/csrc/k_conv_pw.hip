@@ -433,8 +433,8 @@ k_pw_fwd_wr(lhn_view x, const float* __restrict__ w, const float* __restrict__ b
           const int m = mbase + (r & 3) + 8 * (r >> 2);
           if (m < M) {
             float v = acc[r] + bv;
-            if (CIN < 256 && yacc) v += yo[(int64_t)m * y.cstride];       // second K slice of a wide input (LHN_PW_K256=0): statistics see the sum
-                                                                   // (never with K = 256 in one pass: no load -- and no vmcnt(0) -- in that instance's loop)
+            if (yacc) v += yo[(int64_t)m * y.cstride];       // second K slice of a wide input (LHN_PW_K256=0), or the data gradient of a
+                                                             // 256-feature convolution accumulating into dx (lhn_pw_dgrad_wr): statistics see the sum
             yo[(int64_t)m * y.cstride] = v;
             ts.add(v);
           }

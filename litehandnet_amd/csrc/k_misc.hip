@@ -343,8 +343,10 @@ __global__ void __launch_bounds__(256) k_maxpool2_fwd(lhn_view x, lhn_view y) {
 // gradient goes to the first window element (scan order) holding the max.  One thread per OUTPUT element
 // re-evaluates its 2x2 window (every input pixel belongs to exactly one window), so the comparison never
 // depends on two kernels rounding the pending transform identically.
+// ADD: the gradients of other readers of x (lhn_grad_adds) join the same store -- one pass over d(x) instead of three
+template <bool ADD>
 __global__ void __launch_bounds__(256) k_maxpool2_bwd(lhn_view x, lhn_view y, const float* __restrict__ dy,
-                                                      float* __restrict__ dx, int accumulate, lhn_bnsum bs) {
+                                                      float* __restrict__ dx, int accumulate, lhn_bnsum bs, lhn_grad_adds ad) {
   __shared__ f4 bred[512];
   const int C4 = y.C >> 2, c4 = threadIdx.x % C4, pl = threadIdx.x / C4, PL = 256 / C4;
   const int ca = x.coff + 4 * c4;
@@ -380,6 +382,22 @@ __global__ void __launch_bounds__(256) k_maxpool2_bwd(lhn_view x, lhn_view y, co
         const int ih = 2 * ho + (o >> 1), iw = 2 * wo + (o & 1);
         if (ih < x.H && iw < x.W) {
           f4 r = (f4){arg[0] == o ? g.x : 0.f, arg[1] == o ? g.y : 0.f, arg[2] == o ? g.z : 0.f, arg[3] == o ? g.w : 0.f};
+          if (ADD) {
+            if (ad.same) r += *reinterpret_cast<const f4*>(ad.same + ((size_t)(n * x.H + ih) * x.W + iw) * ad.same_cstride + ad.same_coff + 4 * c4);
+            if (ad.pooled) {      // the bins of lhn_avgpool_bwd that contain (ih, iw)
+              const int OH = ad.OH, OW = ad.OW, ohc = (ih * OH) / x.H, owc = (iw * OW) / x.W;
+              for (int oh = max(ohc - 1, 0); oh <= min(ohc + 1, OH - 1); ++oh) {
+                const int h0 = (oh * x.H) / OH, h1 = ((oh + 1) * x.H + OH - 1) / OH;
+                if (ih < h0 || ih >= h1) continue;
+                for (int ow = max(owc - 1, 0); ow <= min(owc + 1, OW - 1); ++ow) {
+                  const int w0 = (ow * x.W) / OW, w1 = ((ow + 1) * x.W + OW - 1) / OW;
+                  if (iw < w0 || iw >= w1) continue;
+                  const float inv = 1.f / (float)((h1 - h0) * (w1 - w0));
+                  r += *reinterpret_cast<const f4*>(ad.pooled + ((size_t)(n * OH + oh) * OW + ow) * ad.pooled_cstride + ad.pooled_coff + 4 * c4) * inv;
+                }
+              }
+            }
+          }
           float* q = dx + ((size_t)(n * x.H + ih) * x.W + iw) * x.cstride + ca;
           if (bs.sums) {
             const f4 du = r * lhn_dact_xf(raws[o], xf);
@@ -1240,11 +1258,28 @@ int lhn_maxpool2_bwd(const lhn_view* x, const lhn_view* y, const float* dy, floa
 }
 int lhn_maxpool2_bwd2(const lhn_view* x, const lhn_view* y, const float* dy, float* dx, int dx_accumulate, const lhn_bnsum* bns,
                       void* stream) {
+  return lhn_maxpool2_bwd3(x, y, dy, dx, dx_accumulate, bns, nullptr, stream);
+}
+int lhn_maxpool2_bwd3(const lhn_view* x, const lhn_view* y, const float* dy, float* dx, int dx_accumulate, const lhn_bnsum* bns,
+                      const lhn_grad_adds* adds, void* stream) {
   LHN_CHECK_ARG(lhn_view_ok(x) && lhn_view_ok(y) && dy && dx && x->C == y->C && lhn_no_pend(x), "lhn_maxpool2_bwd: bad args");
   LHN_CHECK_ARG(y->C % 4 == 0 && y->C <= 1024, "lhn_maxpool2_bwd: C=%d", y->C);
   lhn_bnsum bs;
   if (bns_of(bns, x, &bs, "lhn_maxpool2_bwd2")) return 1;
-  hipLaunchKernelGGL(k_maxpool2_bwd, dim3(grid_cap((int64_t)y->N * y->H, 8)), dim3(256), 0, (hipStream_t)stream, *x, *y, dy, dx, dx_accumulate, bs);
+  lhn_grad_adds ad;
+  memset(&ad, 0, sizeof(ad));
+  if (adds && (adds->same || adds->pooled)) {
+    ad = *adds;
+    LHN_CHECK_ARG(x->H % 2 == 0 && x->W % 2 == 0 && y->H == x->H / 2 && y->W == x->W / 2, "lhn_maxpool2_bwd3: gradient addends need even H, W (%dx%d)", x->H, x->W);
+    LHN_CHECK_ARG(!ad.same || (ad.same_cstride % 4 == 0 && ad.same_coff % 4 == 0 && ad.same_coff >= 0 && ad.same_coff + x->C <= ad.same_cstride),
+                  "lhn_maxpool2_bwd3: same-resolution addend layout");
+    LHN_CHECK_ARG(!ad.pooled || (ad.OH > 0 && ad.OW > 0 && ad.OH <= x->H && ad.OW <= x->W && ad.pooled_cstride % 4 == 0 && ad.pooled_coff % 4 == 0 &&
+                                 ad.pooled_coff >= 0 && ad.pooled_coff + x->C <= ad.pooled_cstride),
+                  "lhn_maxpool2_bwd3: pooled addend layout");
+    hipLaunchKernelGGL(k_maxpool2_bwd<true>, dim3(grid_cap((int64_t)y->N * y->H, 8)), dim3(256), 0, (hipStream_t)stream, *x, *y, dy, dx, dx_accumulate, bs, ad);
+  } else {
+    hipLaunchKernelGGL(k_maxpool2_bwd<false>, dim3(grid_cap((int64_t)y->N * y->H, 8)), dim3(256), 0, (hipStream_t)stream, *x, *y, dy, dx, dx_accumulate, bs, ad);
+  }
   LHN_CHECK_LAUNCH("lhn_maxpool2_bwd");
   return 0;
 }

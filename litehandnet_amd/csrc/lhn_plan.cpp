@@ -520,8 +520,22 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
         lhn_view x = mkview(P, ws, o.in_buf[0], o.in_coff[0], o.in_C[0]);
         lhn_view y = mkview(P, ws, o.out_buf, o.out_coff, o.out_C);
         const lhn_bnsum bs = mkbns(ws, o.ws[0], o.ws[1], o.i[4], o.i[5]);
-        rc = lhn_maxpool2_bwd2(&x, &y, reinterpret_cast<const float*>(at(ws, P->bufs[o.out_buf].grad_off)),
-                               reinterpret_cast<float*>(at(ws, P->bufs[o.in_buf[0]].grad_off)), o.i[0], bs.sums ? &bs : nullptr, stream);
+        // ws[2] / i[1], i[2]: gradient of a plain sum that also reads x (base, pixel stride, first channel); ws[3] / i[3], i[6], i[7]:
+        // gradient of an adaptive average pool of x (base, pixel stride, first channel, OH << 16 | OW) -- lhn_grad_adds
+        lhn_grad_adds ad;
+        memset(&ad, 0, sizeof(ad));
+        if (o.ws[2] >= 0) {
+          ad.same = reinterpret_cast<const float*>(at(ws, o.ws[2]));
+          ad.same_cstride = o.i[1]; ad.same_coff = o.i[2];
+        }
+        if (o.ws[3] >= 0) {
+          ad.pooled = reinterpret_cast<const float*>(at(ws, o.ws[3]));
+          ad.pooled_cstride = o.i[3]; ad.pooled_coff = o.i[6];
+          ad.OH = o.i[7] >> 16; ad.OW = o.i[7] & 0xffff;
+        }
+        rc = lhn_maxpool2_bwd3(&x, &y, reinterpret_cast<const float*>(at(ws, P->bufs[o.out_buf].grad_off)),
+                               reinterpret_cast<float*>(at(ws, P->bufs[o.in_buf[0]].grad_off)), o.i[0], bs.sums ? &bs : nullptr,
+                               (ad.same || ad.pooled) ? &ad : nullptr, stream);
         break;
       }
       case OP_AVGPOOL_BWD: {

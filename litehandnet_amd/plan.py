@@ -845,6 +845,47 @@ class PlanBuilder:
                     return (-1, -1), (0, 0)
                 P, off = e
                 return (self._abs(P["sums"]), self._abs(P["save"])), (P["out"].C, off)
+            # ---- readers of one tensor whose gradients meet in ONE store (lhn_grad_adds): a 2x2 max-pool, an adaptive average pool
+            # and a plain same-resolution sum reading the same view (the skip tensor of an hourglass level, litehourglass.py:139-163)
+            # -- the max-pool's backward, which runs last, takes the other two gradients on the way (LHN_POOL_GRAD_ADDS=0: three
+            # read-modify-write passes over d(x) as before)
+            fused_mp, skip_ew_src, skip_ap = {}, set(), set()
+            if os.environ.get("LHN_POOL_GRAD_ADDS", "1") != "0":
+                order = {id(q): i for i, q in enumerate(self.recs)}
+                for mp in self.recs:
+                    if mp["op"] != MAXPOOL or isinstance(mp["x"], TCat) or mp["x"].H % 2 or mp["x"].W % 2 or mp["x"].buf == self._no_grad_buf:
+                        continue
+                    X = mp["x"]
+
+                    def same(t, X=X):
+                        return not isinstance(t, TCat) and t.buf == X.buf and t.coff == X.coff and t.C == X.C
+                    ap = next((q for q in self.recs if q["op"] == AVGPOOL and "OH" in q and same(q["x"]) and order[id(q)] > order[id(mp)]
+                               and id(q) not in skip_ap), None)
+                    ew = None
+                    for q in self.recs:
+                        if q["op"] != EW or q.get("lazy") or q.get("fwd_fused") or "flat" in q or q.get("mode") or q.get("coefs") is not None:
+                            continue
+                        if order[id(q)] < order[id(mp)] or float(q["slope"]) != 1.0 or isinstance(q["out"], TCat):
+                            continue
+                        ob = self.bufs[q["out"].buf]
+                        idx = [j for j, t in enumerate(q["srcs"]) if same(t)]
+                        if ob.gate or ob.dpool or len(idx) != 1 or (q["srcs"][idx[0]].H, q["srcs"][idx[0]].W) != (q["out"].H, q["out"].W):
+                            continue
+                        if (id(q), idx[0]) in skip_ew_src or any(a[0] == id(q) for a in pending_add.get(X.buf, ())):
+                            continue
+                        ew = (q, idx[0])
+                        break
+                    if ap is None and ew is None:
+                        continue
+                    keys = [bns_of(mp, X)] + ([bns_of(ap, X)] if ap else []) + ([bns_of(ew[0], X)] if ew else [])
+                    if any(kk != keys[0] for kk in keys):      # the producer's BatchNorm sums: all of x's readers or none
+                        continue
+                    fused_mp[id(mp)] = (ew, ap)
+                    if ew:
+                        skip_ew_src.add((id(ew[0]), ew[1]))
+                    if ap:
+                        skip_ap.add(id(ap))
+            self.pool_grad_adds = len(fused_mp)
             for r in reversed(self.recs):
                 k = r["op"]
                 if k in (STEM, PW, DW, KXK, EW, SHUFFLE, MAXPOOL, AVGPOOL) and not (k == PW and r.get("nchw")) and \
@@ -924,9 +965,11 @@ class PlanBuilder:
                         else:
                             body.append(mk(EW_BWD, ins=(s,), out=r["out"], i=(acc,), f=(r["slope"],)))
                 elif k == EW:
-                    for s in r["srcs"]:
+                    for j, s in enumerate(r["srcs"]):
                         if s.buf == self._no_grad_buf or (s.buf in aliased and self.bufs[s.buf].off["grad"] == self.bufs[r["out"].buf].off["grad"]):
                             continue
+                        if (id(r), j) in skip_ew_src:
+                            continue                # d(out) joins s's gradient inside the max-pool backward that reads s (fused_mp)
                         if any(a[0] == id(r) for a in pending_add.get(s.buf, ())):
                             continue                # d(out) joins s's gradient inside the depthwise backward kernels that read s
                         mode = self._grad_mode(written, s)
@@ -939,8 +982,19 @@ class PlanBuilder:
                 elif k == MAXPOOL:
                     mode = self._grad_mode(written, r["x"])
                     bw, bc = bns_of(r, r["x"])
-                    body.append(mk(MAXPOOL_BWD, ins=(r["x"],), out=r["out"], ws=bw, i=(1 if mode == 2 else 0, 0, 0, 0, bc[0], bc[1])))
+                    ew, ap = fused_mp.get(id(r), (None, None))
+                    sw, si, pw_, pi = -1, (0, 0), -1, (0, 0, 0)
+                    if ew is not None:
+                        eo = ew[0]["out"]
+                        sw, si = self.bufs[eo.buf].off["grad"], (self.bufs[eo.buf].C, eo.coff)
+                    if ap is not None:
+                        ob = self.bufs[ap["out"].buf]
+                        pw_, pi = ob.off["grad"], (ob.C, ap["out"].coff, (ap["OH"] << 16) | ap["OW"])
+                    body.append(mk(MAXPOOL_BWD, ins=(r["x"],), out=r["out"], ws=bw + (sw, pw_),
+                                   i=(1 if mode == 2 else 0, si[0], si[1], pi[0], bc[0], bc[1], pi[1], pi[2])))
                 elif k == AVGPOOL:
+                    if id(r) in skip_ap:
+                        continue                    # its gradient joins d(x) inside the max-pool backward (fused_mp)
                     mode = self._grad_mode(written, r["x"])
                     ob = self.bufs[r["out"].buf]
                     bw, bc = bns_of(r, r["x"])
