@@ -105,10 +105,12 @@ static lhn_bnfin mkfin(const Plan* P, void* ws, const lhn_op& o, void* const* pa
   f.conv_bias = prm<const float>(params, o.p[1]);   // biased conv + BN: the bias lives in the finalize only
   return f;
 }
-// LHN_FUSE_FINALIZE: the last workgroup of a convolution folds the statistics and writes the table (lhn_bnfin) instead of a
-// separate 1-workgroup launch.  Round 1 measured it SLOWER (one returning ticket atomic per workgroup on one word, ~88 tickets
-// per us: 13.5 vs 12.9 ms per step of variant B); round 3 takes the tickets in two levels (32 group words + 1 top word) and
-// folds the replicas with the whole block, see lhn_last_block / lhn_bn_finalize_block_par.
+// LHN_FUSE_FINALIZE=1 (default 0): the last workgroup of a convolution folds the statistics and writes the table (lhn_bnfin) instead
+// of a separate 1-workgroup launch.  Round 1 measured it SLOWER (one returning ticket atomic per workgroup on one word, ~88 tickets
+// per us: 13.5 vs 12.9 ms per step of variant B); round 3 takes the tickets in two levels (32 group words + 1 top word) and folds
+// the replicas with the whole block (lhn_last_block / lhn_bn_finalize_block_par).  Same box, alternating: variant B forward 2.550 ->
+// 2.542 ms (97 instead of 149 launches), step 8.05 -> 8.06; Lite-HRNet step 35.85 -> 36.61; A 19.30 -> 19.42.  A finalize is its
+// latency chain either way, so the separate launch stays the default.  Whole-plan runs only (SyncBatchNorm splits the op).
 static bool fuse_finalize() {
   static int v = -1;
   if (v < 0) {
