@@ -423,6 +423,9 @@ typedef struct lhn_bn_slices {
 } lhn_bn_slices;
 int lhn_gate_bwd_reduce2(const lhn_view* y, const float* dz, float* dgate /*[3][N][C]: dgate | tsum*/, float* tsum,
                          const lhn_bn_slices* slices, void* stream);
+/* prezeroed != 0: dgate (and tsum) are already zero (the caller zeroes many such buffers with one memset) */
+int lhn_gate_bwd_reduce3(const lhn_view* y, const float* dz, float* dgate, float* tsum, const lhn_bn_slices* slices, int prezeroed,
+                         void* stream);
 int lhn_avgpool_fwd3(const lhn_view* x, float* out /*[N,OH,OW,C]*/, int OH, int OW, float* pstat /*[N*OH*OW][2][C] or NULL*/,
                      const lhn_bn_slices* slices, void* stream);
 int lhn_ca_mlp_bwd2(const float* pooled, const float* w3, const float* gamma, const float* w1, const float* w2,

@@ -1387,13 +1387,19 @@ int lhn_gate_bwd_reduce(const lhn_view* y, const float* dz, float* dgate, void* 
   return lhn_gate_bwd_reduce2(y, dz, dgate, nullptr, nullptr, stream);
 }
 int lhn_gate_bwd_reduce2(const lhn_view* y, const float* dz, float* dgate, float* tsum, const lhn_bn_slices* slices, void* stream) {
+  return lhn_gate_bwd_reduce3(y, dz, dgate, tsum, slices, 0, stream);
+}
+int lhn_gate_bwd_reduce3(const lhn_view* y, const float* dz, float* dgate, float* tsum, const lhn_bn_slices* slices, int prezeroed,
+                         void* stream) {
   LHN_CHECK_ARG(lhn_view_ok(y) && dz && dgate && y->C % 4 == 0 && y->C <= 1024 && lhn_no_pend(y), "lhn_gate_bwd_reduce: bad args");
   LHN_CHECK_ARG(!tsum || (y->coff == 0 && y->C == y->cstride && tsum == dgate + (size_t)y->N * y->C),
                 "lhn_gate_bwd_reduce2: tsum = the 2*N*C floats behind dgate, whole-buffer view");
   hipStream_t s = (hipStream_t)stream;
   BnSlices sl;
   if (mk_slices(tsum ? slices : nullptr, y->C, &sl, "lhn_gate_bwd_reduce2")) return 1;
-  if (hipMemsetAsync(dgate, 0, (size_t)y->N * y->C * 4 * (tsum ? 3 : 1), s) != hipSuccess) {
+  // (prezeroed: the caller zeroed dgate / tsum already -- the plan keeps them in the arena its backward zeroes with ONE memset;
+  // eight attentions of variant B cost eight 4.8 us fill launches per step otherwise)
+  if (!prezeroed && hipMemsetAsync(dgate, 0, (size_t)y->N * y->C * 4 * (tsum ? 3 : 1), s) != hipSuccess) {
     lhn_set_error("lhn_gate_bwd_reduce: memset failed");
     return 2;
   }

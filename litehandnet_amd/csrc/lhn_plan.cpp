@@ -560,8 +560,9 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
         lhn_view y = mkview(P, ws, o.out_buf, o.out_coff, o.out_C, false);
         float* dg = reinterpret_cast<float*>(at(ws, o.ws[3]));
         const lhn_bn_slices sl = mkslices(ws, &o.i[0], &o.ws[5], nullptr);
-        rc = lhn_gate_bwd_reduce2(&y, reinterpret_cast<const float*>(at(ws, P->bufs[o.out_buf].grad_off)), dg,
-                                  o.ws[4] >= 0 ? dg + (size_t)y.N * y.C : nullptr, &sl, stream);
+        // (dgate lives in the arena the backward zeroes with one memset: prezeroed)
+        rc = lhn_gate_bwd_reduce3(&y, reinterpret_cast<const float*>(at(ws, P->bufs[o.out_buf].grad_off)), dg,
+                                  o.ws[4] >= 0 ? dg + (size_t)y.N * y.C : nullptr, &sl, 1, stream);
         break;
       }
       case OP_CA_MLP_BWD: {

@@ -407,7 +407,7 @@ class PlanBuilder:
                 rec["copy"] = q
         if self.with_backward:
             rec["gsum_b"] = self._ws("misc", 2 * Cc * 8)
-            rec["dgate"] = self._ws("misc", 3 * self.N * Cc * 4)       # dgate | T0, T1 of the gate-gradient pass (bnslices)
+            rec["dgate"] = self._ws("zb", 3 * self.N * Cc * 4)         # dgate | T0, T1 of the gate-gradient pass (bnslices); zeroed with the arena
             b.dpool = True
             # BatchNorm-backward sums of the convolutions that wrote this buffer: assembled by the attention's backward from the
             # gate-gradient pass and the forward pooling pass (include/lhn.h: lhn_bn_slices) -- their lhn_bn_bwd_reduce passes
@@ -435,7 +435,7 @@ class PlanBuilder:
                    mask=self._ws("mask", self.N * Cc * 4) if self.p_drop > 0 else None, gsum=self._ws("misc", 2 * Cc * 8))
         if self.with_backward:
             rec["gsum_b"] = self._ws("misc", 2 * Cc * 8)
-            rec["dgate"] = self._ws("misc", self.N * Cc * 4)
+            rec["dgate"] = self._ws("zb", self.N * Cc * 4)
             b.dpool = True
         self.recs.append(rec)
         b.gate = True
@@ -454,7 +454,7 @@ class PlanBuilder:
         rec = dict(op=SE_MLP, y=y, se=se, down=down, up=up, mode=int(mode), J=J, pooled=self._ws("misc", self.N * Cc * 4),
                    save=self._ws("misc", self.N * (J + Cc) * 4))
         if self.with_backward:
-            rec["dgate"] = self._ws("misc", self.N * Cc * 4)
+            rec["dgate"] = self._ws("zb", self.N * Cc * 4)
             b.dpool = True
         self.recs.append(rec)
         b.gate = True
