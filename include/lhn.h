@@ -444,6 +444,12 @@ int lhn_ca_mlp_bwd(const float* pooled, const float* w3, const float* gamma, con
                    float* db1, float* dw2, float* db2, int N, int C, int stage, double* gsum, double count_scale,
                    float pgrad_scale, void* stream);
 
+/* torch.optim.Adam (no amsgrad) over one flat fp32 parameter buffer -- the optimizer of dist_train.py:64-69 for the flat parameter
+ * of litehandnet_amd.train.FlatParams: exp_avg / exp_avg_sq are the optimizer state of that one tensor, step = the 1-based count of
+ * this update.  Buffers 16-byte aligned. */
+int lhn_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr, double beta1,
+                  double beta2, double eps, double weight_decay, int64_t step, void* stream);
+
 /* ---------------------------------------------------------------- plan executor
  * A plan is a static list of the calls above over one workspace arena, built by the Python
  * mirror of the reference's nn.Module tree (models/__init__.py:20-26 get_model).  One

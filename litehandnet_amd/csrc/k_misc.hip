@@ -1467,3 +1467,53 @@ int lhn_bn_bwd_finalize2(const double* sums, const float* gamma, const float* sa
   return 0;
 }
 }  // extern "C"
+
+// ------------------------------------------------------------------ Adam over ONE flat parameter buffer
+// torch.optim.Adam (dist_train.py:64-69: Adam, default betas / eps, no weight decay, no amsgrad) in the arithmetic order of
+// torch's single-tensor form:  m = m + (1 - b1) (g - m);  v = b2 v + (1 - b2) g g;  p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps).
+// torch's fused kernel walks a single tensor in 65,536-element chunks, one workgroup each: 5 workgroups and 41 us for the 289 k
+// parameters of variant B; this is a plain streaming kernel.
+__global__ void __launch_bounds__(256) k_adam_flat(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, int64_t n4, int64_t n, float omb1, float b2, float omb2,
+                                                   float eps, float wd, float step_size, float bc2_sqrt) {
+  // omb1 = 1 - beta1, omb2 = 1 - beta2 rounded from the DOUBLE difference, as torch forms them (1 - 0.999f is 4.7e-5 off 0.001)
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    f4 pp = *reinterpret_cast<const f4*>(p + 4 * i), gg = *reinterpret_cast<const f4*>(g + 4 * i);
+    f4 mm = *reinterpret_cast<const f4*>(m + 4 * i), vv = *reinterpret_cast<const f4*>(v + 4 * i);
+    if (wd != 0.f) gg += pp * wd;
+    mm += (gg - mm) * omb1;
+    vv = vv * b2 + gg * gg * omb2;
+    const f4 den = (f4){sqrtf(vv.x) / bc2_sqrt + eps, sqrtf(vv.y) / bc2_sqrt + eps, sqrtf(vv.z) / bc2_sqrt + eps, sqrtf(vv.w) / bc2_sqrt + eps};
+    pp -= (f4){mm.x / den.x, mm.y / den.y, mm.z / den.z, mm.w / den.w} * step_size;
+    *reinterpret_cast<f4*>(p + 4 * i) = pp;
+    *reinterpret_cast<f4*>(m + 4 * i) = mm;
+    *reinterpret_cast<f4*>(v + 4 * i) = vv;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {      // tail (n % 4 elements)
+    const int64_t i = 4 * n4 + threadIdx.x;
+    float gg = g[i];
+    if (wd != 0.f) gg += p[i] * wd;
+    const float mm = m[i] + (gg - m[i]) * omb1, vv = v[i] * b2 + gg * gg * omb2;
+    p[i] -= mm / (sqrtf(vv) / bc2_sqrt + eps) * step_size;
+    m[i] = mm;
+    v[i] = vv;
+  }
+}
+
+extern "C" int lhn_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr, double beta1,
+                             double beta2, double eps, double weight_decay, int64_t step, void* stream) {
+  LHN_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && n > 0 && step >= 1, "lhn_adam_step: null pointer / n / step");
+  LHN_CHECK_ARG(((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(exp_avg) |
+                  reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15) == 0, "lhn_adam_step: buffers must be 16-byte aligned");
+  const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);      // python floats in torch
+  const int64_t n4 = n / 4;
+  int64_t grid = (n4 + 255) / 256;
+  const int64_t cap = (int64_t)lhn_num_cus() * 8;
+  if (grid > cap) grid = cap;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(k_adam_flat, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n4, n, (float)(1.0 - beta1),
+                     (float)beta2, (float)(1.0 - beta2), (float)eps, (float)weight_decay, (float)(lr / bc1), (float)sqrt(bc2));
+  LHN_CHECK_LAUNCH("lhn_adam_step");
+  return 0;
+}
+

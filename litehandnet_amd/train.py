@@ -5,6 +5,7 @@ MI355X-first differences: parameters and gradients live in two flat fp32 buffers
 Adam over the flat parameter, and data parallelism is ONE RCCL all-reduce of the flat gradient (SUM, then
 divide by world) instead of DDP's bucketed reducer -- same arithmetic as DistributedDataParallel.
 """
+import ctypes as C
 import os
 
 import torch
@@ -101,6 +102,46 @@ def allreduce_mean_(flat_grads, group=None):
     return flat_grads
 
 
+class FlatAdam(torch.optim.Adam):
+    """torch.optim.Adam whose step() is ONE launch of lhn_adam_step per (flat, contiguous fp32, GPU) parameter.  The state layout is
+    torch's own ({"step": tensor, "exp_avg", "exp_avg_sq"} per parameter, `step` a CPU scalar tensor as in torch's default form),
+    so `state_dict()` / `load_state_dict()` interchange with the reference's `torch.optim.Adam` (dist_train.py:64-69).
+    amsgrad / maximize / complex parameters are not supported (the reference uses none)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False, foreach=False, fused=False)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        L = _lib.lib()
+        for group in self.param_groups:
+            if group.get("amsgrad") or group.get("maximize"):
+                raise _lib.LhnError("FlatAdam: amsgrad / maximize are not built")
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                g = p.grad
+                if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and g.is_contiguous() and g.dtype == torch.float32):
+                    raise _lib.LhnError("FlatAdam: parameters and gradients must be contiguous fp32 GPU tensors")
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = torch.tensor(0.0)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] += 1
+                lr = group["lr"]
+                _lib.check(L.lhn_adam_step(_lib.ptr(p), _lib.ptr(g), _lib.ptr(st["exp_avg"]), _lib.ptr(st["exp_avg_sq"]),
+                                           C.c_int64(p.numel()), C.c_double(float(lr)), C.c_double(float(b1)), C.c_double(float(b2)),
+                                           C.c_double(float(group["eps"])), C.c_double(float(group["weight_decay"])),
+                                           C.c_int64(int(st["step"].item())), _lib.stream()), "lhn_adam_step")
+        return loss
+
+
 class Trainer:
     """step(img, meta): forward -> criterion -> zero_grad -> backward -> [all-reduce] -> Adam step
     (topdown_trainer.py:70-81).  Loss values stay on the device (no per-step .item())."""
@@ -123,7 +164,9 @@ class Trainer:
         self.world = world_size
         lr = lr * world_size                           # dist_train.py:68
         if optimizer.lower() == "adam":
-            self.opt = torch.optim.Adam([self.fp.leaf], lr=lr, fused=True)
+            # (LHN_TORCH_ADAM=1: torch's fused Adam -- 41 us per step for variant B's 289 k parameters against 5 for lhn_adam_step)
+            self.opt = torch.optim.Adam([self.fp.leaf], lr=lr, fused=True) if os.environ.get("LHN_TORCH_ADAM") == "1" \
+                else FlatAdam([self.fp.leaf], lr=lr)
         else:
             self.opt = torch.optim.SGD([self.fp.leaf], lr=lr, momentum=0.9)
         self.loss_sum = torch.zeros((), device=self.fp.flat.device)

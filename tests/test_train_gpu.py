@@ -427,3 +427,31 @@ def test_fused_finalize_agrees_with_separate_finalize(dev, tmp_path):
         else:
             assert np.abs(x - y).max() <= 1e-5 * (np.abs(x).max() + 1e-12), k
 
+
+def test_flat_adam_matches_torch_adam(dev):
+    """lhn_adam_step / train.FlatAdam against torch.optim.Adam on the CPU (the reference's optimizer, dist_train.py:64-69): eight
+    steps on seeded gradients, parameters and both moments within fp32 rounding; the state dictionaries interchange; weight decay
+    and a length that is not a multiple of 4 included."""
+    from litehandnet_amd.train import FlatAdam
+    for n, wd in ((289_813, 0.0), (1001, 1e-2)):
+        g0 = torch.Generator().manual_seed(n)
+        p_ref = torch.nn.Parameter(torch.randn(n, generator=g0))
+        p_our = torch.nn.Parameter(p_ref.detach().clone().to(dev))
+        ref = torch.optim.Adam([p_ref], lr=5e-4, weight_decay=wd)
+        our = FlatAdam([p_our], lr=5e-4, weight_decay=wd)
+        for step in range(8):
+            g = torch.randn(n, generator=g0) * (10.0 ** (step % 3 - 1))
+            p_ref.grad, p_our.grad = g.clone(), g.clone().to(dev)
+            ref.step(); our.step()
+            if step == 3:      # state written by torch's Adam continues in ours and vice versa
+                sd_r, sd_o = ref.state_dict(), our.state_dict()
+                assert set(sd_r["state"][0]) == set(sd_o["state"][0]) and float(sd_r["state"][0]["step"]) == float(sd_o["state"][0]["step"]) == 4
+                our.load_state_dict({"state": {0: {k: (v.clone().to(dev) if k != "step" else v.clone()) for k, v in sd_r["state"][0].items()}},
+                                     "param_groups": sd_o["param_groups"]})
+                p_our.data.copy_(p_ref.data)
+        sr, so = ref.state[p_ref], our.state[p_our]
+        for a, b, name in ((p_ref.data, p_our.data, "param"), (sr["exp_avg"], so["exp_avg"], "exp_avg"), (sr["exp_avg_sq"], so["exp_avg_sq"], "exp_avg_sq")):
+            e = float((a.double() - b.cpu().double()).abs().max() / a.double().abs().max())
+            assert e < 2e-6, (n, name, e)
+        assert float(so["step"]) == 8
+
