@@ -399,6 +399,10 @@ int lhn_maxpool2_bwd3(const lhn_view* x, const lhn_view* y, const float* dy, flo
                       const lhn_grad_adds* adds /*or NULL*/, void* stream);
 int lhn_ew_bwd3(const lhn_view* src, const lhn_view* dst, const float* ddst, const float* dst_dpool, float out_slope, float* dsrc,
                 int accumulate, const lhn_bnsum* bns, void* stream);
+/* the same for 1..3 sources that all have dst's own geometry, in ONE pass over d(dst) / dst (residual sums); bns: per-source
+ * lhn_bnsum pointers or NULL */
+int lhn_ew_bwd_multi(const lhn_view* srcs, int nsrc, const lhn_view* dst, const float* ddst, const float* dst_dpool, float out_slope,
+                     float* const* dsrcs, const int* accumulate, const lhn_bnsum* const* bns, void* stream);
 int lhn_avgpool_bwd3(const lhn_view* x, const float* dout, int OH, int OW, int out_cstride, int out_coff, float* dx,
                      int dx_accumulate, const lhn_bnsum* bns, void* stream);
 int lhn_conv_pw_bwd3(const lhn_view* x, const float* w, const lhn_view* y, const lhn_gradview* gy, float* dx, int dx_accumulate,

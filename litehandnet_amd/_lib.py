@@ -49,7 +49,7 @@ SYMBOLS = [
     "lhn_conv_pw_fwd", "lhn_conv_pw_fwd2", "lhn_conv_pw_bwd2", "lhn_conv_dw_fwd", "lhn_conv_dw_fwd2", "lhn_conv_dw_fwd3", "lhn_conv_stem_fwd", "lhn_conv_kxk_fwd",
     "lhn_bn_finalize", "lhn_table_fill", "lhn_table_bias", "lhn_fold_bn", "lhn_ew_fwd", "lhn_ew_fwd2", "lhn_ew_fwd3", "lhn_ew_mul_bwd", "lhn_bilinear_bwd", "lhn_shuffle2_fwd", "lhn_shuffle2_bwd", "lhn_bn_finalize2", "lhn_bn_bwd_finalize2", "lhn_maxpool2_fwd", "lhn_avgpool_fwd", "lhn_avgpool_fwd2", "lhn_avgpool_bwd2", "lhn_se_mlp_fwd2", "lhn_se_mlp_bwd2", "lhn_ca_mlp_fwd", "lhn_att_mlp_fwd", "lhn_att_mlp_bwd", "lhn_se_mlp_fwd", "lhn_se_mlp_bwd",
     "lhn_bn_bwd_reduce", "lhn_bn_bwd_finalize", "lhn_conv_pw_bwd", "lhn_conv_dw_bwd", "lhn_conv_dw_bwd2", "lhn_conv_dw_bwd3", "lhn_conv_stem_bwd",
-    "lhn_conv_kxk_bwd", "lhn_ew_bwd", "lhn_ew_bwd2", "lhn_maxpool2_bwd", "lhn_maxpool2_bwd2", "lhn_maxpool2_bwd3", "lhn_ew_bwd3", "lhn_avgpool_bwd3", "lhn_conv_pw_bwd3", "lhn_avgpool_bwd", "lhn_gate_bwd_reduce", "lhn_gate_bwd_reduce2", "lhn_gate_bwd_reduce3", "lhn_adam_step", "lhn_avgpool_fwd3", "lhn_avgpool_fwd4", "lhn_ca_mlp_bwd2",
+    "lhn_conv_kxk_bwd", "lhn_ew_bwd", "lhn_ew_bwd2", "lhn_maxpool2_bwd", "lhn_maxpool2_bwd2", "lhn_maxpool2_bwd3", "lhn_ew_bwd3", "lhn_ew_bwd_multi", "lhn_avgpool_bwd3", "lhn_conv_pw_bwd3", "lhn_avgpool_bwd", "lhn_gate_bwd_reduce", "lhn_gate_bwd_reduce2", "lhn_gate_bwd_reduce3", "lhn_adam_step", "lhn_avgpool_fwd3", "lhn_avgpool_fwd4", "lhn_ca_mlp_bwd2",
     "lhn_ca_mlp_bwd", "lhn_reduce_replicas", "lhn_fold_stat_replicas", "lhn_plan_create", "lhn_plan_destroy", "lhn_plan_run", "lhn_plan_run_range",
 ]
 

@@ -314,6 +314,75 @@ __global__ void __launch_bounds__(256) k_ew_bwd_src(lhn_view src, lhn_view dst, 
   if (bs.sums) lhn_bns_flush(bs, bsum, bsq, C4, bred);
 }
 
+// The same for up to THREE sources of the destination's own resolution in one pass (residual sums: d(dst) * lrelu'(dst) is the
+// gradient of every one of them): d(dst) and dst are read once instead of once per source.
+struct EwBwdMulti {
+  int n;
+  lhn_view src[3];
+  float* dsrc[3];
+  int acc[3];
+  lhn_bnsum bs[3];
+};
+__global__ void __launch_bounds__(256) k_ew_bwd_multi(EwBwdMulti m, lhn_view dst, const float* __restrict__ ddst,
+                                                      const float* __restrict__ dst_dpool, float out_slope) {
+  __shared__ f4 bred[512];
+  const int C4 = dst.C >> 2, c4 = threadIdx.x % C4, pl = threadIdx.x / C4, PL = 256 / C4;
+  f4 bsum[3], bsq[3], bmean[3], binv[3];
+  Xf4 bxf[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    bsum[k] = bsq[k] = bmean[k] = binv[k] = (f4){0.f, 0.f, 0.f, 0.f};
+    if (k < m.n && m.bs[k].sums) {
+      bxf[k] = lhn_load_xf(m.src[k], m.src[k].coff + 4 * c4);
+      bmean[k] = *reinterpret_cast<const f4*>(m.bs[k].save + m.bs[k].coff + 4 * c4);
+      binv[k] = *reinterpret_cast<const f4*>(m.bs[k].save + m.bs[k].C + m.bs[k].coff + 4 * c4);
+    }
+  }
+  const int cd = dst.coff + 4 * c4;
+  const int rows = dst.N * dst.H;
+  for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+    const int n = row / dst.H, h = row - n * dst.H;
+    const f4 gate = dst.gate ? *reinterpret_cast<const f4*>(dst.gate + (size_t)n * dst.cstride + cd) : (f4){1.f, 1.f, 1.f, 1.f};
+    for (int w = LHN_LANE0(pl, PL); w < dst.W; w += PL) {
+      const size_t pix = (size_t)row * dst.W + w, pd = pix * dst.cstride + cd;
+      f4 e = *reinterpret_cast<const f4*>(ddst + pd) * gate;
+      if (dst_dpool) {
+        lhn_gradview gv{nullptr, dst_dpool, nullptr};
+        e += lhn_dpool_sum(gv, dst, n, h, w, cd);
+      }
+      if (out_slope != 1.f) {
+        const f4 o = *reinterpret_cast<const f4*>(dst.data + pd);
+        e.x *= o.x > 0.f ? 1.f : out_slope;
+        e.y *= o.y > 0.f ? 1.f : out_slope;
+        e.z *= o.z > 0.f ? 1.f : out_slope;
+        e.w *= o.w > 0.f ? 1.f : out_slope;
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        if (k < m.n) {
+          const size_t ps = pix * m.src[k].cstride + m.src[k].coff + 4 * c4;
+          f4 g = e;
+          if (m.bs[k].sums) {
+            const f4 raw = *reinterpret_cast<const f4*>(m.src[k].data + ps);
+            const f4 du = g * lhn_dact_xf(raw, bxf[k]);
+            bsum[k] += du;
+            bsq[k] += du * ((raw - bmean[k]) * binv[k]);
+          }
+          float* o = m.dsrc[k] + ps;
+          if (m.acc[k]) g += *reinterpret_cast<const f4*>(o);
+          *reinterpret_cast<f4*>(o) = g;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+    if (k < m.n && m.bs[k].sums) {
+      lhn_bns_flush(m.bs[k], bsum[k], bsq[k], C4, bred);
+      __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------ 2x2 stride-2 max pool (ceil_mode)
 __global__ void __launch_bounds__(256) k_maxpool2_fwd(lhn_view x, lhn_view y) {
   const int C4 = y.C >> 2, c4 = threadIdx.x % C4, pl = threadIdx.x / C4, PL = 256 / C4;
@@ -1241,6 +1310,29 @@ int lhn_ew_bwd3(const lhn_view* src, const lhn_view* dst, const float* ddst, con
   hipLaunchKernelGGL(k_ew_bwd_src, dim3(grid_cap((int64_t)src->N * src->H, 8)), dim3(256), 0, (hipStream_t)stream, *src, *dst, ddst,
                      dst_dpool, out_slope, dsrc, accumulate, bs);
   LHN_CHECK_LAUNCH("lhn_ew_bwd2");
+  return 0;
+}
+
+// up to three sources of dst's own resolution in one pass (see k_ew_bwd_multi)
+int lhn_ew_bwd_multi(const lhn_view* srcs, int nsrc, const lhn_view* dst, const float* ddst, const float* dst_dpool, float out_slope,
+                     float* const* dsrcs, const int* accumulate, const lhn_bnsum* const* bns, void* stream) {
+  LHN_CHECK_ARG(srcs && nsrc >= 1 && nsrc <= 3 && lhn_view_ok(dst) && ddst && dsrcs && accumulate && lhn_no_pend(dst), "lhn_ew_bwd_multi: bad args");
+  LHN_CHECK_ARG(out_slope != LHN_SLOPE_SILU && out_slope != LHN_SLOPE_RELU_SIGMOID, "lhn_ew_bwd_multi: SiLU / ReLU-sigmoid take lhn_ew_bwd3");
+  LHN_CHECK_ARG(dst->C % 4 == 0 && dst->C <= 1024, "lhn_ew_bwd_multi: C=%d", dst->C);
+  EwBwdMulti m;
+  memset(&m, 0, sizeof(m));
+  m.n = nsrc;
+  for (int k = 0; k < nsrc; ++k) {
+    const lhn_view* v = &srcs[k];
+    LHN_CHECK_ARG(lhn_view_ok(v) && lhn_no_pend(v) && dsrcs[k] && v->C == dst->C && v->N == dst->N && v->H == dst->H && v->W == dst->W,
+                  "lhn_ew_bwd_multi: source %d must have the destination's geometry", k);
+    m.src[k] = *v;
+    m.dsrc[k] = dsrcs[k];
+    m.acc[k] = accumulate[k];
+    if (bns_of(bns ? bns[k] : nullptr, v, &m.bs[k], "lhn_ew_bwd_multi")) return 1;
+  }
+  hipLaunchKernelGGL(k_ew_bwd_multi, dim3(grid_cap((int64_t)dst->N * dst->H, 8)), dim3(256), 0, (hipStream_t)stream, m, *dst, ddst, dst_dpool, out_slope);
+  LHN_CHECK_LAUNCH("lhn_ew_bwd_multi");
   return 0;
 }
 

@@ -510,6 +510,22 @@ static int run_ops(const Plan* P, int phase, void* ws, void* const* params, void
         } else if (o.i[1] == 2) {     // bilinearly resampled source
           rc = lhn_bilinear_bwd(&src, &d, reinterpret_cast<const float*>(at(ws, db.grad_off)),
                                 reinterpret_cast<float*>(at(ws, P->bufs[o.in_buf[0]].grad_off)), o.i[0], o.f[0], stream);
+        } else if (o.i[1] == 3) {     // 2 or 3 sources of the destination's resolution in one pass: in_buf[0..2]; accumulate flags i[0], i[2],
+                                      // i[3]; their producers' sums ws[0..5], (C, coff) in i[4..7] and f[4..5]
+          lhn_view srcs[3];
+          float* dsrcs[3];
+          int acc[3] = {o.i[0], o.i[2], o.i[3]};
+          lhn_bnsum bsv[3] = {mkbns(ws, o.ws[0], o.ws[1], o.i[4], o.i[5]), mkbns(ws, o.ws[2], o.ws[3], o.i[6], o.i[7]),
+                              mkbns(ws, o.ws[4], o.ws[5], (int)o.f[4], (int)o.f[5])};
+          const lhn_bnsum* bsp[3];
+          int ns = 0;
+          for (; ns < 3 && o.in_buf[ns] >= 0; ++ns) {
+            srcs[ns] = mkview(P, ws, o.in_buf[ns], o.in_coff[ns], o.in_C[ns]);
+            dsrcs[ns] = reinterpret_cast<float*>(at(ws, P->bufs[o.in_buf[ns]].grad_off));
+            bsp[ns] = bsv[ns].sums ? &bsv[ns] : nullptr;
+          }
+          rc = lhn_ew_bwd_multi(srcs, ns, &d, reinterpret_cast<const float*>(at(ws, db.grad_off)),
+                                reinterpret_cast<const float*>(at(ws, db.dpool_off)), o.f[0], dsrcs, acc, bsp, stream);
         } else {
           const lhn_bnsum bs = mkbns(ws, o.ws[0], o.ws[1], o.i[4], o.i[5]);
           rc = lhn_ew_bwd3(&src, &d, reinterpret_cast<const float*>(at(ws, db.grad_off)),

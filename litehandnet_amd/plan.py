@@ -965,6 +965,7 @@ class PlanBuilder:
                         else:
                             body.append(mk(EW_BWD, ins=(s,), out=r["out"], i=(acc,), f=(r["slope"],)))
                 elif k == EW:
+                    todo = []
                     for j, s in enumerate(r["srcs"]):
                         if s.buf == self._no_grad_buf or (s.buf in aliased and self.bufs[s.buf].off["grad"] == self.bufs[r["out"].buf].off["grad"]):
                             continue
@@ -974,7 +975,36 @@ class PlanBuilder:
                             continue                # d(out) joins s's gradient inside the depthwise backward kernels that read s
                         mode = self._grad_mode(written, s)
                         bw, bc = bns_of(r, s)
-                        body.append(mk(EW_BWD, ins=(s,), out=r["out"], ws=bw, i=(1 if mode == 2 else 0, 0, 0, 0, bc[0], bc[1]), f=(r["slope"],)))
+                        todo.append((s, 1 if mode == 2 else 0, bw, bc))
+                    # sources of the destination's own resolution (residual sums) share ONE pass over d(out) / out (lhn_ew_bwd_multi)
+                    o_ = r["out"]
+                    same = [t for t in todo if not isinstance(t[0], TCat) and (t[0].H, t[0].W, t[0].C) == (o_.H, o_.W, o_.C)]
+                    if os.environ.get("LHN_EW_BWD_MULTI", "1") == "0" or len(same) < 2 or r["slope"] in (SLOPE_SILU, SLOPE_RELU_SIGMOID):
+                        same = []
+                    groups, rest_same = [], list(same)
+                    while len(rest_same) >= 2:
+                        take = 3 if len(rest_same) != 4 else 2
+                        groups.append(rest_same[:take])
+                        rest_same = rest_same[take:]
+                    grouped = {id(t[0]) for g in groups for t in g}
+                    for g in groups:
+                        ws_, iv, fv = [], [g[0][1], 3, g[1][1], g[2][1] if len(g) > 2 else 0], [r["slope"], 0.0, 0.0, 0.0, 0.0, 0.0]
+                        cc = []
+                        for q in range(3):
+                            if q < len(g):
+                                ws_ += list(g[q][2])
+                                cc.append(g[q][3])
+                            else:
+                                ws_ += [-1, -1]
+                                cc.append((0, 0))
+                        iv += [cc[0][0], cc[0][1], cc[1][0], cc[1][1]]
+                        fv[4], fv[5] = float(cc[2][0]), float(cc[2][1])
+                        body.append(mk(EW_BWD, ins=tuple(t[0] for t in g), out=o_, ws=tuple(ws_), i=tuple(iv), f=tuple(fv)))
+                        self.ew_bwd_multi = getattr(self, "ew_bwd_multi", 0) + 1
+                    for s, acc, bw, bc in todo:
+                        if id(s) in grouped:
+                            continue
+                        body.append(mk(EW_BWD, ins=(s,), out=o_, ws=bw, i=(acc, 0, 0, 0, bc[0], bc[1]), f=(r["slope"],)))
                 elif k == SHUFFLE:
                     ma = 0 if r["a"].buf == self._no_grad_buf else self._grad_mode(written, r["a"])
                     mb = 0 if r["b"].buf == self._no_grad_buf else self._grad_mode(written, r["b"])

@@ -232,8 +232,10 @@ def test_residual_sum_gradients_ride_in_the_depthwise_backward(monkeypatch):
         assert spans == [(0, 64), (64, 128)] and all(o.i[4] == 1 for o in withadd if o.in_buf[0] == b)
     grads = {cb[j].grad_off for j in range(len(pb.bufs))}
     assert all(o.ws[2] in grads and (o.ws[3] < 0 or o.ws[3] in grads) for o in withadd)
-    n_ew = sum(1 for o in bwd if o.kind == EW_BWD)
+    def slots(ops):         # gradient destinations of the combines' backward ops (a multi-source op, i[1] == 3, writes 2 or 3)
+        return sum((sum(1 for q in range(3) if o.in_buf[q] >= 0) if o.i[1] == 3 else 1) for o in ops if o.kind == EW_BWD)
+    n_ew = slots(bwd)
     monkeypatch.setenv("LHN_GRAD_ADDENDS", "0")
     _, p0, _ = _build("B", backward=True)
     _, _, cbw0, _, nb0 = p0.finalize()
-    assert p0.grad_addends == 0 and sum(1 for i in range(nb0) if cbw0[i].kind == EW_BWD) == n_ew + 6
+    assert p0.grad_addends == 0 and slots([cbw0[i] for i in range(nb0)]) == n_ew + 6
