@@ -239,3 +239,53 @@ def test_residual_sum_gradients_ride_in_the_depthwise_backward(monkeypatch):
     _, p0, _ = _build("B", backward=True)
     _, _, cbw0, _, nb0 = p0.finalize()
     assert p0.grad_addends == 0 and slots([cbw0[i] for i in range(nb0)]) == n_ew + 6
+
+
+def test_pool_gradients_meet_in_one_store(monkeypatch):
+    """The skip tensor of an hourglass level is read by a 2x2 max-pool, an adaptive average pool and the decoder's sum
+    (litehourglass.py:139-163): the max-pool's backward op carries the other two gradients (lhn_grad_adds) and their own backward
+    ops for that view disappear.  LHN_POOL_GRAD_ADDS=0 restores three read-modify-write passes."""
+    from litehandnet_amd.plan import AVGPOOL_BWD, MAXPOOL_BWD
+    monkeypatch.delenv("LHN_POOL_GRAD_ADDS", raising=False)
+    _, pb, _ = _build("B", backward=True)
+    _, _, cbw, _, nb = pb.finalize()
+    bwd = [cbw[i] for i in range(nb)]
+    fused = [o for o in bwd if o.kind == MAXPOOL_BWD and (o.ws[2] >= 0 or o.ws[3] >= 0)]
+    assert pb.pool_grad_adds == len(fused) == 6                       # 2 halves x 3 levels of the hourglass
+    assert all(o.ws[2] >= 0 for o in fused)                           # every level has the decoder's sum
+    assert sum(1 for o in fused if o.ws[3] >= 0) == 2                 # ... and the top level the 8x8 average pool
+    grads = {pb.bufs[j].off["grad"] for j in range(len(pb.bufs)) if "grad" in pb.bufs[j].off}
+    assert all(o.ws[2] in grads and (o.ws[3] < 0 or o.ws[3] in grads) for o in fused)
+    assert all((o.i[7] >> 16, o.i[7] & 0xffff) == (8, 8) for o in fused if o.ws[3] >= 0)
+    n_ap, n_mp = sum(1 for o in bwd if o.kind == AVGPOOL_BWD), sum(1 for o in bwd if o.kind == MAXPOOL_BWD)
+    monkeypatch.setenv("LHN_POOL_GRAD_ADDS", "0")
+    _, p0, _ = _build("B", backward=True)
+    _, _, cbw0, _, nb0 = p0.finalize()
+    bwd0 = [cbw0[i] for i in range(nb0)]
+    assert p0.pool_grad_adds == 0 and not [o for o in bwd0 if o.kind == MAXPOOL_BWD and (o.ws[2] >= 0 or o.ws[3] >= 0)]
+    assert sum(1 for o in bwd0 if o.kind == AVGPOOL_BWD) == n_ap + 2 and sum(1 for o in bwd0 if o.kind == MAXPOOL_BWD) == n_mp
+    assert len(bwd0) == len(bwd) + 2 + 6                              # two average-pool and six sum-source passes more
+
+
+def test_residual_sums_share_one_backward_pass(monkeypatch):
+    """Sources of a combine that have its own resolution get their gradient in ONE op (lhn_ew_bwd_multi, i[1] == 3) instead of one
+    op per source; upsampled sources keep their own."""
+    from litehandnet_amd.plan import EW_BWD
+    monkeypatch.delenv("LHN_EW_BWD_MULTI", raising=False)
+    for variant, groups in (("A", 21), ("M", 19)):
+        _, pb, _ = _build(variant, backward=True)
+        _, _, cbw, _, nb = pb.finalize()
+        multi = [cbw[i] for i in range(nb) if cbw[i].kind == EW_BWD and cbw[i].i[1] == 3]
+        assert pb.ew_bwd_multi == len(multi) == groups
+        for o in multi:
+            srcs = [q for q in range(3) if o.in_buf[q] >= 0]
+            assert len(srcs) >= 2
+            ob = pb.bufs[o.out_buf]
+            assert all((pb.bufs[o.in_buf[q]].H, pb.bufs[o.in_buf[q]].W, o.in_C[q]) == (ob.H, ob.W, o.out_C) for q in srcs)
+        monkeypatch.setenv("LHN_EW_BWD_MULTI", "0")
+        _, p0, _ = _build(variant, backward=True)
+        _, _, cbw0, _, nb0 = p0.finalize()
+        assert not [1 for i in range(nb0) if cbw0[i].kind == EW_BWD and cbw0[i].i[1] == 3]
+        assert nb0 == nb + sum(len([q for q in range(3) if o.in_buf[q] >= 0]) - 1 for o in multi)
+        monkeypatch.delenv("LHN_EW_BWD_MULTI")
+
